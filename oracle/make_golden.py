@@ -1,0 +1,395 @@
+"""ORACLE tooling: generate tests/golden/*.npz by running the REFERENCE's own modules.
+
+Runs only in the build container (needs /root/reference).  Imports the reference
+read-only: `sys.dont_write_bytecode` is set before any reference import, nothing
+is copied, only INPUT/OUTPUT tensors are written out as fixtures.
+
+Unavailable third-party packages are replaced by in-memory stubs (ours, below):
+  torchvision.models._utils.IntermediateLayerGetter  (feature_extractor.py:4,48)
+  torchvision.models.utils.load_state_dict_from_url  (resnet.py:3, never reached)
+  mmcv.runner.load_checkpoint                        (resnet.py:2, never reached: pretrained=False)
+  torchvision.transforms                              (utility.py:14, unused on this path)
+Network-fetching loaders (MODEL.WEIGHTS URL) are never called: models are built
+with pretrained_backbone=False and filled with formula weights
+(rnd_semantic_segmentation_amd/host/synth.py), which the tests regenerate.
+
+Usage:  python oracle/make_golden.py [--out tests/golden] [--skip-big]
+"""
+import sys
+
+sys.dont_write_bytecode = True
+
+import argparse
+import hashlib
+import json
+import os
+import types
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+from rnd_semantic_segmentation_amd.host import synth  # noqa: E402
+
+
+# ------------------------------------------------------------------ stubs (ours)
+class IntermediateLayerGetter(nn.ModuleDict):
+    """Stand-in for torchvision's: keep children up to the last requested layer,
+    run them in order, return {alias: activation}."""
+
+    def __init__(self, model, return_layers):
+        wanted = dict(return_layers)
+        kept = OrderedDict()
+        pending = set(wanted)
+        for name, child in model.named_children():
+            kept[name] = child
+            pending.discard(name)
+            if not pending:
+                break
+        super().__init__(kept)
+        self.return_layers = wanted
+
+    def forward(self, x):
+        out = OrderedDict()
+        for name, child in self.items():
+            x = child(x)
+            if name in self.return_layers:
+                out[self.return_layers[name]] = x
+        return out
+
+
+def _offline(*a, **k):
+    raise RuntimeError("offline: no fetch")
+
+
+def install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    tv = mod("torchvision")
+    tv.models = mod("torchvision.models")
+    tv.models._utils = mod("torchvision.models._utils", IntermediateLayerGetter=IntermediateLayerGetter)
+    tv.models.utils = mod("torchvision.models.utils", load_state_dict_from_url=_offline)
+    tv.transforms = mod("torchvision.transforms")
+    mm = mod("mmcv")
+    mm.runner = mod("mmcv.runner", load_checkpoint=_offline)
+
+
+def import_reference():
+    install_stubs()
+    sys.path.insert(0, REF)
+    from core.components import resnet as ref_resnet
+    from core.components.layers import FrozenBatchNorm2d
+    from core.models.feature_extractor import resnet_feature_extractor
+    from core.models.classifiers.aspp.classifier import ASPP_Classifier_V2
+    from core.utils.adapt_lr import adjust_learning_rate
+    from core.utils import utility as ref_utility
+
+    # extra tiny architecture registered at run time (no file is modified):
+    def resnet_tiny(pretrained=False, progress=True, pretrained_weights=None, **kw):
+        return ref_resnet._resnet("resnet_tiny", ref_resnet.Bottleneck, [1, 1, 2, 2], pretrained, progress,
+                                  pretrained_weights, **kw)
+
+    ref_resnet.__dict__["resnet_tiny"] = resnet_tiny
+    return types.SimpleNamespace(resnet=ref_resnet, FrozenBN=FrozenBatchNorm2d, fe=resnet_feature_extractor,
+                                 ASPP=ASPP_Classifier_V2, adjust_lr=adjust_learning_rate, util=ref_utility)
+
+
+# ------------------------------------------------------------------ helpers
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def save(out, name, **arrays):
+    path = os.path.join(out, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print("  wrote %-28s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+def bf16(a):
+    return synth.bf16_round(np.asarray(a, np.float32))
+
+
+# ------------------------------------------------------------------ G1 conv ops
+def g_conv(ref, out):
+    """reference resnet.py:22-30 conv3x3 / conv1x1 (+ stride-2 cases of layer2.0),
+    forward + autograd backward, on bf16-representable operands."""
+    cases = [  # name, cin, cout, H, W, k, stride, dil
+        ("d1", 64, 64, 13, 11, 3, 1, 1),
+        ("d2", 64, 128, 17, 15, 3, 1, 2),
+        ("d4", 128, 64, 12, 14, 3, 1, 4),
+        ("p1", 128, 64, 9, 10, 1, 1, 1),
+        ("s2", 64, 64, 13, 12, 3, 2, 1),
+        ("p1s2", 64, 128, 13, 12, 1, 2, 1),
+    ]
+    for name, ci, co, H, W, k, s, d in cases:
+        arrays = {}
+        conv = ref.resnet.conv3x3(ci, co, stride=s, dilation=d) if k == 3 else ref.resnet.conv1x1(ci, co, stride=s)
+        w = bf16(synth.formula_tensor("g1.%s.weight" % name, conv.weight.shape))
+        x = bf16(synth.uniform("g1.%s.x" % name, (2, ci, H, W)) * 4)
+        conv.weight.data.copy_(t(w))
+        xt = t(x).requires_grad_(True)
+        y = conv(xt)
+        dy = bf16(synth.uniform("g1.%s.dy" % name, tuple(y.shape)) * 2)
+        y.backward(t(dy))
+        # inputs are regenerated by the tests from the same formulas (conv_case_inputs below)
+        arrays.update({"meta": np.array([ci, co, H, W, k, s, d]), "y": y.detach().numpy(),
+                       "dx": xt.grad.numpy(), "dw": conv.weight.grad.numpy(),
+                       "in_sha": np.array(sha(x) + sha(w) + sha(dy))})
+        save(out, "g1_conv_" + name, **arrays)
+
+
+# ------------------------------------------------------------------ G2/G3 ASPP head + upsample + CE
+def g_aspp(ref, out):
+    """reference classifier.py:6-32 (C_in=64 instance of the same class), upsample to a
+    non-integer-scale size, CrossEntropyLoss(ignore_index=255) as aspp_trainer.py:61,91."""
+    B, C, H, W, K = 2, 64, 33, 29, 19
+    size = (65, 57)
+    head = ref.ASPP(C, [6, 12, 18, 24], [6, 12, 18, 24], K)
+    ws, bs = [], []
+    for i, m in enumerate(head.conv2d_list):
+        w = bf16(synth.formula_tensor("conv2d_list.%d.weight" % i, m.weight.shape) * 4)
+        b = synth.formula_tensor("conv2d_list.%d.bias" % i, m.bias.shape)
+        m.weight.data.copy_(t(w))
+        m.bias.data.copy_(t(b))
+        ws.append(w)
+        bs.append(b)
+    x = bf16(np.maximum(synth.uniform("g2.x", (B, C, H, W)) * 4, 0))
+    lab = synth.synth_label(B, size[0], size[1], K, seed=7)
+    xt = t(x).requires_grad_(True)
+    low = head(xt)
+    low.retain_grad()
+    up = head(xt, size)  # same call the trainer makes (classifier.py:26-32)
+    up.retain_grad()
+    loss = nn.CrossEntropyLoss(ignore_index=255)(up, t(lab).long())
+    loss.backward()
+    # gradient of the upsample alone
+    low2 = low.detach().clone().requires_grad_(True)
+    up2 = F.interpolate(low2, size=size, mode="bilinear", align_corners=True)
+    up2.backward(up.grad)
+    save(out, "g2_aspp", in_sha=np.array(sha(x) + sha(np.stack(ws)) + sha(np.stack(bs)) + sha(lab)), size=np.array(size),
+         low=low.detach().numpy(), up_sub=up.detach().numpy()[:, :, ::3, ::3], loss=loss.item(),
+         dup_sub=up.grad.numpy()[:, :, ::3, ::3], dlow=low2.grad.numpy(), dx=xt.grad.numpy(),
+         dw=np.stack([m.weight.grad.numpy() for m in head.conv2d_list]),
+         db=np.stack([m.bias.grad.numpy() for m in head.conv2d_list]))
+    # edge cases: integer scale 17->129, every label ignored
+    low3 = synth.uniform("g3.low", (1, K, 17, 17)).astype(np.float32) * 6
+    up3 = F.interpolate(t(low3), size=(129, 129), mode="bilinear", align_corners=True)
+    lab3 = synth.synth_label(1, 129, 129, K, seed=3)
+    l3 = F.cross_entropy(up3, t(lab3).long(), ignore_index=255)
+    lab_all = np.full((1, 129, 129), 255, np.float32)
+    l_all = F.cross_entropy(up3, t(lab_all).long(), ignore_index=255)
+    up3r = up3.clone().requires_grad_(True)
+    F.cross_entropy(up3r, t(lab3).long(), ignore_index=255).backward()
+    save(out, "g3_upsample_ce", in_sha=np.array(sha(low3) + sha(lab3)), up_sub=up3.numpy()[:, :, ::5, ::3], loss=l3.item(),
+         dup_sub=up3r.grad.numpy()[:, :, ::5, ::3], loss_all_ignored=l_all.item())
+
+
+# ------------------------------------------------------------------ G4 FrozenBN
+def g_frozenbn(ref, out):
+    n = 96
+    bn = ref.FrozenBN(n)
+    sd = {k: t(synth.formula_tensor("layer9.0.bn2." + k, (n,))) for k in ("weight", "bias", "running_mean", "running_var")}
+    bn.load_state_dict(sd)
+    x = synth.uniform("g4.x", (2, n, 5, 7)).astype(np.float32) * 3
+    save(out, "g4_frozenbn", x=x, y=bn(t(x)).numpy(), **{k: v.numpy() for k, v in sd.items()})
+
+
+# ------------------------------------------------------------------ G5 tiny net train steps (+G9 bf16 autocast)
+def build_ref_net(ref, arch):
+    fe = ref.fe(arch, pretrained_weights=None, aux=False, pretrained_backbone=False, freeze_bn=True)
+    cls = ref.ASPP(2048, [6, 12, 18, 24], [6, 12, 18, 24], 19)
+    synth.load_formula_weights(fe)
+    synth.load_formula_weights(cls)
+    return fe, cls
+
+
+def train_steps(ref, fe, cls, x, lab, steps, base_lr, max_iter, autocast=False):
+    """reference aspp_trainer.py:25-26, 61, 77-97, verbatim order of operations."""
+    opt_fea = torch.optim.SGD(fe.parameters(), lr=base_lr, momentum=0.9, weight_decay=5e-4)
+    opt_cls = torch.optim.SGD(cls.parameters(), lr=base_lr * 10, momentum=0.9, weight_decay=5e-4)
+    crit = nn.CrossEntropyLoss(ignore_index=255)
+    fe.train()
+    cls.train()
+    rec = dict(loss=[], lr=[])
+    first = {}
+    for it in range(steps):
+        lr = ref.adjust_lr("poly", base_lr, it, max_iter, power=0.9)
+        for g in opt_fea.param_groups:
+            g["lr"] = lr
+        for g in opt_cls.param_groups:
+            g["lr"] = lr * 10
+        opt_fea.zero_grad()
+        opt_cls.zero_grad()
+        label = t(lab).long()
+        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+            feat = fe(t(x))
+            outp = cls(feat, label.shape[-2:])
+        loss = crit(outp.float(), label)
+        loss.backward()
+        if it == 0:
+            first["feat"] = feat.detach().float().numpy()
+            with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+                first["low"] = cls(feat).float().numpy()
+            first["grads"] = {k: p.grad.detach().clone().numpy() for m in (fe, cls) for k, p in m.named_parameters()}
+        opt_fea.step()
+        opt_cls.step()
+        rec["loss"].append(loss.item())
+        rec["lr"].append(lr)
+    return rec, first
+
+
+def g_tinynet(ref, out):
+    B, S = 2, 65
+    x = synth.synth_image(B, S, S, seed=11)
+    lab = synth.synth_label(B, S, S, 19, seed=11)
+    fe, cls = build_ref_net(ref, "resnet_tiny")
+    keys = list(fe.state_dict().keys()) + list(cls.state_dict().keys())
+    rec, first = train_steps(ref, fe, cls, x, lab, steps=3, base_lr=5e-4, max_iter=30)
+    arrays = dict(x_seed=11, loss=np.array(rec["loss"]), lr=np.array(rec["lr"]), low=first["low"],
+                  feat_crop=first["feat"][:, :64, :, :].copy(), feat_absmax=np.abs(first["feat"]).max())
+    gn, gcrop, pn = {}, {}, {}
+    for k, g in first["grads"].items():
+        gn[k] = float(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        gcrop[k] = g.reshape(-1)[:16].copy()
+    for m in (fe, cls):
+        for k, p in m.named_parameters():
+            pn[k] = float(p.detach().double().norm())
+    names = sorted(gn)
+    arrays.update(param_names=np.array(names), grad_norm=np.array([gn[k] for k in names]),
+                  grad_crop=np.stack([gcrop[k] for k in names]), param_norm_after=np.array([pn[k] for k in names]))
+    # a few full tensors after 3 steps, to check the SGD update exactly
+    arrays["after_aspp0_bias"] = cls.conv2d_list[0].bias.detach().numpy()
+    arrays["after_l4_1_conv2_crop"] = fe.backbone["layer4"][1].conv2.weight.detach().numpy()[:8, :8]
+    save(out, "g5_tinynet_fp32", **arrays)
+    with open(os.path.join(out, "g8_tinynet_keys.json"), "w") as f:
+        json.dump(keys, f)
+
+    # G9: same net under CPU bf16 autocast (regime reference for the bf16 GPU path; loose pin)
+    fe, cls = build_ref_net(ref, "resnet_tiny")
+    rec, first = train_steps(ref, fe, cls, x, lab, steps=1, base_lr=5e-4, max_iter=30, autocast=True)
+    save(out, "g9_tinynet_bf16", loss=np.array(rec["loss"]), low=first["low"])
+
+
+# ------------------------------------------------------------------ G6 full R101
+def g_r101(ref, out, big):
+    fe, cls = build_ref_net(ref, "resnet101")
+    fe.eval()
+    cls.eval()
+    sd_keys = list(fe.state_dict().keys()) + list(cls.state_dict().keys())
+    with open(os.path.join(out, "g8_r101_keys.json"), "w") as f:
+        json.dump({"keys": sd_keys, "n_fe_params": sum(p.numel() for p in fe.parameters()),
+                   "n_cls_params": sum(p.numel() for p in cls.parameters())}, f)
+    x = synth.synth_image(1, 129, 129, seed=21)
+    lab = synth.synth_label(1, 129, 129, 19, seed=21)
+    xt = t(x)
+    feat = fe(xt)
+    low = cls(feat)
+    up = cls(feat, (129, 129))
+    loss = F.cross_entropy(up, t(lab).long(), ignore_index=255)
+    loss.backward()
+    gn = {k: float(p.grad.double().norm()) for m in (fe, cls) for k, p in m.named_parameters()}
+    stage = {}
+    for k, v in gn.items():
+        s = k.split(".")[1] if k.startswith("backbone.") else "aspp"
+        stage[s] = float(np.sqrt(stage.get(s, 0.0) ** 2 + v ** 2))
+    probs = ref.util.inference(fe, cls, xt, t(lab), flip=False)  # utility.py:179-191
+    pred = probs.max(1)[1]
+    save(out, "g6_r101_129", low=low.detach().numpy(), feat_crop=feat.detach().numpy()[0, :32, :8, :8],
+         feat_absmax=feat.abs().max().item(), loss=loss.item(), argmax_sha=sha(up.argmax(1).numpy().astype(np.uint8)),
+         stage_names=np.array(sorted(stage)), stage_grad_norm=np.array([stage[k] for k in sorted(stage)]),
+         probs_crop=probs.numpy()[0, :, :16, :16], pred=pred.numpy().astype(np.uint8))
+    if big:
+        # BASELINE config[0]: one 512x1024 image on CPU through the test path.
+        x = synth.synth_image(1, 512, 1024, seed=31)
+        lab = synth.synth_label(1, 512, 1024, 19, seed=31)
+        with torch.no_grad():
+            low = cls(fe(t(x)))
+        probs = ref.util.inference(fe, cls, t(x), t(lab), flip=False)
+        pred = probs.max(1)[1].numpy().astype(np.uint8)
+        save(out, "g6_r101_512x1024", low_crop=low.numpy()[0, :, :16, :32], low_absmax=low.abs().max().item(),
+             low_sum=low.double().sum().item(), pred_sha=sha(pred), pred_crop=pred[0, 200:232, 400:464],
+             probs_crop=probs.numpy()[0, :, 250:258, 500:508])
+
+
+# ------------------------------------------------------------------ G7 metrics, LR, SGD, misc utils
+def g_metrics(ref, out):
+    K = 19
+    H, W = 40, 56
+    target = synth.synth_label(1, H, W, K, seed=5)[0].astype(np.int64)
+    pred = target.copy()
+    flip = synth.hash_u32("g7.flip", H * W).reshape(H, W) % np.uint64(3) == 0
+    pred[flip] = (synth.hash_u32("g7.pred", H * W).reshape(H, W) % np.uint64(K)).astype(np.int64)[flip]
+    pred[pred == 255] = 0
+    iu = ref.util.intersectionAndUnion(pred.copy(), target, K, 255)  # utility.py:133-145 (numpy twin of :148-161)
+    meter = ref.util.AverageMeter()
+    meter.update(*[a.astype(np.float64) for a in iu])
+    t2 = np.roll(target, 7, axis=1)
+    iu2 = ref.util.intersectionAndUnion(pred.copy(), t2, K, 255)
+    meter.update(*[a.astype(np.float64) for a in iu2])
+    logged = []
+
+    class L:
+        def info(self, s):
+            logged.append(s)
+
+    meter.summary(L(), K)
+    cfg = types.SimpleNamespace(MODEL=types.SimpleNamespace(NUM_CLASSES=K))
+    small_p, small_t = pred[:6, :9].reshape(-1), target[:6, :9].reshape(-1)
+    cmt = ref.util.confusion_matrix(cfg, t(small_p), t(small_t))  # utility.py:347-359 (python loop)
+    lrs = [ref.adjust_lr("poly", 5e-4, it, 1000, power=0.9) for it in (0, 1, 17, 500, 999)]
+    # torch.optim.SGD exactly as configured in aspp_trainer.py:25-26
+    p0 = synth.uniform("g7.p", (257,)).astype(np.float32)
+    p = torch.nn.Parameter(t(p0.copy()))
+    opt = torch.optim.SGD([p], lr=0.01, momentum=0.9, weight_decay=5e-4)
+    ps, gs = [], []
+    for s in range(3):
+        g = synth.uniform("g7.g%d" % s, (257,)).astype(np.float32)
+        p.grad = t(g.copy())
+        opt.param_groups[0]["lr"] = 0.01 * (s + 1)
+        opt.step()
+        gs.append(g)
+        ps.append(p.detach().numpy().copy())
+    sdk = ref.util.strip_prefix_if_present(OrderedDict(a=1, b=2), "module.")
+    save(out, "g7_metrics", pred=pred, target=target, target2=t2, iu=np.stack(iu), iu2=np.stack(iu2),
+         summary=np.array(logged), cmt=cmt.numpy(), small_p=small_p, small_t=small_t, lr_iters=np.array([0, 1, 17, 500, 999]),
+         lrs=np.array(lrs), sgd_p0=p0, sgd_g=np.stack(gs), sgd_p=np.stack(ps), sgd_lrs=np.array([0.01, 0.02, 0.03]),
+         strip_keys=np.array(list(sdk.keys())))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--skip-big", action="store_true")
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    ref = import_reference()
+    jobs = dict(conv=lambda: g_conv(ref, args.out), aspp=lambda: g_aspp(ref, args.out),
+                frozenbn=lambda: g_frozenbn(ref, args.out), tinynet=lambda: g_tinynet(ref, args.out),
+                r101=lambda: g_r101(ref, args.out, not args.skip_big), metrics=lambda: g_metrics(ref, args.out))
+    for name, fn in jobs.items():
+        if args.only and name not in args.only.split(","):
+            continue
+        print("[golden]", name)
+        fn()
+    assert not any(d == "__pycache__" for _, ds, _ in os.walk(REF) for d in ds), "bytecode leaked into reference"
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,136 @@
+"""Deterministic, RNG-free synthetic weights / images / labels.
+
+There is no network in the build or on the GPU box, so ImageNet weights
+(`MODEL.WEIGHTS` URL in the reference's YAMLs, reference
+core/components/resnet.py:211-215) and Cityscapes/GTA5 images are unavailable.
+Everything here is a pure function of (tensor name, element index) computed in
+integer arithmetic, so the golden-fixture generator (which runs the reference
+model in the build container) and the GPU box regenerate bit-identical
+tensors without shipping 170 MB of weights.
+
+Tensor contract of the data side follows reference
+core/datasets/transform.py:31-46 and core/configs/defaults.py:21-24:
+image f32 [3,H,W] already mean/std normalised, label f32 [H,W] holding
+train-ids 0..K-1 and 255 (ignore).
+"""
+import zlib
+
+import numpy as np
+
+_M32 = np.uint64(0xFFFFFFFF)
+
+
+def _mix32(x):
+    """murmur3 finaliser on uint64 arrays holding 32-bit values."""
+    x = x & _M32
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x85EBCA6B)) & _M32
+    x ^= x >> np.uint64(13)
+    x = (x * np.uint64(0xC2B2AE35)) & _M32
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def hash_u32(name, n, salt=0):
+    """n pseudo-random uint32 values, a pure function of (name, salt, index)."""
+    seed = np.uint64((zlib.crc32(name.encode()) ^ (salt * 0x9E3779B1)) & 0xFFFFFFFF)
+    idx = np.arange(n, dtype=np.uint64)
+    return _mix32(_mix32(idx + seed) ^ (seed * np.uint64(0x27D4EB2F) & _M32))
+
+
+def uniform(name, shape, salt=0):
+    """float64 uniform in [-0.5, 0.5), exact dyadic rationals (k/2^32 - 0.5)."""
+    n = int(np.prod(shape))
+    u = hash_u32(name, n, salt).astype(np.float64) / 4294967296.0 - 0.5
+    return u.reshape(shape)
+
+
+_SQRT12 = 3.4641016151377544
+
+
+def formula_tensor(key, shape):
+    """Value of state_dict entry `key` (float32 numpy).
+
+    conv weights : uniform, std = sqrt(2 / fan_in)   (keeps post-ReLU second moment ~1)
+    ASPP weights : uniform, std = 0.01               (reference classifier.py:23-24 uses N(0,0.01))
+    FrozenBN     : weight 0.25 for the last BN of a residual branch and 0.5 for a
+                   downsample BN, else 1 (all +-5 %); bias, running_mean small;
+                   running_var in [0.8, 1.2]  -> exercises the no-eps rsqrt of
+                   reference core/components/layers.py:18-23 without blowing up.
+    """
+    shape = tuple(int(s) for s in shape)
+    u = uniform(key, shape)
+    if key.startswith("conv2d_list."):
+        if key.endswith(".weight"):
+            return (u * _SQRT12 * 0.01).astype(np.float32)
+        return (u * 0.2).astype(np.float32)  # bias
+    if key.endswith("num_batches_tracked"):
+        return np.zeros(shape, np.int64)
+    leaf = key.rsplit(".", 1)[-1]
+    parent = key.rsplit(".", 1)[0]
+    is_bn = parent.rsplit(".", 1)[-1].startswith("bn") or ".downsample.1" in key
+    if is_bn:
+        if leaf == "weight":
+            base = 0.25 if parent.endswith("bn3") else (0.5 if ".downsample.1" in key else 1.0)
+            return (base * (1.0 + 0.1 * u)).astype(np.float32)
+        if leaf == "bias":
+            return (0.1 * u).astype(np.float32)
+        if leaf == "running_mean":
+            return (0.2 * u).astype(np.float32)
+        if leaf == "running_var":
+            return (1.0 + 0.4 * u).astype(np.float32)
+    if leaf == "weight" and len(shape) == 4:
+        fan_in = shape[1] * shape[2] * shape[3]
+        return (u * _SQRT12 * np.sqrt(2.0 / fan_in)).astype(np.float32)
+    if leaf == "weight" and len(shape) == 2:
+        return (u * _SQRT12 * np.sqrt(1.0 / shape[1])).astype(np.float32)
+    return (0.1 * u).astype(np.float32)
+
+
+def load_formula_weights(module, prefix=""):
+    """Fill every parameter and buffer of `module` with formula_tensor(prefix+key)."""
+    import torch
+
+    sd = module.state_dict()
+    new = {}
+    for k, v in sd.items():
+        t = torch.from_numpy(formula_tensor(prefix + k, v.shape))
+        new[k] = t.to(v.dtype)
+    module.load_state_dict(new)
+    return module
+
+
+def synth_image(batch, height, width, seed=1234):
+    """float32 [B,3,H,W], ~N(0,1)-ish (sum of 4 uniforms), post-normalisation statistics."""
+    shape = (batch, 3, height, width)
+    acc = np.zeros(shape, np.float64)
+    for s in range(4):
+        acc += uniform("image", shape, salt=seed * 4 + s)
+    return (acc * (_SQRT12 / 2.0)).astype(np.float32)
+
+
+def synth_label(batch, height, width, num_classes=19, seed=1234, ignore=255, border=None):
+    """float32 [B,H,W] train-ids (as the reference loader yields floats,
+    core/datasets/cityscapes.py:137-151) in blocky regions, with an ignore
+    border band and ~2 % scattered ignore pixels."""
+    if border is None:
+        border = max(1, min(height, width) // 24)
+    cell = max(4, min(height, width) // 12)
+    gh, gw = -(-height // cell), -(-width // cell)
+    grid = hash_u32("label_grid", batch * gh * gw, salt=seed).reshape(batch, gh, gw) % np.uint64(num_classes)
+    lab = np.repeat(np.repeat(grid, cell, axis=1), cell, axis=2)[:, :height, :width].astype(np.float32)
+    noise = hash_u32("label_noise", batch * height * width, salt=seed).reshape(batch, height, width)
+    lab[(noise % np.uint64(50)) == 0] = ignore
+    lab[:, :border, :] = ignore
+    lab[:, -border:, :] = ignore
+    lab[:, :, :border] = ignore
+    lab[:, :, -border:] = ignore
+    return lab
+
+
+def bf16_round(a):
+    """Round float32 numpy array to the nearest bf16 (ties to even), returned as float32."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    u = a.view(np.uint32).astype(np.uint64)
+    r = ((u + np.uint64(0x7FFF) + ((u >> np.uint64(16)) & np.uint64(1))) >> np.uint64(16)) << np.uint64(16)
+    return (r & _M32).astype(np.uint32).view(np.float32).reshape(a.shape)
