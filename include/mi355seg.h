@@ -1,0 +1,150 @@
+/* mi355seg.h — C-ABI of libmi355seg.so (MI355X / gfx950 only).
+ *
+ * The reference (taintpro98/rnd-semantic-segmentation) has no FFI: its hot path is
+ * Python calling torch ops.  This header DEFINES the boundary underneath the
+ * reference's Python class surface.  Every entry point names the
+ * reference call it replaces.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *  - plain pointers + sizes, no torch types.  All pointers are DEVICE pointers
+ *    unless a parameter says "host".  The caller owns every buffer, including
+ *    workspaces (query sizes with the *_workspace functions).
+ *  - activations are NHWC ("channels_last") bf16: x[b][h][w][c]; a GEMM row m is
+ *    the pixel (b,h,w).  Logits / losses / gradients of parameters are fp32.
+ *  - master weights are fp32 in torch's OIHW layout; kernels consume bf16 packed
+ *    copies produced by mi_pack_*.
+ *  - every function enqueues on `stream` (a hipStream_t passed as void*) and
+ *    never synchronises, allocates or frees: safe under HIP graph capture.
+ *  - return 0 on success, a negative MI_E* code otherwise; mi_last_error()
+ *    returns a thread-local message.  Nothing throws.  Re-entrant.
+ */
+#ifndef MI355SEG_H
+#define MI355SEG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355SEG_VERSION 100
+
+#define MI_OK 0
+#define MI_EINVAL (-22)   /* bad shape / alignment / null pointer */
+#define MI_ENOMEM (-12)   /* workspace too small */
+#define MI_EHIP (-5)      /* HIP launch error */
+
+/* epilogue flags of mi_conv_gemm (applied in this order on the fp32 accumulator) */
+#define MI_EPI_SCALE_BIAS 1  /* v = v*scale[n] + bias[n]      FrozenBatchNorm2d, reference core/components/layers.py:18-23 */
+#define MI_EPI_RESIDUAL 2    /* v += res[m][n]                 `out += identity`, reference core/components/resnet.py:110 */
+#define MI_EPI_RELU 4        /* v = max(v,0)                   resnet.py:95,99,111 */
+#define MI_EPI_MASK 8        /* v = msk[m][n] > 0 ? v : 0      ReLU backward of the producer of msk */
+#define MI_EPI_OUT_F32 16    /* store fp32 instead of bf16 */
+#define MI_EPI_ZSPLIT 32     /* fp32 store to [n/zgw][M][zgw] (ASPP tap planes) */
+
+/* gather modes */
+#define MI_GATHER_FWD 0      /* src = out*stride + tap*dil - pad            (forward conv, wgrad) */
+#define MI_GATHER_DGRAD 1    /* src = (out + pad - tap*dil)/stride if exact (data gradient)       */
+
+int mi_version(void);
+const char* mi_last_error(void);
+
+/* ---- weight packing (fp32 OIHW master -> bf16 GEMM operand) ------------------------------- */
+/* wp[t][o][i] = bf16(w[o][i][t]),  t = ky*k+kx.  Operand of the forward conv. */
+int mi_pack_weight_fwd(const float* w_oihw, void* wp_bf16, int O, int I, int ksize, void* stream);
+/* wp[t][i][o] = bf16(w[o][i][t] * (scale ? scale[o] : 1)).  Operand of the data gradient; the
+ * FrozenBN scale of the conv's output channel is folded in (scale is a constant buffer). */
+int mi_pack_weight_dgrad(const float* w_oihw, const float* scale_o, void* wp_bf16, int O, int I, int ksize, void* stream);
+
+/* ---- implicit-GEMM convolution, MFMA bf16 -> fp32 accumulate ----------------------------------
+ * Replaces nn.Conv2d forward and the data-gradient half of convolution_backward for every
+ * conv of reference core/components/resnet.py:22-30 (conv3x3 with dilation, conv1x1) and, through
+ * the fused epilogue, the FrozenBN / ReLU / residual that follow it (resnet.py:93-113).
+ *   out[b][ho][wo][n] = epi( sum_{t,c} a[b][src_h(ho,t)][src_w(wo,t)][c] * wp[t][n][c] )
+ * a: [B][Ha][Wa][Ca] bf16, wp: [k*k][N][Ca] bf16, out: [B][Ho][Wo][N] bf16 (or fp32).
+ * Requirements: Ca % 64 == 0, N % 4 == 0, 16-byte aligned pointers. */
+int mi_conv_gemm(const void* a, const void* wp, void* out,
+                 int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N,
+                 int ksize, int stride, int pad, int dil, int gather_mode,
+                 const float* scale, const float* bias, const void* res, const void* msk,
+                 int flags, int zgw, void* stream);
+
+/* ---- weight gradient (contraction over pixels), split-K with deterministic reduction ------------
+ * Replaces the weight-gradient half of convolution_backward.
+ *   dw[o][i][t] (+)= scale[o] * sum_m dy[m][o] * x[src(m,t)][i]
+ * dy: [B][Ho][Wo][O] bf16, x: [B][Ha][Wa][I] bf16, dw: fp32 OIHW.  O % 8 == 0, I % 8 == 0.
+ * out_map 0: OIHW as above.  out_map 1 (ASPP): ksize must be 1 and o = (br*9+tap)*19+cls is scattered to
+ * dw[br][cls][i][tap] of the 4 stacked [19][I][3][3] tensors. */
+size_t mi_conv_wgrad_workspace(int B, int Ho, int Wo, int O, int I, int ksize);
+int mi_conv_wgrad(const void* dy, const void* x, float* dw,
+                  int B, int Ha, int Wa, int I, int Ho, int Wo, int O,
+                  int ksize, int stride, int pad, int dil,
+                  const float* scale_o, int accumulate, int out_map,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- ASPP head (reference core/models/classifiers/aspp/classifier.py:6-32) ---------------------
+ * forward:  Z = X * Wall^T as ONE plain GEMM (mi_conv_gemm, ksize 1, MI_EPI_ZSPLIT, zgw 20) over all
+ * 4 rates x 9 taps x 19 classes, then mi_aspp_col2im sums the 36 shifted planes (+ the 4 biases):
+ *   low[b][h][w][n] = sum_r bias[r][n] + sum_{r,ky,kx} Z[r*9+ky*3+kx][b][h+(ky-1)d_r][w+(kx-1)d_r][n]
+ * which is exactly out = conv_0(x); out += conv_i(x) (classifier.py:27-29) re-associated.
+ * backward: mi_aspp_im2col builds G[m][(r*9+t)*19+n] = dlow[m - shift][n]; then dX = G * Wall (mi_conv_gemm),
+ * dWall = G^T X (mi_conv_wgrad, out_map 1), dbias = column sums of dlow. */
+#define MI_ASPP_NRATES 4
+#define MI_ASPP_ZGW 20          /* classes padded 19 -> 20 per tap plane */
+#define MI_ASPP_KPAD 704        /* 36*19 = 684 padded to a multiple of 64 */
+/* wall[(g*20+n)][c] = bf16(w[r][n][c][tap]), g = r*9+tap; row n==19 of each plane is zero.  [720][C] */
+int mi_aspp_pack_fwd(const float* w4 /*[4][K][C][3][3]*/, void* wall_bf16, int C, int K, void* stream);
+/* wallT[c][g*K+n] = bf16(w[r][n][c][tap]); columns >= 36*K are zero.  [C][704] */
+int mi_aspp_pack_dgrad(const float* w4, void* wallT_bf16, int C, int K, void* stream);
+int mi_aspp_col2im(const float* z /*[36][M][20]*/, const float* bias4 /*[4][K]*/, float* low /*[B][H][W][K]*/,
+                   int B, int H, int W, int K, const int* rates4 /*host*/, void* stream);
+/* g[m][k] bf16, k = (r*9+t)*K+n, columns >= 36*K zero */
+int mi_aspp_im2col(const float* dlow /*[B][H][W][K]*/, void* g_bf16 /*[M][704]*/,
+                   int B, int H, int W, int K, const int* rates4 /*host*/, void* stream);
+int mi_aspp_bias_grad(const float* dlow, float* dbias4 /*[4][K]*/, int M, int K, int accumulate, void* stream);
+
+/* ---- bilinear upsample, align_corners=True (classifier.py:31, core/utils/utility.py:185) --------
+ * low: [B][h][w][K] fp32 NHWC, up: [B][K][H][W] fp32 NCHW (the layout the reference returns). */
+int mi_upsample_ac_fwd(const float* low, float* up, int B, int h, int w, int K, int H, int W, void* stream);
+int mi_upsample_ac_bwd(const float* dup, float* dlow, int B, int h, int w, int K, int H, int W, void* stream);
+
+/* ---- per-pixel softmax cross-entropy, ignore_index (core/trainers/aspp_trainer.py:61,91) --------
+ * logits [B][K][H][W] fp32 NCHW, labels [B][H][W] int64.  loss_out[0] = mean over valid pixels
+ * (nan if none), loss_out[1] = number of valid pixels.  workspace: mi_ce_workspace bytes. */
+size_t mi_ce_workspace(int B, int H, int W);
+int mi_softmax_ce_fwd(const float* logits, const int64_t* labels, float* loss_out /*[2]*/,
+                      int B, int K, int H, int W, int ignore_index, void* workspace, size_t workspace_bytes, void* stream);
+/* dlogits = (softmax - onehot) * valid / n_valid * grad_scale, n_valid read from loss_out[1] on device */
+int mi_softmax_ce_bwd(const float* logits, const int64_t* labels, const float* loss_out, float* dlogits,
+                      int B, int K, int H, int W, int ignore_index, float grad_scale, void* stream);
+
+/* ---- fused upsample + cross-entropy: never materialises the [B][K][H][W] tensor (training path) --
+ * classifier(feat, size) + CrossEntropyLoss of reference aspp_trainer.py:89-91 in one call.
+ * low [B][h][w][K] fp32 NHWC, labels [B][H][W] int64 (H >= h, W >= w, K <= 32).
+ * loss_out[0] = mean loss over valid pixels, loss_out[1] = n_valid.
+ * dlow (may be NULL: loss only) [B][h][w][K] = d loss / d low * grad_scale, already divided by n_valid.
+ * Deterministic (fixed summation order, no atomics). */
+size_t mi_upsample_ce_workspace(int B, int h, int w, int K, int H, int W);
+int mi_upsample_ce(const float* low, const int64_t* labels, float* loss_out /*[2]*/, float* dlow,
+                   int B, int h, int w, int K, int H, int W, int ignore_index, float grad_scale,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- inference tail: upsample to label size + softmax over classes (utility.py:185-186) ---------
+ * probs [B][K][H][W] fp32; pred (optional, may be NULL) [B][H][W] uint8 argmax (first max wins). */
+int mi_upsample_softmax(const float* low, float* probs, uint8_t* pred, int B, int h, int w, int K, int H, int W, void* stream);
+
+/* ---- optimiser: torch.optim.SGD(momentum, weight_decay) on flat fp32 buffers (aspp_trainer.py:25-26,94-95)
+ * g' = g + wd*p; buf = mu*buf + g'; p -= lr*buf  (buf zero-initialised == torch's first-step buf = g'). */
+int mi_sgd_step(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float weight_decay, void* stream);
+
+/* ---- elementwise helpers ------------------------------------------------------------------------ */
+/* y = msk > 0 ? x : 0 (bf16, n % 8 == 0): ReLU backward across an autograd boundary */
+int mi_relu_mask(const void* x_bf16, const void* msk_bf16, void* y_bf16, size_t n, void* stream);
+/* FrozenBN fold: scale = w*rsqrt(var) (no eps), shift = b - mean*scale (layers.py:18-20) */
+int mi_frozen_bn_fold(const float* w, const float* b, const float* mean, const float* var, float* scale, float* shift, int n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

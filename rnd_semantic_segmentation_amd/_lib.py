@@ -1,0 +1,69 @@
+"""ctypes binding of libmi355seg.so (the C-ABI declared in include/mi355seg.h).
+
+The product path has no CPU fallback: `lib()` raises if the shared library is
+missing, and every wrapper in kernels.py insists on CUDA (HIP) tensors.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355seg.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mi355seg.h")
+
+P, I, F, Z = c_void_p, c_int, c_float, c_size_t
+
+# name -> (restype, argtypes); mirrors include/mi355seg.h one to one (tests/test_cabi.py checks it)
+SIGNATURES = {
+    "mi_version": (I, []),
+    "mi_last_error": (c_char_p, []),
+    "mi_pack_weight_fwd": (I, [P, P, I, I, I, P]),
+    "mi_pack_weight_dgrad": (I, [P, P, P, I, I, I, P]),
+    "mi_conv_gemm": (I, [P, P, P] + [I] * 12 + [P, P, P, P, I, I, P]),
+    "mi_conv_wgrad_workspace": (Z, [I] * 6),
+    "mi_conv_wgrad": (I, [P, P, P] + [I] * 11 + [P, I, I, P, Z, P]),
+    "mi_aspp_pack_fwd": (I, [P, P, I, I, P]),
+    "mi_aspp_pack_dgrad": (I, [P, P, I, I, P]),
+    "mi_aspp_col2im": (I, [P, P, P, I, I, I, I, P, P]),
+    "mi_aspp_im2col": (I, [P, P, I, I, I, I, P, P]),
+    "mi_aspp_bias_grad": (I, [P, P, I, I, I, P]),
+    "mi_upsample_ac_fwd": (I, [P, P] + [I] * 6 + [P]),
+    "mi_upsample_ac_bwd": (I, [P, P] + [I] * 6 + [P]),
+    "mi_ce_workspace": (Z, [I, I, I]),
+    "mi_softmax_ce_fwd": (I, [P, P, P, I, I, I, I, I, P, Z, P]),
+    "mi_softmax_ce_bwd": (I, [P, P, P, P, I, I, I, I, I, F, P]),
+    "mi_upsample_ce_workspace": (Z, [I] * 6),
+    "mi_upsample_ce": (I, [P, P, P, P] + [I] * 7 + [F, P, Z, P]),
+    "mi_upsample_softmax": (I, [P, P, P] + [I] * 6 + [P]),
+    "mi_sgd_step": (I, [P, P, P, Z, F, F, F, P]),
+    "mi_relu_mask": (I, [P, P, P, Z, P]),
+    "mi_frozen_bn_fold": (I, [P, P, P, P, P, P, I, P]),
+}
+
+_lib = None
+
+
+class MiError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Fails loudly: no fallback exists."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MiError(
+                "libmi355seg.so not found at %s - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). The MI355X path has no CPU fallback." % LIB_PATH)
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise MiError("%s failed (%d): %s" % (what or "libmi355seg call", rc, lib().mi_last_error().decode()))

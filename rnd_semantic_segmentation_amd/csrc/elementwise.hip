@@ -1,0 +1,99 @@
+// Small HBM-bound kernels: fused SGD step on flat buffers, ReLU-backward mask, FrozenBN fold, error plumbing.
+#include "mi_common.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+int mi_set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" int mi_version(void) { return MI355SEG_VERSION; }
+extern "C" const char* mi_last_error(void) { return g_err; }
+
+namespace {
+
+// torch.optim.SGD (reference core/trainers/aspp_trainer.py:25-26,94-95): g' = g + wd*p; buf = mu*buf + g'; p -= lr*buf
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, size_t n4, size_t n, float lr,
+                           float mu, float wd) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+        const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 bv = reinterpret_cast<f32x4*>(buf)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gg = gv[e] + wd * pv[e];
+            bv[e] = mu * bv[e] + gg;
+            pv[e] = pv[e] - lr * bv[e];
+        }
+        reinterpret_cast<f32x4*>(buf)[i] = bv;
+        reinterpret_cast<f32x4*>(p)[i] = pv;
+    }
+    // tail (n % 4 elements) by the first threads of block 0
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = (n4 << 2) + threadIdx.x;
+        const float gg = g[i] + wd * p[i];
+        const float b = mu * buf[i] + gg;
+        buf[i] = b;
+        p[i] = p[i] - lr * b;
+    }
+}
+
+__global__ void relu_mask_kernel(const bf16x8* __restrict__ x, const bf16x8* __restrict__ m, bf16x8* __restrict__ y, size_t n8) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        const bf16x8 xv = x[i], mv = m[i];
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = ((float)mv[e] > 0.f) ? xv[e] : (__bf16)0.f;
+        y[i] = o;
+    }
+}
+
+// reference core/components/layers.py:18-20 (no eps)
+__global__ void bn_fold_kernel(const float* w, const float* b, const float* mean, const float* var, float* scale, float* shift, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float s = w[i] * (1.0f / sqrtf(var[i]));
+    scale[i] = s;
+    shift[i] = b[i] - mean[i] * s;
+}
+
+}  // namespace
+
+extern "C" int mi_sgd_step(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float weight_decay, void* stream) {
+    MI_REQUIRE(p && g && buf && n > 0, "mi_sgd_step: bad argument");
+    MI_REQUIRE(mi_aligned16(p) && mi_aligned16(g) && mi_aligned16(buf), "mi_sgd_step: flat buffers must be 16-byte aligned");
+    const size_t n4 = n >> 2;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, buf, n4, n, lr, momentum, weight_decay);
+    MI_CHECK_LAUNCH("mi_sgd_step");
+    return MI_OK;
+}
+
+extern "C" int mi_relu_mask(const void* x, const void* msk, void* y, size_t n, void* stream) {
+    MI_REQUIRE(x && msk && y && n > 0 && n % 8 == 0, "mi_relu_mask: bad argument (n %% 8 == 0)");
+    MI_REQUIRE(mi_aligned16(x) && mi_aligned16(msk) && mi_aligned16(y), "mi_relu_mask: alignment");
+    const size_t n8 = n >> 3;
+    size_t blocks = (n8 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)x, (const bf16x8*)msk,
+                       (bf16x8*)y, n8);
+    MI_CHECK_LAUNCH("mi_relu_mask");
+    return MI_OK;
+}
+
+extern "C" int mi_frozen_bn_fold(const float* w, const float* b, const float* mean, const float* var, float* scale, float* shift, int n,
+                                 void* stream) {
+    MI_REQUIRE(w && b && mean && var && scale && shift && n > 0, "mi_frozen_bn_fold: bad argument");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, b, mean, var, scale, shift, n);
+    MI_CHECK_LAUNCH("mi_frozen_bn_fold");
+    return MI_OK;
+}

@@ -1,0 +1,198 @@
+// Weight packing (fp32 OIHW masters -> bf16 GEMM operands) and the ASPP head's data-movement kernels.
+// ASPP: reference core/models/classifiers/aspp/classifier.py:6-32 (4 dilated 3x3 convs, summed).
+#include "mi_common.h"
+
+namespace {
+
+// one thread per (o,i): reads k*k contiguous floats, writes one element into each tap plane
+__global__ void pack_fwd_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int O, int I, int T) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)O * I) return;
+    const long plane = (long)O * I;
+    for (int t = 0; t < T; ++t) wp[t * plane + idx] = (__bf16)w[idx * T + t];
+}
+
+// wp[t][i][o] = bf16(w[o][i][t] * scale[o]); thread per (i,o) so writes are coalesced over o
+__global__ void pack_dgrad_kernel(const float* __restrict__ w, const float* __restrict__ scale, __bf16* __restrict__ wp, int O, int I, int T) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)O * I) return;
+    const int i = (int)(idx / O), o = (int)(idx - (long)i * O);
+    const float s = scale ? scale[o] : 1.f;
+    const long plane = (long)O * I;
+    const float* src = w + ((long)o * I + i) * T;
+    for (int t = 0; t < T; ++t) wp[t * plane + idx] = (__bf16)(src[t] * s);
+}
+
+// wall[(g*20+n)][c], g = r*9+tap
+__global__ void aspp_pack_fwd_kernel(const float* __restrict__ w4, __bf16* __restrict__ wall, int C, int K) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = 36L * MI_ASPP_ZGW * C;
+    if (idx >= total) return;
+    const int row = (int)(idx / C), c = (int)(idx - (long)row * C);
+    const int g = row / MI_ASPP_ZGW, n = row - g * MI_ASPP_ZGW;
+    float v = 0.f;
+    if (n < K) {
+        const int r = g / 9, tap = g - r * 9;
+        v = w4[(((long)r * K + n) * C + c) * 9 + tap];
+    }
+    wall[idx] = (__bf16)v;
+}
+
+// wallT[c][k], k = g*K+n (k >= 36*K zero)
+__global__ void aspp_pack_dgrad_kernel(const float* __restrict__ w4, __bf16* __restrict__ wallT, int C, int K) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)C * MI_ASPP_KPAD;
+    if (idx >= total) return;
+    const int c = (int)(idx / MI_ASPP_KPAD), k = (int)(idx - (long)c * MI_ASPP_KPAD);
+    float v = 0.f;
+    if (k < 36 * K) {
+        const int g = k / K, n = k - g * K;
+        const int r = g / 9, tap = g - r * 9;
+        v = w4[(((long)r * K + n) * C + c) * 9 + tap];
+    }
+    wallT[idx] = (__bf16)v;
+}
+
+struct Rates { int d[4]; };
+
+// low[m][n] = sum_r bias[r][n] + sum_g Z[g][m + shift_g][n]; thread per (m, n) with n fastest (20 lanes per pixel)
+__global__ void aspp_col2im_kernel(const float* __restrict__ z, const float* __restrict__ bias4, float* __restrict__ low,
+                                   int B, int H, int W, int K, Rates rates) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long M = (long)B * H * W;
+    if (idx >= M * MI_ASPP_ZGW) return;
+    const long m = idx / MI_ASPP_ZGW;
+    const int n = (int)(idx - m * MI_ASPP_ZGW);
+    if (n >= K) return;
+    const int hw = (int)(m % ((long)H * W));
+    const int h = hw / W, w = hw - h * W;
+    // same association as the reference: (((conv0 + conv1) + conv2) + conv3), each conv = bias + taps
+    float total = 0.f;
+    for (int r = 0; r < 4; ++r) {
+        const int d = rates.d[r];
+        float s = bias4[r * K + n];
+        for (int ky = 0; ky < 3; ++ky) {
+            const int hh = h + (ky - 1) * d;
+            if ((unsigned)hh >= (unsigned)H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ww = w + (kx - 1) * d;
+                if ((unsigned)ww >= (unsigned)W) continue;
+                const int g = r * 9 + ky * 3 + kx;
+                const long ms = m + (long)(ky - 1) * d * W + (kx - 1) * d;
+                s += z[((long)g * M + ms) * MI_ASPP_ZGW + n];
+            }
+        }
+        total = (r == 0) ? s : total + s;
+    }
+    low[m * K + n] = total;
+}
+
+// G[m][k] = dlow[m - shift_g][n], k = g*K+n; thread per (m, k8) writing 8 bf16 (16 B)
+__global__ void aspp_im2col_kernel(const float* __restrict__ dlow, __bf16* __restrict__ gmat, int B, int H, int W, int K, Rates rates) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long M = (long)B * H * W;
+    constexpr int CH = MI_ASPP_KPAD / 8;
+    if (idx >= M * CH) return;
+    const long m = idx / CH;
+    const int k0 = (int)(idx - m * CH) * 8;
+    const int hw = (int)(m % ((long)H * W));
+    const int h = hw / W, w = hw - h * W;
+    bf16x8 out;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = k0 + e;
+        float v = 0.f;
+        if (k < 36 * K) {
+            const int g = k / K, n = k - g * K;
+            const int r = g / 9, tap = g - r * 9;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int d = rates.d[r];
+            // out[p] += W_tap x[p + s]  =>  dx[q] += W_tap^T dout[q - s]
+            const int hh = h - (ky - 1) * d, ww = w - (kx - 1) * d;
+            if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W)
+                v = dlow[(m - (long)(ky - 1) * d * W - (kx - 1) * d) * K + n];
+        }
+        out[e] = (__bf16)v;
+    }
+    *reinterpret_cast<bf16x8*>(gmat + m * MI_ASPP_KPAD + k0) = out;
+}
+
+// dbias[r][n] = sum_m dlow[m][n] for all 4 branches; one block per class, fixed-order tree -> reproducible
+__global__ void aspp_bias_grad_kernel(const float* __restrict__ dlow, float* __restrict__ dbias4, long M, int K, int accumulate) {
+    __shared__ float red[256];
+    const int n = blockIdx.x;
+    float s = 0.f;
+    for (long m = threadIdx.x; m < M; m += 256) s += dlow[m * K + n];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        for (int r = 0; r < 4; ++r) dbias4[r * K + n] = accumulate ? dbias4[r * K + n] + red[0] : red[0];
+}
+
+inline unsigned nblk(long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+}  // namespace
+
+extern "C" int mi_pack_weight_fwd(const float* w, void* wp, int O, int I, int ksize, void* stream) {
+    MI_REQUIRE(w && wp && O > 0 && I > 0 && ksize > 0, "mi_pack_weight_fwd: bad argument");
+    hipLaunchKernelGGL(pack_fwd_kernel, dim3(nblk((long)O * I, 256)), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)wp, O, I, ksize * ksize);
+    MI_CHECK_LAUNCH("mi_pack_weight_fwd");
+    return MI_OK;
+}
+
+extern "C" int mi_pack_weight_dgrad(const float* w, const float* scale_o, void* wp, int O, int I, int ksize, void* stream) {
+    MI_REQUIRE(w && wp && O > 0 && I > 0 && ksize > 0, "mi_pack_weight_dgrad: bad argument");
+    hipLaunchKernelGGL(pack_dgrad_kernel, dim3(nblk((long)O * I, 256)), dim3(256), 0, (hipStream_t)stream, w, scale_o, (__bf16*)wp, O, I,
+                       ksize * ksize);
+    MI_CHECK_LAUNCH("mi_pack_weight_dgrad");
+    return MI_OK;
+}
+
+extern "C" int mi_aspp_pack_fwd(const float* w4, void* wall, int C, int K, void* stream) {
+    MI_REQUIRE(w4 && wall && C > 0 && K > 0 && K < MI_ASPP_ZGW, "mi_aspp_pack_fwd: bad argument (K=%d must be < 20)", K);
+    hipLaunchKernelGGL(aspp_pack_fwd_kernel, dim3(nblk(36L * MI_ASPP_ZGW * C, 256)), dim3(256), 0, (hipStream_t)stream, w4, (__bf16*)wall, C, K);
+    MI_CHECK_LAUNCH("mi_aspp_pack_fwd");
+    return MI_OK;
+}
+
+extern "C" int mi_aspp_pack_dgrad(const float* w4, void* wallT, int C, int K, void* stream) {
+    MI_REQUIRE(w4 && wallT && C > 0 && K > 0 && 36 * K <= MI_ASPP_KPAD, "mi_aspp_pack_dgrad: bad argument");
+    hipLaunchKernelGGL(aspp_pack_dgrad_kernel, dim3(nblk((long)C * MI_ASPP_KPAD, 256)), dim3(256), 0, (hipStream_t)stream, w4, (__bf16*)wallT, C, K);
+    MI_CHECK_LAUNCH("mi_aspp_pack_dgrad");
+    return MI_OK;
+}
+
+extern "C" int mi_aspp_col2im(const float* z, const float* bias4, float* low, int B, int H, int W, int K, const int* rates4, void* stream) {
+    MI_REQUIRE(z && bias4 && low && rates4 && B > 0 && H > 0 && W > 0 && K > 0 && K < MI_ASPP_ZGW, "mi_aspp_col2im: bad argument");
+    Rates r;
+    for (int i = 0; i < 4; ++i) {
+        MI_REQUIRE(rates4[i] >= 1, "mi_aspp_col2im: rate");
+        r.d[i] = rates4[i];
+    }
+    const long n = (long)B * H * W * MI_ASPP_ZGW;
+    hipLaunchKernelGGL(aspp_col2im_kernel, dim3(nblk(n, 320)), dim3(320), 0, (hipStream_t)stream, z, bias4, low, B, H, W, K, r);
+    MI_CHECK_LAUNCH("mi_aspp_col2im");
+    return MI_OK;
+}
+
+extern "C" int mi_aspp_im2col(const float* dlow, void* g, int B, int H, int W, int K, const int* rates4, void* stream) {
+    MI_REQUIRE(dlow && g && rates4 && B > 0 && H > 0 && W > 0 && K > 0 && 36 * K <= MI_ASPP_KPAD, "mi_aspp_im2col: bad argument");
+    MI_REQUIRE(mi_aligned16(g), "mi_aspp_im2col: alignment");
+    Rates r;
+    for (int i = 0; i < 4; ++i) r.d[i] = rates4[i];
+    const long n = (long)B * H * W * (MI_ASPP_KPAD / 8);
+    hipLaunchKernelGGL(aspp_im2col_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, dlow, (__bf16*)g, B, H, W, K, r);
+    MI_CHECK_LAUNCH("mi_aspp_im2col");
+    return MI_OK;
+}
+
+extern "C" int mi_aspp_bias_grad(const float* dlow, float* dbias4, int M, int K, int accumulate, void* stream) {
+    MI_REQUIRE(dlow && dbias4 && M > 0 && K > 0, "mi_aspp_bias_grad: bad argument");
+    hipLaunchKernelGGL(aspp_bias_grad_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, dlow, dbias4, (long)M, K, accumulate);
+    MI_CHECK_LAUNCH("mi_aspp_bias_grad");
+    return MI_OK;
+}

@@ -1,0 +1,261 @@
+"""Tensor-level wrappers over the C-ABI (torch is plumbing: device memory + streams).
+
+Layout: every activation handled here is an NHWC-contiguous tensor [B,H,W,C]
+(bf16 unless stated).  Callers that hold NCHW-shaped channels_last tensors pass
+`x.permute(0, 2, 3, 1)` (a free view).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+EPI_SCALE_BIAS, EPI_RESIDUAL, EPI_RELU, EPI_MASK, EPI_OUT_F32, EPI_ZSPLIT = 1, 2, 4, 8, 16, 32
+GATHER_FWD, GATHER_DGRAD = 0, 1
+ASPP_ZGW, ASPP_KPAD = 20, 704
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _chk(t, dtype, name):
+    if not t.is_cuda:
+        raise _lib.MiError("%s must live on the GPU (no CPU path exists)" % name)
+    if t.dtype != dtype:
+        raise _lib.MiError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise _lib.MiError("%s must be contiguous" % name)
+    return t
+
+
+def pack_weight_fwd(w, out=None):
+    """fp32 OIHW -> bf16 [k*k][O][I]"""
+    _chk(w, torch.float32, "w")
+    O, I, k, _ = w.shape
+    if out is None:
+        out = torch.empty((k * k, O, I), dtype=torch.bfloat16, device=w.device)
+    check(_lib.lib().mi_pack_weight_fwd(_p(w), _p(out), O, I, k, _stream()), "mi_pack_weight_fwd")
+    return out
+
+
+def pack_weight_dgrad(w, scale=None, out=None):
+    """fp32 OIHW -> bf16 [k*k][I][O], FrozenBN scale[o] folded in"""
+    _chk(w, torch.float32, "w")
+    O, I, k, _ = w.shape
+    if out is None:
+        out = torch.empty((k * k, I, O), dtype=torch.bfloat16, device=w.device)
+    check(_lib.lib().mi_pack_weight_dgrad(_p(w), _p(scale), _p(out), O, I, k, _stream()), "mi_pack_weight_dgrad")
+    return out
+
+
+def conv_gemm(a, wp, out_hw, ksize=1, stride=1, pad=0, dil=1, mode=GATHER_FWD, scale=None, bias=None, res=None,
+              msk=None, relu=False, out_f32=False, zsplit=0, out=None):
+    """out[b,ho,wo,n] = epi(sum_{t,c} a[b,src(ho,wo,t),c] * wp[t,n,c]);  a [B,Ha,Wa,Ca] bf16, wp [k*k,N,Ca] bf16."""
+    _chk(a, torch.bfloat16, "a")
+    _chk(wp, torch.bfloat16, "wp")
+    B, Ha, Wa, Ca = a.shape
+    T, N, Cw = wp.shape
+    if T != ksize * ksize or Cw != Ca:
+        raise _lib.MiError("packed weight %s does not match ksize=%d, Ca=%d" % (tuple(wp.shape), ksize, Ca))
+    Ho, Wo = out_hw
+    flags = 0
+    if scale is not None:
+        flags |= EPI_SCALE_BIAS
+        _chk(scale, torch.float32, "scale")
+        _chk(bias, torch.float32, "bias")
+    if res is not None:
+        flags |= EPI_RESIDUAL
+        _chk(res, torch.bfloat16, "res")
+        assert tuple(res.shape) == (B, Ho, Wo, N)
+    if relu:
+        flags |= EPI_RELU
+    if msk is not None:
+        flags |= EPI_MASK
+        _chk(msk, torch.bfloat16, "msk")
+        assert tuple(msk.shape) == (B, Ho, Wo, N)
+    if zsplit:
+        flags |= EPI_ZSPLIT | EPI_OUT_F32
+        if out is None:
+            out = torch.empty((N // zsplit, B * Ho * Wo, zsplit), dtype=torch.float32, device=a.device)
+    elif out_f32:
+        flags |= EPI_OUT_F32
+        if out is None:
+            out = torch.empty((B, Ho, Wo, N), dtype=torch.float32, device=a.device)
+    elif out is None:
+        out = torch.empty((B, Ho, Wo, N), dtype=torch.bfloat16, device=a.device)
+    check(_lib.lib().mi_conv_gemm(_p(a), _p(wp), _p(out), B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, pad, dil, mode,
+                                   _p(scale), _p(bias), _p(res), _p(msk), flags, zsplit, _stream()), "mi_conv_gemm")
+    return out
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device, tag="ws"):
+    key = (tag, str(device))
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def conv_wgrad(dy, x, dw, ksize=1, stride=1, pad=0, dil=1, scale=None, accumulate=False, out_map=0):
+    """dw[o,i,ky,kx] (+)= scale[o] * sum_m dy[m,o] x[src(m,t),i];  dy [B,Ho,Wo,O], x [B,Ha,Wa,I] bf16; dw fp32."""
+    _chk(dy, torch.bfloat16, "dy")
+    _chk(x, torch.bfloat16, "x")
+    _chk(dw, torch.float32, "dw")
+    B, Ho, Wo, O = dy.shape
+    _, Ha, Wa, I = x.shape
+    L = _lib.lib()
+    need = L.mi_conv_wgrad_workspace(B, Ho, Wo, O, I, ksize)
+    ws = _workspace(need, dy.device, "wgrad")
+    check(L.mi_conv_wgrad(_p(dy), _p(x), _p(dw), B, Ha, Wa, I, Ho, Wo, O, ksize, stride, pad, dil, _p(scale),
+                          int(accumulate), out_map, _p(ws), ws.numel(), _stream()), "mi_conv_wgrad")
+    return dw
+
+
+def _rates(rates):
+    return (ctypes.c_int * 4)(*[int(r) for r in rates])
+
+
+def aspp_pack_fwd(w4, out=None):
+    """[4,K,C,3,3] fp32 -> Wall bf16 [1, 720, C] (packed-weight form for conv_gemm, ksize 1)"""
+    _chk(w4, torch.float32, "w4")
+    R, K, C = w4.shape[:3]
+    if out is None:
+        out = torch.empty((1, 36 * ASPP_ZGW, C), dtype=torch.bfloat16, device=w4.device)
+    check(_lib.lib().mi_aspp_pack_fwd(_p(w4), _p(out), C, K, _stream()), "mi_aspp_pack_fwd")
+    return out
+
+
+def aspp_pack_dgrad(w4, out=None):
+    """[4,K,C,3,3] fp32 -> WallT bf16 [1, C, 704]"""
+    _chk(w4, torch.float32, "w4")
+    R, K, C = w4.shape[:3]
+    if out is None:
+        out = torch.empty((1, C, ASPP_KPAD), dtype=torch.bfloat16, device=w4.device)
+    check(_lib.lib().mi_aspp_pack_dgrad(_p(w4), _p(out), C, K, _stream()), "mi_aspp_pack_dgrad")
+    return out
+
+
+def aspp_col2im(z, bias4, B, H, W, K, rates):
+    _chk(z, torch.float32, "z")
+    _chk(bias4, torch.float32, "bias4")
+    low = torch.empty((B, H, W, K), dtype=torch.float32, device=z.device)
+    check(_lib.lib().mi_aspp_col2im(_p(z), _p(bias4), _p(low), B, H, W, K, _rates(rates), _stream()), "mi_aspp_col2im")
+    return low
+
+
+def aspp_im2col(dlow, rates):
+    _chk(dlow, torch.float32, "dlow")
+    B, H, W, K = dlow.shape
+    g = torch.empty((B, H, W, ASPP_KPAD), dtype=torch.bfloat16, device=dlow.device)
+    check(_lib.lib().mi_aspp_im2col(_p(dlow), _p(g), B, H, W, K, _rates(rates), _stream()), "mi_aspp_im2col")
+    return g
+
+
+def aspp_bias_grad(dlow, dbias4, accumulate=False):
+    _chk(dlow, torch.float32, "dlow")
+    _chk(dbias4, torch.float32, "dbias4")
+    B, H, W, K = dlow.shape
+    check(_lib.lib().mi_aspp_bias_grad(_p(dlow), _p(dbias4), B * H * W, K, int(accumulate), _stream()), "mi_aspp_bias_grad")
+    return dbias4
+
+
+def upsample_ac_fwd(low, size):
+    """low [B,h,w,K] fp32 NHWC -> up [B,K,H,W] fp32 NCHW"""
+    _chk(low, torch.float32, "low")
+    B, h, w, K = low.shape
+    H, W = size
+    up = torch.empty((B, K, H, W), dtype=torch.float32, device=low.device)
+    check(_lib.lib().mi_upsample_ac_fwd(_p(low), _p(up), B, h, w, K, H, W, _stream()), "mi_upsample_ac_fwd")
+    return up
+
+
+def upsample_ac_bwd(dup, low_hw):
+    _chk(dup, torch.float32, "dup")
+    B, K, H, W = dup.shape
+    h, w = low_hw
+    dlow = torch.empty((B, h, w, K), dtype=torch.float32, device=dup.device)
+    check(_lib.lib().mi_upsample_ac_bwd(_p(dup), _p(dlow), B, h, w, K, H, W, _stream()), "mi_upsample_ac_bwd")
+    return dlow
+
+
+def softmax_ce_fwd(logits, labels, ignore_index=255):
+    """logits [B,K,H,W] fp32, labels [B,H,W] int64 -> loss_out fp32[2] = (mean loss, n_valid) on device"""
+    _chk(logits, torch.float32, "logits")
+    _chk(labels, torch.int64, "labels")
+    B, K, H, W = logits.shape
+    L = _lib.lib()
+    ws = _workspace(L.mi_ce_workspace(B, H, W), logits.device, "ce")
+    out = torch.empty(2, dtype=torch.float32, device=logits.device)
+    check(L.mi_softmax_ce_fwd(_p(logits), _p(labels), _p(out), B, K, H, W, ignore_index, _p(ws), ws.numel(), _stream()),
+          "mi_softmax_ce_fwd")
+    return out
+
+
+def softmax_ce_bwd(logits, labels, loss_out, grad_scale=1.0, ignore_index=255):
+    _chk(logits, torch.float32, "logits")
+    _chk(labels, torch.int64, "labels")
+    B, K, H, W = logits.shape
+    d = torch.empty_like(logits)
+    check(_lib.lib().mi_softmax_ce_bwd(_p(logits), _p(labels), _p(loss_out), _p(d), B, K, H, W, ignore_index,
+                                        float(grad_scale), _stream()), "mi_softmax_ce_bwd")
+    return d
+
+
+def upsample_ce(low, labels, want_grad=True, grad_scale=1.0, ignore_index=255):
+    """Fused classifier-upsample + CrossEntropyLoss.  Returns (loss_out[2], dlow or None)."""
+    _chk(low, torch.float32, "low")
+    _chk(labels, torch.int64, "labels")
+    B, h, w, K = low.shape
+    _, H, W = labels.shape
+    L = _lib.lib()
+    ws = _workspace(L.mi_upsample_ce_workspace(B, h, w, K, H, W), low.device, "upce")
+    out = torch.empty(2, dtype=torch.float32, device=low.device)
+    dlow = torch.empty_like(low) if want_grad else None
+    check(L.mi_upsample_ce(_p(low), _p(labels), _p(out), _p(dlow), B, h, w, K, H, W, ignore_index, float(grad_scale),
+                           _p(ws), ws.numel(), _stream()), "mi_upsample_ce")
+    return out, dlow
+
+
+def upsample_softmax(low, size, want_pred=True):
+    _chk(low, torch.float32, "low")
+    B, h, w, K = low.shape
+    H, W = size
+    probs = torch.empty((B, K, H, W), dtype=torch.float32, device=low.device)
+    pred = torch.empty((B, H, W), dtype=torch.uint8, device=low.device) if want_pred else None
+    check(_lib.lib().mi_upsample_softmax(_p(low), _p(probs), _p(pred), B, h, w, K, H, W, _stream()), "mi_upsample_softmax")
+    return probs, pred
+
+
+def sgd_step(p, g, buf, lr, momentum, weight_decay):
+    for t, n in ((p, "p"), (g, "g"), (buf, "buf")):
+        _chk(t, torch.float32, n)
+    check(_lib.lib().mi_sgd_step(_p(p), _p(g), _p(buf), p.numel(), float(lr), float(momentum), float(weight_decay), _stream()),
+          "mi_sgd_step")
+
+
+def relu_mask(x, msk, out=None):
+    _chk(x, torch.bfloat16, "x")
+    _chk(msk, torch.bfloat16, "msk")
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.lib().mi_relu_mask(_p(x), _p(msk), _p(out), x.numel(), _stream()), "mi_relu_mask")
+    return out
+
+
+def frozen_bn_fold(w, b, mean, var):
+    for t in (w, b, mean, var):
+        _chk(t, torch.float32, "bn buffer")
+    scale, shift = torch.empty_like(w), torch.empty_like(w)
+    check(_lib.lib().mi_frozen_bn_fold(_p(w), _p(b), _p(mean), _p(var), _p(scale), _p(shift), w.numel(), _stream()),
+          "mi_frozen_bn_fold")
+    return scale, shift

@@ -1,0 +1,276 @@
+"""GPU parity: every C-ABI kernel (through kernels.py -> ctypes -> libmi355seg.so) against
+(a) the golden fixtures produced by the reference's own modules and (b) the numpy oracle on the
+same bf16-rounded operands.
+
+Tolerances (written where used):
+  * fp32 outputs of bf16-operand / fp32-accumulate kernels vs exact math: 1e-3 relative to the tensor's
+    max magnitude is BASELINE.json's bar; these kernels measure ~1e-6, asserted at 2e-5.
+  * bf16 outputs: one bf16 ulp of the largest magnitude (2^-8 relative).
+  * integer results (argmax, histograms): bit exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+import _cases
+from oracle import ref_ops
+from rnd_semantic_segmentation_amd.host import synth
+
+pytestmark = pytest.mark.gpu
+
+K = None  # kernels module, imported lazily so collection works without the .so
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _kern():
+    global K
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from rnd_semantic_segmentation_amd import kernels
+    K = kernels
+    yield
+
+
+DEV = "cuda"
+
+
+def nhwc_bf16(x_nchw):
+    return torch.from_numpy(np.ascontiguousarray(x_nchw)).to(DEV).permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+
+
+def to_nchw(t_nhwc):
+    return t_nhwc.float().permute(0, 3, 1, 2).contiguous().cpu().numpy()
+
+
+def relmax(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def dev(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV).to(dtype)
+
+
+# ------------------------------------------------------------------------------------------------ conv family
+@pytest.mark.parametrize("name", _cases.CONV_CASES)
+def test_conv_fwd_dgrad_wgrad_vs_reference_golden(name):
+    c = _cases.conv_case(name)
+    x, w, dy = c["x"], c["w"], c["dy"]
+    k, s, d, pad = c["k"], c["stride"], c["dil"], c["pad"]
+    B, Ci, H, W = x.shape
+    Co = w.shape[0]
+    Ho, Wo = c["y"].shape[-2:]
+    xd, dyd, wd = nhwc_bf16(x), nhwc_bf16(dy), dev(w)
+    wp = K.pack_weight_fwd(wd)
+    y = K.conv_gemm(xd, wp, (Ho, Wo), k, s, pad, d, K.GATHER_FWD, out_f32=True)
+    assert relmax(to_nchw(y), c["y"]) < 2e-5
+    wpt = K.pack_weight_dgrad(wd)
+    dx = K.conv_gemm(dyd, wpt, (H, W), k, s, pad, d, K.GATHER_DGRAD, out_f32=True)
+    assert relmax(to_nchw(dx), c["dx"]) < 2e-5
+    dw = torch.full((Co, Ci, k, k), float("nan"), device=DEV)
+    K.conv_wgrad(dyd, xd, dw, k, s, pad, d)
+    assert relmax(dw.cpu().numpy(), c["dw"]) < 2e-5
+    # reproducibility + accumulate
+    dw2 = torch.empty_like(dw)
+    K.conv_wgrad(dyd, xd, dw2, k, s, pad, d)
+    assert torch.equal(dw, dw2)
+    K.conv_wgrad(dyd, xd, dw2, k, s, pad, d, accumulate=True)
+    assert relmax(dw2.cpu().numpy(), 2 * c["dw"]) < 2e-5
+
+
+def test_conv_fused_epilogue_bn_residual_relu_mask():
+    """FrozenBN + residual + ReLU epilogue (reference resnet.py:107-111, layers.py:18-23) and the backward mask."""
+    B, Ci, Co, H, W, d = 3, 256, 320, 19, 23, 2      # M = 1311 (tail), N = 320 (2.5 tiles)
+    x = synth.bf16_round(np.maximum(synth.uniform("t.x", (B, Ci, H, W)) * 4, 0))
+    w = synth.bf16_round(synth.formula_tensor("t.conv.weight", (Co, Ci, 3, 3)))
+    res = synth.bf16_round(synth.uniform("t.res", (B, Co, H, W)) * 2)
+    bn = {k: synth.formula_tensor("t.bn2." + k, (Co,)) for k in ("weight", "bias", "running_mean", "running_var")}
+    scale, shift = ref_ops.frozen_bn_scale_bias(*[bn[k].astype(np.float64) for k in ("weight", "bias", "running_mean", "running_var")])
+    conv = ref_ops.conv2d(x, w, None, 1, d, d)
+    want = np.maximum(conv * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1) + res, 0)
+    sc, sh = K.frozen_bn_fold(*[dev(bn[k]) for k in ("weight", "bias", "running_mean", "running_var")])
+    assert relmax(sc.cpu().numpy(), scale) < 1e-6 and relmax(sh.cpu().numpy(), shift) < 1e-6
+    wp = K.pack_weight_fwd(dev(w))
+    xd, resd = nhwc_bf16(x), nhwc_bf16(res)
+    y32 = K.conv_gemm(xd, wp, (H, W), 3, 1, d, d, scale=sc, bias=sh, res=resd, relu=True, out_f32=True)
+    assert relmax(to_nchw(y32), want) < 2e-5
+    y16 = K.conv_gemm(xd, wp, (H, W), 3, 1, d, d, scale=sc, bias=sh, res=resd, relu=True)
+    assert relmax(to_nchw(y16), want) < 2.0 ** -8          # bf16 output: one ulp of the max
+    assert (to_nchw(y16) >= 0).all()
+    # mask epilogue: v = msk > 0 ? v : 0
+    ym = K.conv_gemm(xd, wp, (H, W), 3, 1, d, d, res=resd, msk=y16, out_f32=True)
+    want_m = (conv + res) * (to_nchw(y16) > 0)
+    assert relmax(to_nchw(ym), want_m) < 2e-5
+    # scale folded into the dgrad pack and into the wgrad reduce
+    dy = synth.bf16_round(synth.uniform("t.dy", (B, Co, H, W)))
+    wpt = K.pack_weight_dgrad(dev(w), sc)
+    dx = K.conv_gemm(nhwc_bf16(dy), wpt, (H, W), 3, 1, d, d, K.GATHER_DGRAD, out_f32=True)
+    w_s = synth.bf16_round((w.astype(np.float64) * scale.reshape(-1, 1, 1, 1)).astype(np.float32))
+    assert relmax(to_nchw(dx), ref_ops.conv2d_dgrad(dy, w_s, (H, W), 1, d, d)) < 2e-5
+    dw = torch.empty((Co, Ci, 3, 3), device=DEV)
+    K.conv_wgrad(nhwc_bf16(dy), xd, dw, 3, 1, d, d, scale=sc)
+    assert relmax(dw.cpu().numpy(), ref_ops.conv2d_wgrad(dy, x, 3, 1, d, d) * scale.reshape(-1, 1, 1, 1)) < 2e-5
+
+
+def test_conv_identity_weight_is_exact_shift_full_size():
+    """Size-independent property at the BASELINE shape (B=8, 97x97, C=256, d=2): a one-hot tap weight makes the
+    conv an exact spatial shift with zero fill - bit exact in bf16."""
+    B, C, H, W, d = 8, 256, 97, 97, 2
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn((B, H, W, C), generator=g).to(DEV).to(torch.bfloat16)
+    for tap in (0, 5, 8):
+        w = torch.zeros((C, C, 3, 3), device=DEV)
+        w[torch.arange(C), torch.arange(C), tap // 3, tap % 3] = 1.0
+        y = K.conv_gemm(x, K.pack_weight_fwd(w), (H, W), 3, 1, d, d)
+        dy_, dx_ = (tap // 3 - 1) * d, (tap % 3 - 1) * d
+        want = torch.zeros_like(x)
+        hs, he = max(0, -dy_), min(H, H - dy_)
+        ws, we = max(0, -dx_), min(W, W - dx_)
+        want[:, hs:he, ws:we] = x[:, hs + dy_:he + dy_, ws + dx_:we + dx_]
+        assert torch.equal(y, want)
+
+
+def test_wgrad_full_size_linearity_and_reproducibility():
+    """At M = 75 272: wgrad(dy1 + dy2) == wgrad(dy1) + wgrad(dy2) to fp32 round-off, and two runs are bitwise equal."""
+    B, C, H, W, d = 8, 256, 97, 97, 2
+    g = torch.Generator(device="cpu").manual_seed(7)
+    x = torch.randn((B, H, W, C), generator=g).to(DEV).to(torch.bfloat16)
+    dy1 = (torch.randint(-4, 5, (B, H, W, C), generator=g).float() / 4).to(DEV).to(torch.bfloat16)
+    dy2 = (torch.randint(-4, 5, (B, H, W, C), generator=g).float() / 4).to(DEV).to(torch.bfloat16)
+    out = [torch.empty((C, C, 3, 3), device=DEV) for _ in range(4)]
+    K.conv_wgrad(dy1, x, out[0], 3, 1, d, d)
+    K.conv_wgrad(dy2, x, out[1], 3, 1, d, d)
+    K.conv_wgrad(dy1 + dy2, x, out[2], 3, 1, d, d)      # dy1+dy2 exact in bf16 (multiples of 1/4, |.| <= 2)
+    K.conv_wgrad(dy1 + dy2, x, out[3], 3, 1, d, d)
+    assert torch.equal(out[2], out[3])
+    err = (out[0] + out[1] - out[2]).abs().max().item()
+    assert err < 1e-3 * out[2].abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------------ ASPP head chain
+def _aspp_forward(xd, w4, b4, rates=(6, 12, 18, 24)):
+    B, H, W, C = xd.shape
+    wall = K.aspp_pack_fwd(w4)
+    z = K.conv_gemm(xd, wall, (H, W), zsplit=K.ASPP_ZGW)
+    return K.aspp_col2im(z, b4, B, H, W, 19, rates)
+
+
+def test_aspp_head_upsample_ce_vs_reference_golden():
+    c = _cases.aspp_case()
+    g = c["g"]
+    x, ws, bs, lab, size = c["x"], c["w"], c["b"], c["label"], c["size"]
+    B, C, H, W = x.shape
+    xd = nhwc_bf16(x)
+    w4, b4 = dev(ws), dev(bs)
+    low = _aspp_forward(xd, w4, b4)                                     # [B,H,W,19] fp32
+    assert relmax(to_nchw(low), g["low"]) < 2e-5
+    # unfused: upsample (materialised NCHW) + CE, forward and backward
+    up = K.upsample_ac_fwd(low, size)
+    assert relmax(up.cpu().numpy()[:, :, ::3, ::3], g["up_sub"]) < 2e-5
+    labd = dev(lab, torch.int64)
+    lo = K.softmax_ce_fwd(up, labd)
+    assert abs(lo[0].item() - float(g["loss"])) < 2e-5 * abs(float(g["loss"]))
+    assert lo[1].item() == float((lab != 255).sum())
+    dup = K.softmax_ce_bwd(up, labd, lo)
+    assert relmax(dup.cpu().numpy()[:, :, ::3, ::3], g["dup_sub"]) < 2e-5
+    dlow_u = K.upsample_ac_bwd(dup, (H, W))
+    assert relmax(to_nchw(dlow_u), g["dlow"]) < 2e-5
+    # fused: never materialises `up`
+    lo2, dlow = K.upsample_ce(low, labd)
+    assert abs(lo2[0].item() - float(g["loss"])) < 2e-5 * abs(float(g["loss"]))
+    assert lo2[1].item() == lo[1].item()
+    assert relmax(to_nchw(dlow), g["dlow"]) < 2e-5
+    lo3, dlow3 = K.upsample_ce(low, labd)
+    assert torch.equal(dlow, dlow3) and torch.equal(lo2, lo3)            # deterministic
+    # backward of the head.  G is bf16, so compare against the oracle fed the bf16-rounded dlow (tight) ...
+    gm = K.aspp_im2col(dlow, (6, 12, 18, 24))
+    wallT = K.aspp_pack_dgrad(w4)
+    dx = K.conv_gemm(gm, wallT, (H, W), out_f32=True)
+    dlow_r = synth.bf16_round(to_nchw(dlow))
+    dx_ref, dw_ref, db_ref = ref_ops.aspp_head_backward(dlow_r, x, ws)
+    assert relmax(to_nchw(dx), dx_ref) < 2e-5
+    dw4 = torch.empty_like(w4)
+    K.conv_wgrad(gm, xd, dw4, out_map=1)
+    assert relmax(dw4.cpu().numpy(), np.stack(dw_ref)) < 2e-5
+    db4 = torch.empty_like(b4)
+    K.aspp_bias_grad(dlow, db4)
+    assert relmax(db4.cpu().numpy(), g["db"]) < 2e-5
+    # ... and against the reference's fp32 autograd (bf16 rounding of dlow: 2^-9 relative per element)
+    assert relmax(to_nchw(dx), g["dx"]) < 4e-3
+    assert relmax(dw4.cpu().numpy(), g["dw"]) < 4e-3
+
+
+def test_upsample_integer_scale_all_ignored_and_inference_tail():
+    c = _cases.upsample_case()
+    g = c["g"]
+    low = dev(c["low"]).permute(0, 2, 3, 1).contiguous()
+    up = K.upsample_ac_fwd(low, (129, 129))
+    assert relmax(up.cpu().numpy()[:, :, ::5, ::3], g["up_sub"]) < 2e-5
+    labd = dev(c["label"], torch.int64)
+    lo, dlow = K.upsample_ce(low, labd)
+    assert abs(lo[0].item() - float(g["loss"])) < 2e-5 * abs(float(g["loss"]))
+    want_dlow = ref_ops.bilinear_ac_backward(ref_ops.cross_entropy_ignore(ref_ops.bilinear_ac(c["low"], (129, 129)), c["label"])[1], (17, 17))
+    assert relmax(to_nchw(dlow), want_dlow) < 2e-5
+    # every label ignored: loss nan (0/0) exactly like torch
+    lab_all = torch.full((1, 129, 129), 255, dtype=torch.int64, device=DEV)
+    lo0, _ = K.upsample_ce(low, lab_all, want_grad=False)
+    assert np.isnan(lo0[0].item()) and lo0[1].item() == 0 and np.isnan(float(g["loss_all_ignored"]))
+    # inference tail (reference utility.py:185-186): probabilities and argmax
+    probs, pred = K.upsample_softmax(low, (129, 129))
+    want = ref_ops.inference_probs(c["low"], (129, 129))
+    assert relmax(probs.cpu().numpy(), want) < 2e-5
+    assert abs(probs.sum(1).cpu().numpy() - 1).max() < 1e-5
+    assert torch.equal(pred.long(), probs.argmax(1))                      # integer result: exact
+    # non-integer scale to a label size larger than train crops (64x128 -> 512x1024 shape class, scaled down)
+    low2 = dev(synth.uniform("t.low2", (1, 19, 9, 17)).astype(np.float32) * 5).permute(0, 2, 3, 1).contiguous()
+    probs2, _ = K.upsample_softmax(low2, (70, 133))
+    want2 = ref_ops.inference_probs(to_nchw(low2), (70, 133))
+    assert relmax(probs2.cpu().numpy(), want2) < 2e-5
+
+
+def test_upsample_ce_full_size_properties():
+    """B=8, 97x97 -> 769x769 (BASELINE shape): fused loss == unfused loss; gradient sums to ~0 per pixel set;
+    two runs bitwise identical."""
+    B, h, w, Kc, H, W = 8, 97, 97, 19, 769, 769
+    g = torch.Generator(device="cpu").manual_seed(3)
+    low = (torch.randn((B, h, w, Kc), generator=g) * 3).to(DEV)
+    lab = torch.from_numpy(synth.synth_label(B, H, W, Kc, seed=9)).to(DEV).long()
+    lo, dlow = K.upsample_ce(low, lab)
+    up = K.upsample_ac_fwd(low, (H, W))
+    lo_u = K.softmax_ce_fwd(up, lab)
+    assert lo[1].item() == lo_u[1].item() == float((lab != 255).sum().item())
+    assert abs(lo[0].item() - lo_u[0].item()) < 1e-5 * abs(lo_u[0].item())
+    dlow_u = K.upsample_ac_bwd(K.softmax_ce_bwd(up, lab, lo_u), (h, w))
+    assert (dlow - dlow_u).abs().max().item() < 2e-5 * dlow_u.abs().max().item()
+    assert abs(dlow.sum().item()) < 1e-4                                  # softmax - onehot sums to zero over classes
+    lo2, dlow2 = K.upsample_ce(low, lab)
+    assert torch.equal(dlow, dlow2) and torch.equal(lo, lo2)
+
+
+# ------------------------------------------------------------------------------------------------ optimiser & helpers
+def test_sgd_matches_torch_optim_golden():
+    g = _cases.load("g7_metrics")
+    p = dev(g["sgd_p0"]).clone()
+    buf = torch.zeros_like(p)
+    for s in range(3):
+        K.sgd_step(p, dev(g["sgd_g"][s]), buf, float(g["sgd_lrs"][s]), 0.9, 5e-4)
+        assert relmax(p.cpu().numpy(), g["sgd_p"][s]) < 3e-7
+
+
+def test_frozen_bn_fold_and_relu_mask():
+    g = _cases.load("g4_frozenbn")
+    sc, sh = K.frozen_bn_fold(*[dev(g[k]) for k in ("weight", "bias", "running_mean", "running_var")])
+    y = dev(g["x"]) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    assert relmax(y.cpu().numpy(), g["y"]) < 1e-6
+    x = torch.randn(4096 * 8, device=DEV).to(torch.bfloat16)
+    m = torch.randn(4096 * 8, device=DEV).to(torch.bfloat16)
+    assert torch.equal(K.relu_mask(x, m), torch.where(m > 0, x, torch.zeros_like(x)))
+
+
+def test_errors_are_reported_not_thrown_across_the_abi():
+    from rnd_semantic_segmentation_amd import _lib
+    a = torch.zeros((1, 4, 4, 32), device=DEV, dtype=torch.bfloat16)
+    wp = torch.zeros((1, 64, 32), device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(_lib.MiError, match="multiple of 64"):
+        K.conv_gemm(a, wp, (4, 4))
+    with pytest.raises(_lib.MiError, match="GPU"):
+        K.relu_mask(torch.zeros(8, dtype=torch.bfloat16), torch.zeros(8, dtype=torch.bfloat16))
