@@ -1,0 +1,171 @@
+"""Headline benchmark (BASELINE.json): train images/s of DeepLabV2-ResNet101 + ASPP at 769x769, bf16 operands,
+B = 8 per GPU, on N MI355X of one node (weak scaling), synthetic data resident in HBM, formula weights.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One step = reference core/trainers/aspp_trainer.py:77-95 (poly LR, zero_grad, forward, CE loss, backward, both SGD
+steps) through host/trainer.py:ASPPTrainer.train_step on the HIP engine; N > 1 adds the RCCL gradient average.
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the MFMA implicit-GEMM conv,
+igemm_nt_kernel): algorithmic FLOPs / its launch time measured with HIP events on the launch stream inside the
+timed region.  `cpu_baseline` times the oracle's torch-CPU port of the same step on the host cores (rank 0, N = 1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md chip table
+ALG_GFLOP_PER_IMAGE = 2518.5   # fwd + dgrad + wgrad of all 108 convs at 769x769
+
+
+def synthetic_batch(batch, size, rank, device):
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    x = torch.randn((batch, 3, size, size), generator=g)
+    lab = torch.randint(0, 19, (batch, size, size), generator=g).float()
+    band = 32 if size >= 256 else max(1, size // 24)
+    lab[:, :band] = 255
+    lab[:, -band:] = 255
+    lab[:, :, :band] = 255
+    lab[:, :, -band:] = 255
+    lab[torch.rand((batch, size, size), generator=g) < 0.02] = 255
+    return x.to(device), lab.to(device)
+
+
+def cpu_baseline(size, budget_s=25.0):
+    """The oracle's stock-PyTorch CPU restatement of the same training step (kind 'port'), B = 1, bounded sample."""
+    from oracle import ref_model
+    from rnd_semantic_segmentation_amd.host import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    fe, cls = ref_model.RefFeatureExtractor(), ref_model.RefASPP()
+    synth.load_formula_weights(fe)
+    synth.load_formula_weights(cls)
+    of, oc = ref_model.make_optimizers(fe, cls, 5e-4)
+    x, lab = synthetic_batch(1, size, 0, "cpu")
+    ref_model.ref_train_step(fe, cls, of, oc, x, lab, 0, 100, 5e-4)      # warm-up (oneDNN primitive creation)
+    n, t0 = 0, time.time()
+    while n < 3 and (n == 0 or time.time() - t0 < budget_s):
+        ref_model.ref_train_step(fe, cls, of, oc, x, lab, n + 1, 100, 5e-4)
+        n += 1
+    dt = time.time() - t0
+    return {"value": round(n / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d full train steps (fwd+CE+bwd+2xSGD) of B=1 %dx%d fp32 after 1 warm-up, oracle/ref_model.py" % (n, size, size)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU (BASELINE: 8)")
+    ap.add_argument("--size", type=int, default=769)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py measures the MI355X path; no GPU is visible")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group(backend="nccl", init_method="env://")       # RCCL
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    from rnd_semantic_segmentation_amd import kernels
+    from rnd_semantic_segmentation_amd.host import config as hc
+    from rnd_semantic_segmentation_amd.host import synth
+    from rnd_semantic_segmentation_amd.host.trainer import ASPPTrainer
+
+    cfg = hc.CfgNode(hc.default_tree())
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "deeplabv2_r101_src.yaml"))
+    cfg.merge_from_list(["OUTPUT_DIR", os.path.join(ROOT, "gpurun_out", "bench_out")])
+    cfg.freeze()
+    import logging
+    log = logging.getLogger("bench")
+    log.addHandler(logging.NullHandler())
+    trainer = ASPPTrainer("aspp", cfg, [None] * 1000, local, logger=log)
+    with torch.no_grad():
+        for m in (trainer.feature_extractor, trainer.classifier):
+            synth.load_formula_weights(m)          # O(1) activations; random init explodes
+            st = getattr(m, "_store", None)
+            if st is not None:
+                st.generation += 1
+    x, lab = synthetic_batch(args.batch, args.size, rank, device)
+    max_iter = 100000
+
+    def step():
+        loss, _ = trainer.train_step(x, lab, max_iter)
+        trainer.iteration += 1
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if not args.no_kernel_events:
+        kernels.PROFILE = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    events, kernels.PROFILE = kernels.PROFILE, None
+    final_loss = float(loss)
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        images = args.batch * world * args.steps
+        value = images / elapsed
+        out = {
+            "metric": "train images/sec at 769x769 bf16 (DeepLabV2-ResNet101 + ASPP)", "value": round(value, 3), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "train_src.py DeepLabV2-R101 bf16, %dx%d synthetic Cityscapes crops, batch %d per GPU, %dxMI355X"
+                                   % (args.size, args.size, args.batch, world),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "weights": "formula (synthetic)",
+                       "final_loss": round(final_loss, 5)},
+            "whole_step_mfma_frac": round(ALG_GFLOP_PER_IMAGE * 1e9 * (args.size / 769.0) ** 2 * value / (PEAK_BF16_TFLOPS * 1e12 * world), 4),
+        }
+        if events:
+            by = {}
+            for name, e0, e1, flops in events:
+                d = by.setdefault(name, [0.0, 0.0, 0])
+                d[0] += e0.elapsed_time(e1) * 1e-3
+                d[1] += flops
+                d[2] += 1
+            dom = max(by, key=lambda k: by[k][0])
+            tsec, fl, n = by[dom]
+            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(fl / tsec / 1e12, 2), "peak": PEAK_BF16_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(fl / tsec / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                               "launches_per_step": n // args.steps, "avg_launch_us": round(1e6 * tsec / n, 2),
+                               "alg_gflop_per_launch": round(fl / n / 1e9, 3), "ms_per_step_in_kernel": round(1e3 * tsec / args.steps, 3)}
+            out["kernels"] = {k: {"ms_per_step": round(1e3 * v[0] / args.steps, 3), "tflops": round(v[1] / v[0] / 1e12, 2),
+                                  "launches_per_step": v[2] // args.steps} for k, v in by.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.size)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

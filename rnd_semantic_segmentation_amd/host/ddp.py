@@ -1,0 +1,110 @@
+"""Data-parallel gradient exchange: one process per GPU, bucketed all-reduce of the modules' flat fp32
+gradient buffers over RCCL (torch.distributed backend "nccl" on ROCm) on a side HIP stream, launched while
+the rest of backward is still being enqueued.
+
+The reference never wraps its models ('Parallelism'): base/base_trainer.py:23-24 only sets a flag,
+and dead train_distill.py:48-64 shows the intended recipe (DDP per module, per-rank batch = BATCH_SIZE/world,
+rank-0 checkpointing).  Semantics implemented: gradients are averaged over ranks (mean of per-rank mean
+losses, as DistributedDataParallel does); FrozenBN needs no cross-rank statistics.
+
+Backward produces weight gradients in reverse layer order and the flat buffer is laid out in forward order, so
+finished gradients form a growing suffix of the buffer: buckets are contiguous ranges cut from the end.
+"""
+import torch
+import torch.distributed as dist
+
+
+class _Bucket:
+    __slots__ = ("lo", "hi", "launched", "work")
+
+    def __init__(self, lo, hi):
+        self.lo, self.hi, self.launched, self.work = lo, hi, False, None
+
+
+class GradAllReducer:
+    def __init__(self, stores, bucket_bytes=32 << 20, process_group=None, overlap=True):
+        """stores: FlatStore objects in the order their gradients complete during backward."""
+        self.stores = list(stores)
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.overlap = overlap
+        self.buckets = {}
+        self.lowwater = {}
+        per = max(1, bucket_bytes // 4)
+        for st in self.stores:
+            bks, hi = [], st.total
+            for start in reversed(st.offsets):          # cut at parameter boundaries, from the end of the buffer
+                if hi - start >= per:
+                    bks.append(_Bucket(start, hi))
+                    hi = start
+            if hi > 0:
+                bks.append(_Bucket(0, hi))
+            self.buckets[id(st)] = bks
+            self.lowwater[id(st)] = st.total
+            st.grad_hooks.append(self._on_ready)
+        dev = self.stores[0].grad.device
+        self.cuda = dev.type == "cuda"
+        self.side = torch.cuda.Stream(device=dev) if self.cuda else None
+
+    def _launch(self, st, b):
+        if b.launched or self.world == 1:
+            b.launched = True
+            return
+        b.launched = True
+        chunk = st.grad[b.lo:b.hi]
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.side.wait_event(ev)
+            with torch.cuda.stream(self.side):
+                chunk.div_(self.world)                       # pre-divide: sum of 1/N-scaled == average
+                b.work = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        else:
+            chunk.div_(self.world)
+            b.work = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
+    def _on_ready(self, st, lo, hi):
+        """Engine callback: gradients of [lo, hi) are enqueued; everything above the low-water mark is final."""
+        if not self.overlap:
+            return
+        key = id(st)
+        self.lowwater[key] = min(self.lowwater[key], lo)
+        for b in self.buckets[key]:
+            if not b.launched and b.lo >= self.lowwater[key]:
+                self._launch(st, b)
+
+    def _adopt_foreign_grads(self, st):
+        """Parameters whose .grad is not the flat view (plain autograd + foreign optimizer): copy in, re-point."""
+        for p in st.params:
+            view = st.grad_view(p)
+            if p.grad is None:
+                view.zero_()
+                p.grad = view
+            elif p.grad.data_ptr() != view.data_ptr():
+                view.copy_(p.grad)
+                p.grad = view
+
+    def finish(self):
+        """Call after loss.backward(), before optimizer.step(): reduce what is left, then make the compute
+        stream wait for the side stream."""
+        for st in self.stores:
+            self._adopt_foreign_grads(st)
+            for b in self.buckets[id(st)]:
+                self._launch(st, b)
+        for st in self.stores:
+            for b in self.buckets[id(st)]:
+                if b.work is not None:
+                    b.work.wait()
+                    b.work = None
+                b.launched = False
+            self.lowwater[id(st)] = st.total
+        if self.cuda and self.world > 1:
+            torch.cuda.current_stream().wait_stream(self.side)
+
+    def broadcast_parameters(self, src=0):
+        """Rank-0 weights everywhere before the first step (what DDP's constructor does)."""
+        if self.world == 1:
+            return
+        for st in self.stores:
+            dist.broadcast(st.data, src=src, group=self.pg)
+            st.generation += 1

@@ -1,0 +1,363 @@
+"""The MI355X execution engine of the DeepLabV2 hot path: a static schedule of C-ABI kernel launches
+(forward AND hand-written backward) over NHWC bf16 buffers, exposed to PyTorch as autograd Functions.
+
+What it replaces in the reference: the eager op-by-op execution of
+core/components/resnet.py:93-113 (Bottleneck.forward: conv, FrozenBN, ReLU, residual) for every
+block of layer1..layer4, core/models/classifiers/aspp/classifier.py:26-32 (ASPP forward) and the
+autograd-generated backward of both, plus `criterion(output, label)` of
+core/trainers/aspp_trainer.py:89-92.
+
+Design: one process per GPU owns the schedule.  FrozenBN (+ReLU, +residual) lives in the GEMM
+epilogues; in backward the ReLU masks are applied in the epilogue of the data-gradient GEMM that
+produces the tensor, and FrozenBN scales are folded into the packed dgrad weights / the wgrad
+reduction.  Weight gradients are written by the wgrad reduce kernel straight into each
+parameter's `.grad` (a view of one flat fp32 buffer per module -> fused SGD and bucketed RCCL
+all-reduce work on contiguous ranges).  No tensor of the schedule ever visits the CPU.
+"""
+import torch
+
+from .. import kernels as K
+from . import arch
+
+
+# ------------------------------------------------------------------------------------------------ flat storage
+class FlatStore:
+    """One contiguous fp32 buffer for a module's parameters and one for their gradients."""
+
+    ALIGN = 64  # floats (256 B): every parameter starts on a cache-line boundary
+
+    def __init__(self, named_params, device):
+        self.names = [n for n, _ in named_params]
+        self.params = [p for _, p in named_params]
+        self.offsets = []
+        off = 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += -(-p.numel() // self.ALIGN) * self.ALIGN
+        self.total = off
+        self.data = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=device)
+        self.written = set()      # ids of params whose .grad the engine has overwritten since zero_grad
+        self.generation = 0       # bumped by FusedSGD.step (raw-pointer updates do not bump torch versions)
+        self.grad_hooks = []      # callables(store, lo, hi) fired when grads [lo, hi) are final (DDP)
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                v = self.data[o:o + p.numel()].view_as(p)
+                v.copy_(p.data)
+                p.data = v
+                p.grad = self.grad[o:o + p.numel()].view_as(p)
+                p._mi_store = self
+                p._mi_off = o
+
+    def owns(self, p):
+        return getattr(p, "_mi_store", None) is self and p.data_ptr() == self.data.data_ptr() + 4 * p._mi_off
+
+    def intact(self):
+        return all(self.owns(p) for p in self.params)
+
+    def grad_view(self, p):
+        return self.grad[p._mi_off:p._mi_off + p.numel()].view_as(p)
+
+    def span(self, params):
+        """[lo, hi) float range covering `params` (must be consecutive in this store)."""
+        lo = min(p._mi_off for p in params)
+        hi = max(p._mi_off + -(-p.numel() // self.ALIGN) * self.ALIGN for p in params)
+        return lo, hi
+
+
+def grad_slot(p):
+    """Where the engine writes d loss / d p, and whether to accumulate into it."""
+    st = getattr(p, "_mi_store", None)
+    if st is not None and st.owns(p):
+        want = st.grad.data_ptr() + 4 * p._mi_off
+        if p.grad is None or p.grad.data_ptr() != want:
+            p.grad = st.grad_view(p)          # a foreign optimizer's zero_grad(set_to_none=True) dropped it
+            st.written.discard(id(p))
+        acc = id(p) in st.written
+        st.written.add(id(p))
+        return p.grad, acc
+    if p.grad is None:
+        p.grad = torch.empty_like(p, memory_format=torch.contiguous_format)
+        return p.grad, False
+    return p.grad, True
+
+
+# ------------------------------------------------------------------------------------------------ backbone stages
+class _ConvRT:
+    __slots__ = ("spec", "weight", "bn", "scale", "shift", "wp", "wpt")
+
+    def __init__(self, spec, weight, bn):
+        self.spec, self.weight, self.bn = spec, weight, bn
+        self.scale = self.shift = self.wp = self.wpt = None
+
+
+class StageEngine:
+    """layer1..layer4 of the dilated ResNet as a kernel schedule."""
+
+    def __init__(self, owner, plan):
+        self.owner = owner                     # the feature-extractor module (holds params/buffers)
+        self.plan = plan
+        self.blocks = []
+        for blk in plan:
+            rts = []
+            for c in arch.block_convs(blk):
+                rts.append(_ConvRT(c, arch.node_at(owner.backbone, c.key).weight, arch.node_at(owner.backbone, c.bn)))
+            self.blocks.append((blk, rts))
+        self.convs = [rt for _, rts in self.blocks for rt in rts]
+        self._bn_sig = None
+        self._pack_sig = None
+        self._have_dgrad = False
+
+    # -- preparation: FrozenBN folds and bf16 operand packs, redone only when their sources changed
+    def _signature(self):
+        store = getattr(self.convs[0].weight, "_mi_store", None)
+        gen = store.generation if store is not None else -1
+        return (gen, sum(rt.weight._version for rt in self.convs), self.convs[0].weight.data_ptr())
+
+    def prepare(self, train):
+        bn_sig = sum(b._version for rt in self.convs for b in (rt.bn.weight, rt.bn.bias, rt.bn.running_mean, rt.bn.running_var))
+        bn_sig = (bn_sig, self.convs[0].bn.weight.data_ptr())
+        refold = bn_sig != self._bn_sig
+        if refold:
+            for rt in self.convs:
+                rt.scale, rt.shift = K.frozen_bn_fold(rt.bn.weight, rt.bn.bias, rt.bn.running_mean, rt.bn.running_var)
+            self._bn_sig = bn_sig
+        sig = self._signature()
+        if sig != self._pack_sig or refold or (train and not self._have_dgrad):
+            for rt in self.convs:
+                w = rt.weight.detach()
+                rt.wp = K.pack_weight_fwd(w, out=rt.wp)
+                if train:
+                    rt.wpt = K.pack_weight_dgrad(w, rt.scale, out=rt.wpt)
+            self._pack_sig = sig
+            self._have_dgrad = train
+
+    # -- forward
+    @staticmethod
+    def _fwd_conv(x, rt, relu, res=None):
+        c = rt.spec
+        hw = arch.out_hw(x.shape[1], x.shape[2], c)
+        return K.conv_gemm(x, rt.wp, hw, c.k, c.stride, c.pad, c.dil, K.GATHER_FWD, scale=rt.scale, bias=rt.shift, res=res, relu=relu)
+
+    def forward(self, x, save):
+        saved = []
+        for blk, rts in self.blocks:
+            a1 = self._fwd_conv(x, rts[0], True)
+            a2 = self._fwd_conv(a1, rts[1], True)
+            idn = self._fwd_conv(x, rts[3], False) if blk.down else x
+            out = self._fwd_conv(a2, rts[2], True, res=idn)
+            if save:
+                saved.append((x, a1, a2))
+            x = out
+        return x, saved
+
+    # -- backward
+    @staticmethod
+    def _wgrad(dy, xin, rt):
+        c = rt.spec
+        dw, acc = grad_slot(rt.weight)
+        K.conv_wgrad(dy, xin, dw, c.k, c.stride, c.pad, c.dil, scale=rt.scale, accumulate=acc)
+
+    @staticmethod
+    def _dgrad(dy, rt, in_hw, res=None, msk=None):
+        c = rt.spec
+        return K.conv_gemm(dy, rt.wpt, in_hw, c.k, c.stride, c.pad, c.dil, K.GATHER_DGRAD, res=res, msk=msk)
+
+    def backward(self, saved, feat, dfeat, need_dx):
+        """dfeat: d loss / d feat (bf16 NHWC).  Returns d loss / d x of the first block (true gradient)."""
+        g = K.relu_mask(dfeat, feat)                      # through the last block's ReLU
+        store = getattr(self.convs[0].weight, "_mi_store", None)
+        for bi in range(len(self.blocks) - 1, -1, -1):
+            blk, rts = self.blocks[bi]
+            x, a1, a2 = saved[bi]
+            first = bi == 0
+            hw_in = (x.shape[1], x.shape[2])
+            hw_mid = (a1.shape[1], a1.shape[2])
+            self._wgrad(g, a2, rts[2])
+            ga2 = self._dgrad(g, rts[2], (a2.shape[1], a2.shape[2]), msk=a2)
+            self._wgrad(ga2, a1, rts[1])
+            ga1 = self._dgrad(ga2, rts[1], hw_mid, msk=a1)
+            self._wgrad(ga1, x, rts[0])
+            if blk.down:
+                self._wgrad(g, x, rts[3])
+            if first and not need_dx:
+                g = None
+            else:
+                skip = self._dgrad(g, rts[3], hw_in) if blk.down else g
+                g = self._dgrad(ga1, rts[0], hw_in, res=skip, msk=None if first else x)
+            saved[bi] = None                              # release activations as we go
+            if store is not None and store.grad_hooks:
+                lo, hi = store.span([rt.weight for rt in rts])
+                for hook in store.grad_hooks:
+                    hook(store, lo, hi)
+        return g
+
+
+class StagesFn(torch.autograd.Function):
+    """pooled stem output [B,H,W,64] bf16 NHWC -> layer4 feature [B,h,w,2048] bf16 NHWC."""
+
+    @staticmethod
+    def forward(ctx, x, eng, *weights):
+        train = torch.is_grad_enabled() and any(w.requires_grad for w in weights)
+        eng.prepare(train)
+        feat, saved = eng.forward(x, save=train)
+        ctx.eng, ctx.saved, ctx.feat = eng, saved, feat
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        dfeat = dfeat.contiguous()
+        dx = ctx.eng.backward(ctx.saved, ctx.feat, dfeat, ctx.needs_input_grad[0])
+        ctx.saved = ctx.feat = None
+        return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+# ------------------------------------------------------------------------------------------------ ASPP head
+class AsppEngine:
+    """Four dilated 3x3 convs (2048 -> K) summed, as ONE plain GEMM over all rates x taps x classes plus a
+    col2im of the tiny K-channel planes; backward as im2col + two plain GEMMs."""
+
+    def __init__(self, owner, rates, num_classes, in_channels):
+        self.owner, self.rates, self.K, self.C = owner, tuple(int(r) for r in rates), num_classes, in_channels
+        self.wall = self.wallT = None
+        self._sig = None
+        self._have_dgrad = False
+
+    def _w4(self):
+        ws = [getattr(self.owner.conv2d_list, str(i)).weight for i in range(4)]
+        n = ws[0].numel()
+        base = ws[0].data_ptr()
+        if all(w.data_ptr() == base + 4 * n * i for i, w in enumerate(ws)):
+            return torch.as_strided(ws[0].detach(), (4,) + tuple(ws[0].shape), (n,) + tuple(ws[0].stride())), ws
+        return torch.stack([w.detach() for w in ws]).contiguous(), ws
+
+    def _b4(self):
+        bs = [getattr(self.owner.conv2d_list, str(i)).bias for i in range(4)]
+        base = bs[0].data_ptr()
+        if all(b.data_ptr() == base + 4 * self.K * i for i, b in enumerate(bs)):
+            return torch.as_strided(bs[0].detach(), (4, self.K), (self.K, 1)), bs
+        return torch.stack([b.detach() for b in bs]).contiguous(), bs
+
+    def prepare(self, train):
+        w4, ws = self._w4()
+        store = getattr(ws[0], "_mi_store", None)
+        sig = (store.generation if store is not None else -1, sum(w._version for w in ws), ws[0].data_ptr())
+        if sig != self._sig or (train and not self._have_dgrad):
+            self.wall = K.aspp_pack_fwd(w4, out=self.wall)
+            if train:
+                self.wallT = K.aspp_pack_dgrad(w4, out=self.wallT)
+            self._sig = sig
+            self._have_dgrad = train
+
+    def forward(self, x):
+        """x [B,h,w,C] bf16 -> low [B,h,w,K] fp32 (1/8-resolution logits, classifier.py:27-29)."""
+        B, h, w, _ = x.shape
+        z = K.conv_gemm(x, self.wall, (h, w), zsplit=K.ASPP_ZGW)
+        b4, _ = self._b4()
+        return K.aspp_col2im(z, b4, B, h, w, self.K, self.rates)
+
+    def backward(self, x, dlow, need_dx, msk=None):
+        """dlow [B,h,w,K] fp32 = d loss / d low.  Writes weight/bias grads, returns d loss / d x (bf16)."""
+        h, w = x.shape[1], x.shape[2]
+        g = K.aspp_im2col(dlow, self.rates)
+        w4, ws = self._w4()
+        b4, bs = self._b4()
+        slots = [grad_slot(p) for p in ws]
+        n = ws[0].numel()
+        base = slots[0][0].data_ptr()
+        stacked = all(s[0].data_ptr() == base + 4 * n * i for i, s in enumerate(slots)) and len({s[1] for s in slots}) == 1
+        if stacked:
+            dw4 = torch.as_strided(slots[0][0], (4,) + tuple(ws[0].shape), (n,) + tuple(ws[0].stride()))
+            K.conv_wgrad(g, x, dw4, out_map=1, accumulate=slots[0][1])
+        else:
+            dw4 = torch.empty((4,) + tuple(ws[0].shape), dtype=torch.float32, device=x.device)
+            K.conv_wgrad(g, x, dw4, out_map=1)
+            for i, (slot, acc) in enumerate(slots):
+                slot.add_(dw4[i]) if acc else slot.copy_(dw4[i])
+        bslots = [grad_slot(p) for p in bs]
+        bbase = bslots[0][0].data_ptr()
+        if all(s[0].data_ptr() == bbase + 4 * self.K * i for i, s in enumerate(bslots)) and len({s[1] for s in bslots}) == 1:
+            K.aspp_bias_grad(dlow, torch.as_strided(bslots[0][0], (4, self.K), (self.K, 1)), accumulate=bslots[0][1])
+        else:
+            db4 = torch.empty((4, self.K), dtype=torch.float32, device=x.device)
+            K.aspp_bias_grad(dlow, db4)
+            for i, (slot, acc) in enumerate(bslots):
+                slot.add_(db4[i]) if acc else slot.copy_(db4[i])
+        store = getattr(ws[0], "_mi_store", None)
+        if store is not None and store.grad_hooks:
+            for hook in store.grad_hooks:
+                hook(store, 0, store.total)
+        if not need_dx:
+            return None
+        return K.conv_gemm(g, self.wallT, (h, w), msk=msk)
+
+
+class AsppFn(torch.autograd.Function):
+    """feature [B,h,w,C] bf16 NHWC -> low-resolution logits [B,h,w,K] fp32 NHWC."""
+
+    @staticmethod
+    def forward(ctx, x, eng, *params):
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        eng.prepare(train)
+        ctx.eng, ctx.x = eng, (x if train else None)
+        return eng.forward(x)
+
+    @staticmethod
+    def backward(ctx, dlow):
+        dx = ctx.eng.backward(ctx.x, dlow.contiguous().float(), ctx.needs_input_grad[0])
+        ctx.x = None
+        return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class AsppLossFn(torch.autograd.Function):
+    """Training fast path: ASPP head + bilinear upsample to the label size + CrossEntropyLoss(ignore_index),
+    i.e. reference aspp_trainer.py:89-91 `criterion(classifier(feat, size), label)`, without materialising the
+    [B,K,H,W] logits.  The loss gradient w.r.t. the low-resolution logits is produced in the same pass."""
+
+    @staticmethod
+    def forward(ctx, x, labels, eng, ignore_index, *params):
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        eng.prepare(train)
+        low = eng.forward(x)
+        loss_out, dlow = K.upsample_ce(low, labels, want_grad=train, ignore_index=ignore_index)
+        ctx.eng, ctx.x, ctx.dlow = eng, (x if train else None), dlow
+        ctx.loss_out = loss_out
+        return loss_out[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        dlow = ctx.dlow * gout
+        dx = ctx.eng.backward(ctx.x, dlow, ctx.needs_input_grad[0])
+        ctx.x = ctx.dlow = None
+        return (dx, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
+
+
+class UpsampleFn(torch.autograd.Function):
+    """low [B,h,w,K] fp32 NHWC -> [B,K,H,W] fp32 NCHW, bilinear align_corners=True (classifier.py:31)."""
+
+    @staticmethod
+    def forward(ctx, low, size):
+        ctx.hw = (low.shape[1], low.shape[2])
+        return K.upsample_ac_fwd(low, tuple(int(s) for s in size))
+
+    @staticmethod
+    def backward(ctx, dup):
+        return K.upsample_ac_bwd(dup.contiguous(), ctx.hw), None
+
+
+class SoftmaxCEFn(torch.autograd.Function):
+    """CrossEntropyLoss(ignore_index) on materialised [B,K,H,W] fp32 logits (aspp_trainer.py:61,91)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index):
+        logits = logits.contiguous()
+        out = K.softmax_ce_fwd(logits, labels, ignore_index)
+        ctx.save_for_backward(logits, labels, out)
+        ctx.ignore_index = ignore_index
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        logits, labels, out = ctx.saved_tensors
+        d = K.softmax_ce_bwd(logits, labels, out, 1.0, ctx.ignore_index)
+        return d * gout, None, None

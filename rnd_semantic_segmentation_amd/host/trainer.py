@@ -1,0 +1,179 @@
+"""ASPPTrainer: the reference's source-only training loop (core/trainers/aspp_trainer.py:15-145) on the
+MI355X engine.  Same constructor, attributes (feature_extractor, classifier, optimizer_fea, optimizer_cls,
+iteration, checkpoint ...), checkpoint dict / file names (Aspp-{epoch}.pth), log line format and
+aspp_chart_params.json.
+
+Differences, all on the host side:
+ * the step is `classifier.loss(feat, label)` (fused ASPP + upsample + CE) when the classifier offers it,
+   else criterion(classifier(feat, size), label) exactly like aspp_trainer.py:89-91;
+ * loss values stay on the device and are fetched every 20 iterations (when the reference logs), not with a
+   `.item()` sync per step (aspp_trainer.py:96,106);
+ * WORLD_SIZE > 1: gradients are averaged over ranks by host/ddp.py (RCCL) before the optimizer step, rank 0
+   logs and checkpoints; images/s is added to the log line.
+"""
+import datetime
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+from . import ddp
+from .metrics import MetricLogger, adjust_learning_rate, dump_json, strip_prefix_if_present
+from .modules import build_classifier, build_feature_extractor
+from .plugin import BaseTrainer
+from .sgd import FusedSGD
+
+
+class ASPPTrainer(BaseTrainer):
+    def __init__(self, name, cfg, train_loader, local_rank, logger=None):
+        super(ASPPTrainer, self).__init__(name, cfg, train_loader, local_rank, logger)
+
+    # factories are attributes so that tests / other plugins can substitute modules
+    build_feature_extractor = staticmethod(build_feature_extractor)
+    build_classifier = staticmethod(build_classifier)
+
+    def make_optimizer(self, params, lr):
+        cls = FusedSGD if self.device.type == "cuda" else torch.optim.SGD
+        return cls(params, lr=lr, momentum=self.cfg.SOLVER.MOMENTUM, weight_decay=self.cfg.SOLVER.WEIGHT_DECAY)
+
+    def init_params(self):
+        self.feature_extractor = self.build_feature_extractor(self.cfg)
+        self.feature_extractor.to(self.device)
+        self.classifier = self.build_classifier(self.cfg)
+        self.classifier.to(self.device)
+        for m in (self.feature_extractor, self.classifier):
+            if hasattr(m, "ensure_flat") and self.device.type == "cuda":
+                m.ensure_flat()
+        self.optimizer_fea = self.make_optimizer(self._ordered_params(self.feature_extractor), self.cfg.SOLVER.BASE_LR)
+        self.optimizer_cls = self.make_optimizer(self._ordered_params(self.classifier), self.cfg.SOLVER.BASE_LR * 10)
+        self.iteration = 0
+        self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world_size > 1 else 0
+        self.distributed = self.world_size > 1
+        self.reducer = None
+        if self.distributed:
+            stores = [m.ensure_flat() if hasattr(m, "ensure_flat") else _cpu_store(m) for m in (self.classifier, self.feature_extractor)]
+            self.reducer = ddp.GradAllReducer(stores)
+            self.reducer.broadcast_parameters(0)
+
+    @staticmethod
+    def _ordered_params(module):
+        if hasattr(module, "engine_parameters") and getattr(module, "_store", None) is not None:
+            return [p for _, p in module.engine_parameters()]
+        return list(module.parameters())
+
+    def _load_checkpoint(self):
+        self.checkpoint = torch.load(self.cfg.resume, map_location=self.device)
+        self.feature_extractor.load_state_dict(strip_prefix_if_present(self.checkpoint["feature_extractor"], "module."))
+        self.classifier.load_state_dict(strip_prefix_if_present(self.checkpoint["classifier"], "module."))
+        if "optimizer_fea" in self.checkpoint:
+            self.logger.info("Loading optimizer_fea from {}".format(self.cfg.resume))
+            self.optimizer_fea.load_state_dict(self.checkpoint["optimizer_fea"])
+        if "optimizer_cls" in self.checkpoint:
+            self.logger.info("Loading optimizer_cls from {}".format(self.cfg.resume))
+            self.optimizer_cls.load_state_dict(self.checkpoint["optimizer_cls"])
+        if "iteration" in self.checkpoint:
+            self.iteration = self.checkpoint["iteration"]
+        if "epoch" in self.checkpoint:
+            self.start_epoch = self.checkpoint["epoch"] + 1
+
+    def _save_checkpoint(self, epoch, save_path):
+        clone = lambda sd: {k: v.detach().clone() for k, v in sd.items()}    # un-share the flat storage
+        checkpoint = {
+            "epoch": epoch,
+            "iteration": self.iteration,
+            "feature_extractor": clone(self.feature_extractor.state_dict()),
+            "classifier": clone(self.classifier.state_dict()),
+            "optimizer_fea": self.optimizer_fea.state_dict(),
+            "optimizer_cls": self.optimizer_cls.state_dict(),
+        }
+        torch.save(checkpoint, save_path)
+
+    def train_step(self, src_input, src_label, max_iter):
+        """aspp_trainer.py:77-95 for one minibatch; returns the loss as a device tensor (no sync)."""
+        current_lr = adjust_learning_rate(self.cfg.SOLVER.LR_METHOD, self.cfg.SOLVER.BASE_LR, self.iteration, max_iter,
+                                          power=self.cfg.SOLVER.LR_POWER)
+        for group in self.optimizer_fea.param_groups:
+            group["lr"] = current_lr
+        for group in self.optimizer_cls.param_groups:
+            group["lr"] = current_lr * 10
+        self.optimizer_fea.zero_grad()
+        self.optimizer_cls.zero_grad()
+        src_input = src_input.to(self.device, non_blocking=True)
+        src_label = src_label.to(self.device, non_blocking=True).long()
+        feat = self.feature_extractor(src_input)
+        if hasattr(self.classifier, "loss"):
+            loss = self.classifier.loss(feat, src_label, self.cfg.INPUT.IGNORE_LABEL)
+        else:
+            output = self.classifier(feat, src_label.shape[-2:])
+            loss = torch.nn.functional.cross_entropy(output, src_label, ignore_index=self.cfg.INPUT.IGNORE_LABEL)
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        self.optimizer_fea.step()
+        self.optimizer_cls.step()
+        return loss.detach(), current_lr
+
+    def train(self):
+        output_dir = self.cfg.OUTPUT_DIR
+        save_to_disk = self.local_rank == 0 and self.rank == 0
+        self.iteration = (self.start_epoch - 1) * len(self.train_loader)
+        max_iter = self.cfg.SOLVER.EPOCHS * len(self.train_loader)
+        if self.rank == 0:
+            self.logger.info("#" * 20 + " Start Training " + "#" * 20)
+        meters = MetricLogger(delimiter="  ")
+        self.feature_extractor.train()
+        self.classifier.train()
+        start_training_time = time.time()
+        end = time.time()
+        pending = []          # (device loss, lr) not yet fetched
+        images = 0
+
+        def flush():
+            for l, lr in pending:
+                v = float(l)
+                meters.update(loss_seg=v)
+                self.loss_data.append(v)
+                self.lr_data.append(lr)
+            pending.clear()
+
+        for epoch in range(self.start_epoch, self.cfg.SOLVER.EPOCHS + 1):
+            for i, (src_input, src_label, _) in enumerate(self.train_loader):
+                data_time = time.time() - end
+                loss, lr = self.train_step(src_input, src_label, max_iter)
+                pending.append((loss, lr))
+                self.iteration += 1
+                images += src_input.shape[0] * self.world_size
+                log_now = self.iteration % 20 == 0 or self.iteration == max_iter
+                if log_now:
+                    flush()                                   # the only device sync of the loop
+                batch_time = time.time() - end
+                end = time.time()
+                meters.update(time=batch_time, data=data_time)
+                if log_now and self.rank == 0:
+                    eta_seconds = meters.time.global_avg * (max_iter - self.iteration)
+                    mem = torch.cuda.max_memory_allocated() / 1024.0 / 1024.0 if self.device.type == "cuda" else 0.0
+                    self.logger.info(meters.delimiter.join([
+                        "Epoch: {epoch}", "eta: {eta}", "iter: {iter}", "{meters}", "lr: {lr:.6f}", "max mem: {memory:.0f}",
+                        "img/s: {ips:.2f}"]).format(
+                        epoch=epoch, eta=str(datetime.timedelta(seconds=int(eta_seconds))), iter=self.iteration, meters=str(meters),
+                        lr=self.optimizer_fea.param_groups[0]["lr"], memory=mem, ips=images / max(time.time() - start_training_time, 1e-9)))
+            flush()
+            if epoch % self.cfg.SOLVER.CHECKPOINT_PERIOD == 0 and save_to_disk:
+                os.makedirs(output_dir, exist_ok=True)
+                self._save_checkpoint(epoch, os.path.join(output_dir, "Aspp-{}.pth".format(epoch)))
+        total_training_time = time.time() - start_training_time
+        if self.rank == 0:
+            self.logger.info("Total training time: {} ({:.4f} s / epoch)".format(
+                str(datetime.timedelta(seconds=total_training_time)), total_training_time / max(self.cfg.SOLVER.EPOCHS, 1)))
+        if save_to_disk:
+            os.makedirs(output_dir, exist_ok=True)
+            dump_json(os.path.join(output_dir, "aspp_chart_params.json"), {"learning rate": self.lr_data, "loss": self.loss_data})
+
+
+def _cpu_store(module):
+    """Flat storage for a module that does not bring its own (stand-in models in multi-process CPU tests)."""
+    from .engine import FlatStore
+    named = list(module.named_parameters())
+    return FlatStore(named, named[0][1].device)

@@ -20,6 +20,22 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Optional per-launch timing with HIP events on the launch stream (bench.py): set to a list to collect
+# (kernel_name, start_event, stop_event, algorithmic_flops) tuples; None = no overhead.
+PROFILE = None
+
+
+def _timed(name, flops, launch):
+    if PROFILE is None:
+        return launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = launch()
+    e1.record()
+    PROFILE.append((name, e0, e1, flops))
+    return rc
+
+
 def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -89,8 +105,13 @@ def conv_gemm(a, wp, out_hw, ksize=1, stride=1, pad=0, dil=1, mode=GATHER_FWD, s
             out = torch.empty((B, Ho, Wo, N), dtype=torch.float32, device=a.device)
     elif out is None:
         out = torch.empty((B, Ho, Wo, N), dtype=torch.bfloat16, device=a.device)
-    check(_lib.lib().mi_conv_gemm(_p(a), _p(wp), _p(out), B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, pad, dil, mode,
-                                   _p(scale), _p(bias), _p(res), _p(msk), flags, zsplit, _stream()), "mi_conv_gemm")
+    # algorithmic FLOPs (2 * pixels * C_out * C_in * k^2), padding columns of the ASPP operands excluded
+    n_real = N * 19 // 20 if zsplit else N
+    ca_real = 684 if Ca == ASPP_KPAD else Ca
+    flops = 2.0 * B * Ho * Wo * n_real * ca_real * ksize * ksize
+    check(_timed("igemm_nt_kernel", flops, lambda: _lib.lib().mi_conv_gemm(
+        _p(a), _p(wp), _p(out), B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, pad, dil, mode,
+        _p(scale), _p(bias), _p(res), _p(msk), flags, zsplit, _stream())), "mi_conv_gemm")
     return out
 
 
@@ -116,8 +137,11 @@ def conv_wgrad(dy, x, dw, ksize=1, stride=1, pad=0, dil=1, scale=None, accumulat
     L = _lib.lib()
     need = L.mi_conv_wgrad_workspace(B, Ho, Wo, O, I, ksize)
     ws = _workspace(need, dy.device, "wgrad")
-    check(L.mi_conv_wgrad(_p(dy), _p(x), _p(dw), B, Ha, Wa, I, Ho, Wo, O, ksize, stride, pad, dil, _p(scale),
-                          int(accumulate), out_map, _p(ws), ws.numel(), _stream()), "mi_conv_wgrad")
+    o_real = 684 if out_map == 1 else O
+    flops = 2.0 * B * Ho * Wo * o_real * I * ksize * ksize
+    check(_timed("wgrad_tn_kernel+reduce", flops, lambda: L.mi_conv_wgrad(
+        _p(dy), _p(x), _p(dw), B, Ha, Wa, I, Ho, Wo, O, ksize, stride, pad, dil, _p(scale),
+        int(accumulate), out_map, _p(ws), ws.numel(), _stream())), "mi_conv_wgrad")
     return dw
 
 

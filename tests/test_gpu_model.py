@@ -1,0 +1,183 @@
+"""GPU parity of the whole hot path: product modules (MI355X engine, bf16 operands / fp32 accumulate) vs
+(a) an oracle that EMULATES the engine's rounding points in fp32 torch on CPU (tight: checks the schedule,
+    forward and hand-written backward, layer by layer), and
+(b) the reference's fp32 golden vectors (loose: bf16 regime; SURVEY 7 'Tolerance regime').
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import _cases
+from oracle import ref_model
+from rnd_semantic_segmentation_amd.host import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+def emulated_forward(fe, cls, x, size=None):
+    """oracle graph with the engine's rounding points: bf16 conv operands, fp32 accumulate + FrozenBN (+res, ReLU) in
+    fp32, outputs stored bf16; ASPP accumulates fp32 and stays fp32."""
+    bb = fe.backbone
+
+    def bn(t, path):
+        b = ref_model._box_path(bb, path)
+        scale = b.weight * b.running_var.rsqrt()
+        return t * scale.reshape(1, -1, 1, 1) + (b.bias - b.running_mean * scale).reshape(1, -1, 1, 1)
+
+    w = lambda path: bf(ref_model._box_path(bb, path).weight)
+    y = F.conv2d(bf(x), w("conv1"), None, 2, 3)
+    y = bf(F.relu(bn(bf(y), "bn1")))            # stem on torch ops: conv output bf16, BN in fp32, stored bf16
+    y = F.max_pool2d(y, 3, 2, 1)
+    for blk in fe.plan:
+        n = blk["name"]
+        a1 = bf(F.relu(bn(F.conv2d(y, w(n + ".conv1")), n + ".bn1")))
+        a2 = bf(F.relu(bn(F.conv2d(a1, w(n + ".conv2"), None, blk["stride"], blk["dil"], blk["dil"]), n + ".bn2")))
+        idt = y
+        if blk["down"]:
+            idt = bf(bn(F.conv2d(y, w(n + ".downsample.0"), None, blk["stride"]), n + ".downsample.1"))
+        y = bf(F.relu(bn(F.conv2d(a2, w(n + ".conv3")), n + ".bn3") + idt))
+    feat = y
+    low = None
+    for i, r in enumerate(cls.rates):
+        box = getattr(cls.conv2d_list, str(i))
+        t = F.conv2d(feat, bf(box.weight), box.bias, 1, r, r)
+        low = t if low is None else low + t
+    if size is not None:
+        return feat, low, F.interpolate(low, size=size, mode="bilinear", align_corners=True)
+    return feat, low, None
+
+
+def make_pair(layers):
+    from rnd_semantic_segmentation_amd.host import modules
+    rfe, rcls = ref_model.RefFeatureExtractor(layers), ref_model.RefASPP()
+    synth.load_formula_weights(rfe)
+    synth.load_formula_weights(rcls)
+    fe = modules.resnet_feature_extractor("resnet101", freeze_bn=True, pretrained_backbone=False, layers=layers)
+    cls = modules.ASPP_Classifier_V2(2048, [6, 12, 18, 24], [6, 12, 18, 24], 19)
+    synth.load_formula_weights(fe)
+    synth.load_formula_weights(cls)
+    return rfe, rcls, fe.cuda(), cls.cuda()
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def test_tinynet_forward_backward_vs_rounding_emulating_oracle():
+    rfe, rcls, fe, cls = make_pair((1, 1, 2, 2))
+    x, lab = _cases.net_inputs(2, 65, 11)
+    xt, lt = torch.from_numpy(x), torch.from_numpy(lab)
+    # product
+    feat = fe(xt.cuda())
+    low = cls(feat)
+    loss = cls.loss(feat, lt.cuda().long())
+    loss.backward()
+    # emulating oracle (autograd through the same graph; rounding is straight-through)
+    efeat, elow, eup = emulated_forward(rfe, rcls, xt, size=(65, 65))
+    eloss = F.cross_entropy(eup, lt.long(), ignore_index=255)
+    eloss.backward()
+    assert rel(feat.float().cpu().numpy(), efeat.detach().numpy()) < 2e-2        # bf16 storage: ulp flips allowed
+    r_low = rel(low.float().cpu().numpy(), elow.detach().numpy())
+    assert r_low < 5e-3, r_low
+    assert abs(loss.item() - eloss.item()) < 2e-3 * abs(eloss.item())
+    # every parameter gradient: direction and size (bf16 gradient storage -> percent-level)
+    ref_grads = {k: p.grad for m in (rfe, rcls) for k, p in m.named_parameters()}
+    got = {k: p.grad for m in (fe, cls) for k, p in m.named_parameters()}
+    worst = 0.0
+    for k, g in ref_grads.items():
+        a = got[k].float().cpu().double().flatten()
+        b = g.double().flatten()
+        cos = torch.dot(a, b) / (a.norm() * b.norm() + 1e-300)
+        ratio = a.norm() / (b.norm() + 1e-300)
+        worst = max(worst, 1 - cos.item(), abs(ratio.item() - 1))
+        assert cos > 0.995 and abs(ratio - 1) < 0.03, (k, cos.item(), ratio.item())
+    print("tinynet: rel(low)=%.2e worst grad deviation=%.3e" % (r_low, worst))
+
+
+def test_tinynet_vs_reference_golden_fp32_and_bf16_regime():
+    """Against the reference's own numbers (g5 fp32, g9 CPU-autocast bf16): bf16-regime tolerances."""
+    g5, g9 = _cases.load("g5_tinynet_fp32"), _cases.load("g9_tinynet_bf16")
+    rfe, rcls, fe, cls = make_pair((1, 1, 2, 2))
+    x, lab = _cases.net_inputs(2, 65, 11)
+    with torch.no_grad():
+        low = cls(fe(torch.from_numpy(x).cuda())).float().cpu().numpy()
+    e_fp32 = rel(low, g5["low"])
+    e_ref_bf16 = rel(g9["low"], g5["low"])              # what the reference itself loses under bf16 autocast
+    print("tinynet low vs reference fp32: ours %.3e, reference-under-autocast %.3e" % (e_fp32, e_ref_bf16))
+    assert e_fp32 < max(2 * e_ref_bf16, 3e-2)
+
+
+def test_tinynet_three_sgd_steps_track_reference_losses():
+    from rnd_semantic_segmentation_amd.host import sgd
+    g5 = _cases.load("g5_tinynet_fp32")
+    _, _, fe, cls = make_pair((1, 1, 2, 2))
+    fe.ensure_flat()
+    cls.ensure_flat()
+    of = sgd.FusedSGD([p for _, p in fe.engine_parameters()], lr=5e-4, momentum=0.9, weight_decay=5e-4)
+    oc = sgd.FusedSGD([p for _, p in cls.engine_parameters()], lr=5e-3, momentum=0.9, weight_decay=5e-4)
+    x, lab = _cases.net_inputs(2, 65, 11)
+    xt, lt = torch.from_numpy(x).cuda(), torch.from_numpy(lab).cuda().long()
+    losses = []
+    for it in range(3):
+        lr = 5e-4 * ((1 - it / 30) ** 0.9)
+        for gr in of.param_groups:
+            gr["lr"] = lr
+        for gr in oc.param_groups:
+            gr["lr"] = lr * 10
+        of.zero_grad()
+        oc.zero_grad()
+        loss = cls.loss(fe(xt), lt)
+        loss.backward()
+        of.step()
+        oc.step()
+        losses.append(loss.item())
+    print("losses", losses, "reference", g5["loss"])
+    assert np.allclose(losses, g5["loss"], rtol=3e-2)
+    assert losses[2] < losses[0]
+    # momentum buffers keep torch's state_dict format
+    sd = oc.state_dict()
+    assert set(sd) == {"state", "param_groups"} and "momentum_buffer" in sd["state"][0]
+
+
+def test_r101_129_vs_reference_golden_and_dropin_api():
+    """Full ResNet-101 + ASPP, 1x3x129x129, formula weights: reference fp32 golden (g6) vs the engine, through the
+    reference's own API surface (build_* factories, classifier(feat, size), inference())."""
+    from core.configs import cfg as global_cfg
+    from core.models.build import build_classifier, build_feature_extractor
+    from core.utils.utility import inference, intersectionAndUnionGPU
+    g = _cases.load("g6_r101_129")
+    cfg = global_cfg.clone()
+    cfg.defrost()
+    cfg.merge_from_list(["MODEL.FREEZE_BN", True, "MODEL.NUM_CLASSES", 19])
+    fe, cls = build_feature_extractor(cfg), build_classifier(cfg)
+    synth.load_formula_weights(fe)
+    synth.load_formula_weights(cls)
+    fe.cuda().eval()
+    cls.cuda().eval()
+    x, lab = _cases.net_inputs(1, 129, 21)
+    xt, lt = torch.from_numpy(x).cuda(), torch.from_numpy(lab).cuda()
+    with torch.no_grad():
+        feat = fe(xt)
+        assert feat.shape == (1, 2048, 17, 17)
+        low = cls(feat)
+        up = cls(feat, (129, 129))
+    e_low = rel(low.float().cpu().numpy(), g["low"])
+    print("r101@129 low vs reference fp32: %.3e (|low|max %.2f)" % (e_low, np.abs(g["low"]).max()))
+    assert e_low < 5e-2                                                   # bf16 regime through 33 blocks
+    probs = inference(fe, cls, xt, lt, flip=False)
+    assert probs.shape == (1, 19, 129, 129)
+    pred = probs.max(1)[1]
+    agree = (pred.cpu().numpy().astype(np.uint8) == g["pred"]).mean()
+    print("argmax agreement with the fp32 reference: %.4f" % agree)
+    assert agree > 0.85            # random-weight nets have near-tied logits (88.6 % measured for bf16 autocast)
+    assert torch.equal(pred, up.argmax(1))                               # same tensor through both API routes
+    inter, union, target, res = intersectionAndUnionGPU(pred.clone(), lt.long(), 19, 255)
+    assert float(target.sum()) == float((lab != 255).sum())
+    # flip=True path runs
+    assert inference(fe, cls, xt, lt, flip=True).shape == (1, 19, 129, 129)
