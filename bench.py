@@ -29,7 +29,9 @@ ALG_GFLOP_PER_IMAGE = 2518.5   # fwd + dgrad + wgrad of all 108 convs at 769x769
 def synthetic_batch(batch, size, rank, device):
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     x = torch.randn((batch, 3, size, size), generator=g)
-    lab = torch.randint(0, 19, (batch, size, size), generator=g).float()
+    cell = 64                                                     # blocky class regions, like real label maps
+    n = -(-size // cell)
+    lab = torch.randint(0, 19, (batch, n, n), generator=g).repeat_interleave(cell, 1).repeat_interleave(cell, 2)[:, :size, :size].float().contiguous()
     band = 32 if size >= 256 else max(1, size // 24)
     lab[:, :band] = 255
     lab[:, -band:] = 255
@@ -43,7 +45,11 @@ def cpu_baseline(size, budget_s=25.0):
     """The oracle's stock-PyTorch CPU restatement of the same training step (kind 'port'), B = 1, bounded sample."""
     from oracle import ref_model
     from rnd_semantic_segmentation_amd.host import synth
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))                    # a 1-GPU box grants a 16-core share
     torch.set_num_threads(cores)
     fe, cls = ref_model.RefFeatureExtractor(), ref_model.RefASPP()
     synth.load_formula_weights(fe)
@@ -52,12 +58,19 @@ def cpu_baseline(size, budget_s=25.0):
     x, lab = synthetic_batch(1, size, 0, "cpu")
     ref_model.ref_train_step(fe, cls, of, oc, x, lab, 0, 100, 5e-4)      # warm-up (oneDNN primitive creation)
     n, t0 = 0, time.time()
-    while n < 3 and (n == 0 or time.time() - t0 < budget_s):
+    while n < 2 and (n == 0 or time.time() - t0 < budget_s):
         ref_model.ref_train_step(fe, cls, of, oc, x, lab, n + 1, 100, 5e-4)
         n += 1
     dt = time.time() - t0
     return {"value": round(n / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "%d full train steps (fwd+CE+bwd+2xSGD) of B=1 %dx%d fp32 after 1 warm-up, oracle/ref_model.py" % (n, size, size)}
+
+
+_T0 = time.time()
+
+
+def note(msg):
+    print("[bench %7.1fs] %s" % (time.time() - _T0, msg), file=sys.stderr, flush=True)
 
 
 def main():
@@ -94,7 +107,9 @@ def main():
     import logging
     log = logging.getLogger("bench")
     log.addHandler(logging.NullHandler())
+    note("building model")
     trainer = ASPPTrainer("aspp", cfg, [None] * 1000, local, logger=log)
+    note("formula weights")
     with torch.no_grad():
         for m in (trainer.feature_extractor, trainer.classifier):
             synth.load_formula_weights(m)          # O(1) activations; random init explodes
@@ -109,9 +124,16 @@ def main():
         trainer.iteration += 1
         return loss
 
-    for _ in range(args.warmup):
+    note("warm-up")
+    for i in range(args.warmup):
         loss = step()
+        if i == 0:
+            torch.cuda.synchronize()
+            note("first step done")
+        if os.environ.get("MI_BENCH_VERBOSE"):
+            note("warm-up step %d loss %.5f" % (i, float(loss)))
     torch.cuda.synchronize()
+    note("timed region")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -125,6 +147,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    note("timed region done: %.1f ms/step" % (1000 * elapsed / args.steps))
     events, kernels.PROFILE = kernels.PROFILE, None
     final_loss = float(loss)
     if world > 1:

@@ -5,6 +5,8 @@ missing, and every wrapper in kernels.py insists on CUDA (HIP) tensors.
 """
 import ctypes
 import os
+
+import torch  # noqa: F401  (first: the process must bind torch's bundled HIP runtime, not a second copy)
 from ctypes import c_char_p, c_float, c_int, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

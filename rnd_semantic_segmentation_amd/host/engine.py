@@ -198,7 +198,7 @@ class StagesFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, eng, *weights):
-        train = torch.is_grad_enabled() and any(w.requires_grad for w in weights)
+        train = any(ctx.needs_input_grad)            # (grad mode is off inside Function.forward)
         eng.prepare(train)
         feat, saved = eng.forward(x, save=train)
         ctx.eng, ctx.saved, ctx.feat = eng, saved, feat
@@ -297,7 +297,7 @@ class AsppFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, eng, *params):
-        train = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        train = any(ctx.needs_input_grad)
         eng.prepare(train)
         ctx.eng, ctx.x = eng, (x if train else None)
         return eng.forward(x)
@@ -316,7 +316,7 @@ class AsppLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, labels, eng, ignore_index, *params):
-        train = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        train = any(ctx.needs_input_grad)
         eng.prepare(train)
         low = eng.forward(x)
         loss_out, dlow = K.upsample_ce(low, labels, want_grad=train, ignore_index=ignore_index)

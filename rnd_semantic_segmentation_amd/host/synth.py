@@ -46,6 +46,11 @@ def uniform(name, shape, salt=0):
 
 
 _SQRT12 = 3.4641016151377544
+# The stem FrozenBN scales activations by ACT_SCALE and every BN shift is proportional to it, so the (positively
+# homogeneous) ReLU network runs at |feature| ~ 0.8, |logit| ~ 1.  At scale 1 the feature common mode makes the very
+# first SGD step at the config's LR (5e-4, classifier x10) overshoot and the loss diverges - in the fp32 reference
+# too (measured: 4.9 -> 8.4 -> 15); at 0.125 it decreases monotonically.
+ACT_SCALE = 0.125
 
 
 def formula_tensor(key, shape):
@@ -53,8 +58,8 @@ def formula_tensor(key, shape):
 
     conv weights : uniform, std = sqrt(2 / fan_in)   (keeps post-ReLU second moment ~1)
     ASPP weights : uniform, std = 0.01               (reference classifier.py:23-24 uses N(0,0.01))
-    FrozenBN     : weight 0.25 for the last BN of a residual branch and 0.5 for a
-                   downsample BN, else 1 (all +-5 %); bias, running_mean small;
+    FrozenBN     : weight 0.25 for the last BN of a residual branch, 0.5 for a downsample BN,
+                   ACT_SCALE for the stem BN, else 1 (all +-5 %); bias, running_mean small (x ACT_SCALE);
                    running_var in [0.8, 1.2]  -> exercises the no-eps rsqrt of
                    reference core/components/layers.py:18-23 without blowing up.
     """
@@ -70,13 +75,14 @@ def formula_tensor(key, shape):
     parent = key.rsplit(".", 1)[0]
     is_bn = parent.rsplit(".", 1)[-1].startswith("bn") or ".downsample.1" in key
     if is_bn:
+        stem = ".layer" not in "." + key and parent.endswith("bn1")
         if leaf == "weight":
-            base = 0.25 if parent.endswith("bn3") else (0.5 if ".downsample.1" in key else 1.0)
+            base = ACT_SCALE if stem else (0.25 if parent.endswith("bn3") else (0.5 if ".downsample.1" in key else 1.0))
             return (base * (1.0 + 0.1 * u)).astype(np.float32)
         if leaf == "bias":
-            return (0.1 * u).astype(np.float32)
+            return (ACT_SCALE * 0.1 * u).astype(np.float32)
         if leaf == "running_mean":
-            return (0.2 * u).astype(np.float32)
+            return ((1.0 if stem else ACT_SCALE) * 0.2 * u).astype(np.float32)
         if leaf == "running_var":
             return (1.0 + 0.4 * u).astype(np.float32)
     if leaf == "weight" and len(shape) == 4:
