@@ -6,12 +6,15 @@
 // (gather mode DGRAD with transposed packed weights), and the two plain GEMMs of the ASPP head.
 // Replaces nn.Conv2d at reference core/components/resnet.py:22-30 + FrozenBN/ReLU/residual at :93-113.
 //
-// Structure (round 1): 128(m) x 128(n) tile, BK = 64 channels of one tap per step, 4 waves (2x2), each wave
-// 64x64 = 4x4 MFMA 16x16x32 tiles.  Operand tiles are staged global -> VGPR -> LDS (16-B chunks, XOR-swizzled
-// 128-B rows so ds_read_b128 is conflict-free), double-buffered with the next tile's global loads issued
-// before the current tile's MFMAs.  Zero padding is predication in the gather, never a materialised im2col.
-// MFMA orientation: D rows = n (weights are the "A" operand), D cols = m, so a lane owns 4 consecutive
-// channels of one pixel and stores them as one 8-byte (bf16) or 16-byte (fp32) vector.
+// Structure: 128(m) x 128(n) tile, BK = 64 channels of one tap per step, 4 waves (2x2), each wave 64x64 = 4x4
+// MFMA 16x16x32 tiles, 2 workgroups per CU.  Operand tiles go global -> LDS directly (global_load_lds, 16 B per
+// lane, 1 KiB = 8 rows per wave-instruction), double-buffered: the next tile's DMA is in flight during the current
+// tile's MFMAs.  The LDS image is lane-linear per DMA, so the bank-conflict XOR swizzle of the 16-B chunks is applied
+// to the per-lane SOURCE address and to the ds_read_b128 address (never to the destination).  Zero padding of the
+// convolution (and M / N tails) is a per-lane source pointer into a zero page - never a materialised im2col.
+// MFMA orientation: D rows = n (weights are the "A" operand), D cols = m.  The weight rows feeding MFMA tile i are
+// permuted (row rho of tile i is channel 16*(rho>>2) + 4*i + (rho&3) of the wave's 64), so that a lane ends up with
+// 16 CONTIGUOUS channels of one pixel: 4 lanes store a whole 128-B line, and residual / mask loads are 16-B wide.
 #include "mi_common.h"
 
 namespace {
@@ -20,6 +23,8 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + B
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;       // double buffer = 64 KiB
+
+__device__ __attribute__((aligned(256))) uint32_t g_zero_page[64];   // source of every padded / out-of-range chunk
 
 struct IgemmParams {
     const __bf16* A;
@@ -54,21 +59,29 @@ __device__ __forceinline__ bool tap_src(const IgemmParams& p, int ho, int wo, in
     return nh < p.Ha && nw < p.Wa;
 }
 
+__device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwg = p.m_tiles * p.n_tiles;
     const int tile = mi_xcd_remap(blockIdx.x, nwg);
     const int mt = tile / p.n_tiles, nt = tile - mt * p.n_tiles;
     const int m0 = mt * BM, n0 = nt * BN;
 
-    // ---- per-thread staging assignment: 4 A chunks + 4 B chunks of 16 B; rows r0 + 32*i, chunk kc ----
-    const int kc = tid & 7, r0 = tid >> 3;
-    int a_img[4], a_ho[4], a_wo[4];   // a_img = b*Ha*Wa (or -1 if the row is past M)
+    // ---- DMA assignment: wave w moves pieces 4w..4w+3 of each operand tile; a piece = 8 rows x 128 B.
+    //      lane -> (row = piece*8 + lane>>3, physical chunk = lane&7); it fetches logical chunk physical ^ s(row).
+    const int prow = lane >> 3, pch = lane & 7;
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+    int a_img[4], a_ho[4], a_wo[4];
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int m = m0 + r0 + 32 * i;
+        const int m = m0 + (wave * 4 + i) * 8 + prow;
         if (m < p.M) {
             const int b = m / HoWo, rem = m - b * HoWo;
             a_ho[i] = rem / p.Wo;
@@ -79,55 +92,61 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
             a_ho[i] = a_wo[i] = 0;
         }
     }
-    bool b_ok[4];
+    const int a_chunk = (pch ^ (prow & 7)) * 16;                       // s_A(row) = row & 7
+    int w_row[4], w_chunk[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) b_ok[i] = (n0 + r0 + 32 * i) < p.N;
+    for (int i = 0; i < 4; ++i) {
+        w_row[i] = n0 + (wave * 4 + i) * 8 + prow;
+        w_chunk[i] = (pch ^ ((prow & 3) | ((i >> 1) << 2))) * 16;      // s_W(row) = (row&3) | ((row>>4)&1)<<2
+    }
 
     const int cpt = p.Ca >> 6;          // 64-channel chunks per tap
     const int nk = p.T * cpt;
-    int ld_t = 0, ld_cc = 0;            // tap / chunk of the NEXT tile to load
-    long a_off[4];                      // element offset of this thread's chunk for the current tap (or -1)
+    int ld_t = 0, ld_cc = 0;            // tap / chunk of the NEXT tile to stage
+    const char* a_ptr[4];
+    const char* w_ptr[4];
+    int a_inc[4], w_inc[4];
 
     auto set_tap = [&](int t) {
         const int ky = t / p.ksz, kx = t - ky * p.ksz;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int ha, wa;
-            if (a_img[i] >= 0 && tap_src(p, a_ho[i], a_wo[i], ky, kx, ha, wa))
-                a_off[i] = ((long)(a_img[i] + ha * p.Wa + wa)) * p.Ca + kc * 8;
-            else
-                a_off[i] = -1;
+            if (a_img[i] >= 0 && tap_src(p, a_ho[i], a_wo[i], ky, kx, ha, wa)) {
+                a_ptr[i] = reinterpret_cast<const char*>(p.A + ((long)(a_img[i] + ha * p.Wa + wa)) * p.Ca) + a_chunk;
+                a_inc[i] = 128;
+            } else {
+                a_ptr[i] = zero;
+                a_inc[i] = 0;
+            }
+            if (w_row[i] < p.N) {
+                w_ptr[i] = reinterpret_cast<const char*>(p.Wp + ((long)t * p.N + w_row[i]) * p.Ca) + w_chunk[i];
+                w_inc[i] = 128;
+            } else {
+                w_ptr[i] = zero;
+                w_inc[i] = 0;
+            }
         }
     };
     set_tap(0);
 
-    u32x4 ra[4], rb[4];
-    auto load_tile = [&]() {
-        const int cbase = ld_cc * 64;
+    auto stage = [&](int buf) {
+        char* sa = smem + buf * STAGE_BYTES + wave * 4096;
+        char* sb = sa + TILE_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            ra[i] = (a_off[i] >= 0) ? *reinterpret_cast<const u32x4*>(p.A + a_off[i] + cbase) : u32x4{0, 0, 0, 0};
+            glds16(a_ptr[i], sa + i * 1024);
+            a_ptr[i] += a_inc[i];
         }
-        const long wrow = (long)ld_t * p.N + n0 + r0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            rb[i] = b_ok[i] ? *reinterpret_cast<const u32x4*>(p.Wp + (wrow + 32 * i) * p.Ca + cbase + kc * 8) : u32x4{0, 0, 0, 0};
+            glds16(w_ptr[i], sb + i * 1024);
+            w_ptr[i] += w_inc[i];
         }
         if (++ld_cc == cpt) {
             ld_cc = 0;
             ++ld_t;
             if (ld_t < p.T) set_tap(ld_t);
-        }
-    };
-    auto store_tile = [&](int stage) {
-        char* sa = smem + stage * STAGE_BYTES;
-        char* sb = sa + TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = r0 + 32 * i;
-            const int off = r * 128 + ((kc ^ (r & 7)) << 4);
-            *reinterpret_cast<u32x4*>(sa + off) = ra[i];
-            *reinterpret_cast<u32x4*>(sb + off) = rb[i];
         }
     };
 
@@ -139,15 +158,16 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fq = lane >> 4;
-    auto compute = [&](int stage) {
-        const char* sa = smem + stage * STAGE_BYTES;
+    const int wrow0 = wn * 64 + 16 * (frow >> 2) + (frow & 3);          // + 4*i : permuted weight row of MFMA tile i
+    auto compute = [&](int buf) {
+        const char* sa = smem + buf * STAGE_BYTES;
         const char* sb = sa + TILE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            const int sw = (((kk * 4 + fq) ^ (frow & 7)) << 4);
+            const int sw = (((kk * 4 + fq) ^ (frow & 7)) << 4);         // same expression for both operands (see header)
             bf16x8 wf[4], af[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sb + (wn * 64 + i * 16 + frow) * 128 + sw);
+            for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sb + (wrow0 + 4 * i) * 128 + sw);
 #pragma unroll
             for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const bf16x8*>(sa + (wm * 64 + j * 16 + frow) * 128 + sw);
 #pragma unroll
@@ -157,59 +177,97 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
         }
     };
 
-    load_tile();
-    store_tile(0);
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        const bool more = (kt + 1) < nk;
-        if (more) load_tile();
+        if (kt + 1 < nk) stage(cur ^ 1);          // DMA of the next tile flies during this tile's MFMAs
         compute(cur);
-        if (more) store_tile(cur ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
-    // ---- epilogue: lane owns pixel m (col of D) and channels n..n+3 (rows of D) -----------------------
+    if (p.flags & (1 << 30)) {   // perf experiment: main loop only (keeps the accumulators alive, stores nothing)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
+    // ---- epilogue: lane owns pixel m (D col) and the 16 contiguous channels nb .. nb+15 (4 per MFMA tile i) -------
     const int flags = p.flags;
+    const int nb = n0 + wn * 64 + 16 * fq;
+    f32x4 esc[4], ebi[4];               // FrozenBN scale / shift of this lane's 16 channels: loaded once, not per pixel
+    if (flags & MI_EPI_SCALE_BIAS) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = (nb + 4 * i < p.N) ? nb + 4 * i : 0;
+            esc[i] = *reinterpret_cast<const f32x4*>(p.scale + n);
+            ebi[i] = *reinterpret_cast<const f32x4*>(p.bias + n);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int m = m0 + wm * 64 + j * 16 + frow;
         if (m >= p.M) continue;
+        const long o = (long)m * p.N + nb;
+        f32x4 v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = n0 + wn * 64 + i * 16 + fq * 4;
-            if (n >= p.N) continue;
-            f32x4 v = acc[i][j];
-            if (flags & MI_EPI_SCALE_BIAS) {
-                const f32x4 s = *reinterpret_cast<const f32x4*>(p.scale + n);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
-                v = v * s + b;
+        for (int i = 0; i < 4; ++i) v[i] = acc[i][j];
+        if (flags & MI_EPI_SCALE_BIAS) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = v[i] * esc[i] + ebi[i];
+        }
+        if (flags & MI_EPI_RESIDUAL) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (nb + 8 * h < p.N) {
+                    const bf16x8 r = *reinterpret_cast<const bf16x8*>(p.res + o + 8 * h);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[2 * h + (e >> 2)][e & 3] += (float)r[e];
+                }
             }
-            const long o = (long)m * p.N + n;
-            if (flags & MI_EPI_RESIDUAL) {
-                const bf16x4 r = *reinterpret_cast<const bf16x4*>(p.res + o);
+        }
+        if (flags & MI_EPI_RELU) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[i][e] = v[i][e] > 0.f ? v[i][e] : 0.f;
+        }
+        if (flags & MI_EPI_MASK) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (nb + 8 * h < p.N) {
+                    const bf16x8 k = *reinterpret_cast<const bf16x8*>(p.msk + o + 8 * h);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        v[2 * h + (e >> 2)][e & 3] = ((float)k[e] > 0.f) ? v[2 * h + (e >> 2)][e & 3] : 0.f;
+                }
             }
-            if (flags & MI_EPI_RELU) {
+        }
+        if (flags & MI_EPI_ZSPLIT) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            for (int i = 0; i < 4; ++i) {
+                const int n = nb + 4 * i;
+                if (n < p.N) {
+                    const int g = n / p.zgw, nn = n - g * p.zgw;
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + ((long)g * p.M + m) * p.zgw + nn) = v[i];
+                }
             }
-            if (flags & MI_EPI_MASK) {
-                const bf16x4 k = *reinterpret_cast<const bf16x4*>(p.msk + o);
+        } else if (flags & MI_EPI_OUT_F32) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = ((float)k[e] > 0.f) ? v[e] : 0.f;
-            }
-            if (flags & MI_EPI_ZSPLIT) {
-                const int g = n / p.zgw, nn = n - g * p.zgw;
-                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + ((long)g * p.M + m) * p.zgw + nn) = v;
-            } else if (flags & MI_EPI_OUT_F32) {
-                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o) = v;
-            } else {
-                bf16x4 h;
+            for (int i = 0; i < 4; ++i)
+                if (nb + 4 * i < p.N) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o + 4 * i) = v[i];
+        } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
-                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.out) + o) = h;
+            for (int h = 0; h < 2; ++h) {
+                if (nb + 8 * h < p.N) {
+                    bf16x8 hv;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) hv[e] = (__bf16)v[2 * h + (e >> 2)][e & 3];
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.out) + o + 8 * h) = hv;
+                }
             }
         }
     }
@@ -223,14 +281,14 @@ extern "C" int mi_conv_gemm(const void* a, const void* wp, void* out, int B, int
     MI_REQUIRE(a && wp && out, "mi_conv_gemm: null operand");
     MI_REQUIRE(B > 0 && Ha > 0 && Wa > 0 && Ho > 0 && Wo > 0 && N > 0, "mi_conv_gemm: non-positive dimension");
     MI_REQUIRE(Ca > 0 && Ca % 64 == 0, "mi_conv_gemm: Ca=%d must be a multiple of 64", Ca);
-    MI_REQUIRE(N % 4 == 0, "mi_conv_gemm: N=%d must be a multiple of 4", N);
+    MI_REQUIRE(N % 8 == 0, "mi_conv_gemm: N=%d must be a multiple of 8", N);
     MI_REQUIRE(ksize == 1 || ksize == 3, "mi_conv_gemm: ksize=%d (1 or 3)", ksize);
     MI_REQUIRE(stride >= 1 && dil >= 1 && pad >= 0, "mi_conv_gemm: bad stride/dil/pad");
     MI_REQUIRE(gather_mode == MI_GATHER_FWD || gather_mode == MI_GATHER_DGRAD, "mi_conv_gemm: gather_mode");
     MI_REQUIRE(mi_aligned16(a) && mi_aligned16(wp) && mi_aligned16(out), "mi_conv_gemm: operands must be 16-byte aligned");
     MI_REQUIRE(!(flags & MI_EPI_SCALE_BIAS) || (scale && bias && mi_aligned16(scale) && mi_aligned16(bias)), "mi_conv_gemm: scale/bias");
-    MI_REQUIRE(!(flags & MI_EPI_RESIDUAL) || (res && ((uintptr_t)res & 7) == 0), "mi_conv_gemm: residual");
-    MI_REQUIRE(!(flags & MI_EPI_MASK) || (msk && ((uintptr_t)msk & 7) == 0), "mi_conv_gemm: mask");
+    MI_REQUIRE(!(flags & MI_EPI_RESIDUAL) || (res && mi_aligned16(res)), "mi_conv_gemm: residual");
+    MI_REQUIRE(!(flags & MI_EPI_MASK) || (msk && mi_aligned16(msk)), "mi_conv_gemm: mask");
     MI_REQUIRE(!(flags & MI_EPI_ZSPLIT) || (zgw > 0 && zgw % 4 == 0 && N % zgw == 0), "mi_conv_gemm: zgw");
     const long M = (long)B * Ho * Wo;
     MI_REQUIRE(M < (1L << 31) && (long)B * Ha * Wa < (1L << 31), "mi_conv_gemm: pixel count overflows int32");

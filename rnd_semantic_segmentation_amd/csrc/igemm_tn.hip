@@ -14,10 +14,12 @@
 namespace {
 
 constexpr int TO = 128, TI = 128, KP = 64;      // output tile 128(o) x 128(i), 64 pixels per K step
-constexpr int ROWB = 288;                       // 256 B of data + 32 B pad: tr reads are bank-conflict free
-constexpr int TILE_BYTES = KP * ROWB;           // 18 KiB
+constexpr int ROWB = 256;                       // one pixel row of a tile: 128 channels bf16, unpadded
+constexpr int TILE_BYTES = KP * ROWB;           // 16 KiB
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;      // 72 KiB
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;      // 64 KiB -> 2 workgroups per CU
+
+__device__ __attribute__((aligned(256))) uint32_t g_zero_page_tn[64];
 
 struct WgradParams {
     const __bf16* dY;
@@ -34,9 +36,19 @@ __device__ __forceinline__ s16x4 tr_read(const char* addr) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(addr));
 }
 
+__device__ __forceinline__ void glds16_tn(const char* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// Staging: tiles go global -> LDS directly (global_load_lds, 1 KiB = 4 pixel rows x 256 B per wave-instruction).
+// The LDS image is lane-linear per DMA; 16-B chunk c of pixel row r sits at physical chunk c ^ ((r & 7) << 1), applied to
+// the per-lane SOURCE address and to the transposed-read address.  With that XOR the 32 lanes of a
+// ds_read_b64_tr_b16 half-wave (8 pixel rows x 32 B) hit 64 distinct banks.
 __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ot = blockIdx.x / p.i_tiles, it = blockIdx.x - ot * p.i_tiles;
     const int o0 = ot * TO, i0 = it * TI;
     const int t = blockIdx.y, split = blockIdx.z;
@@ -44,41 +56,55 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradParams p) {
     const int m_begin = split * p.rows_per_split;
     const int m_end = min(p.M, m_begin + p.rows_per_split);
     const int nk = (m_end - m_begin + KP - 1) / KP;
+    const char* zero = reinterpret_cast<const char*>(g_zero_page_tn);
 
-    // staging: each tile is 64 rows x 16 chunks of 16 B -> 4 chunks per thread: rows r0 + 16*j, chunk c
-    const int c = tid & 15, r0 = tid >> 4;
-    const bool dy_col_ok = (o0 + c * 8) < p.O;
-    const bool x_col_ok = (i0 + c * 8) < p.I;
+    // DMA assignment: wave w moves pieces 4w..4w+3 (4 rows each) of both tiles; lane -> (row, physical chunk)
+    const int prow = lane >> 4, pch = lane & 15;
+    int r_m[4], r_b[4], r_ho[4], r_wo[4], r_lch[4];
     const int HoWo = p.Ho * p.Wo;
-
-    u32x4 rdy[4], rx[4];
-    auto load_tile = [&](int kt) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m_begin + kt * KP + r0 + 16 * j;
-            u32x4 vdy = {0, 0, 0, 0}, vx = {0, 0, 0, 0};
-            if (m < m_end) {
-                if (dy_col_ok) vdy = *reinterpret_cast<const u32x4*>(p.dY + (long)m * p.O + o0 + c * 8);
-                if (x_col_ok) {
-                    const int b = m / HoWo, rem = m - b * HoWo;
-                    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                    const int ha = ho * p.stride + ky * p.dil - p.pad, wa = wo * p.stride + kx * p.dil - p.pad;
-                    if ((unsigned)ha < (unsigned)p.Ha && (unsigned)wa < (unsigned)p.Wa)
-                        vx = *reinterpret_cast<const u32x4*>(p.X + ((long)(b * p.Ha + ha) * p.Wa + wa) * p.I + i0 + c * 8);
-                }
-            }
-            rdy[j] = vdy;
-            rx[j] = vx;
-        }
-    };
-    auto store_tile = [&](int stage) {
-        char* sy = smem + stage * STAGE_BYTES;
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wave * 4 + j) * 4 + prow;
+        const int m = m_begin + row;
+        r_m[j] = m;
+        const int mm = m < p.M ? m : 0;
+        r_b[j] = mm / HoWo;
+        const int rem = mm - r_b[j] * HoWo;
+        r_ho[j] = rem / p.Wo;
+        r_wo[j] = rem - r_ho[j] * p.Wo;
+        r_lch[j] = pch ^ ((row & 7) << 1);            // logical chunk this lane fetches
+    }
+    const int step_q = KP / p.Wo, step_r = KP - step_q * p.Wo;
+
+    auto stage = [&](int buf) {
+        char* sy = smem + buf * STAGE_BYTES + wave * 4096;
         char* sx = sy + TILE_BYTES;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int off = (r0 + 16 * j) * ROWB + c * 16;
-            *reinterpret_cast<u32x4*>(sy + off) = rdy[j];
-            *reinterpret_cast<u32x4*>(sx + off) = rx[j];
+            const bool row_ok = r_m[j] < m_end;
+            const int oc = o0 + r_lch[j] * 8, ic = i0 + r_lch[j] * 8;
+            const int ha = r_ho[j] * p.stride + ky * p.dil - p.pad, wa = r_wo[j] * p.stride + kx * p.dil - p.pad;
+            const bool y_ok = row_ok && oc < p.O;
+            const bool x_ok = row_ok && ic < p.I && (unsigned)ha < (unsigned)p.Ha && (unsigned)wa < (unsigned)p.Wa;
+            // branch-free: form the address from clamped coordinates, then select the zero page
+            const long yoff = (long)(row_ok ? r_m[j] : 0) * p.O + (y_ok ? oc : 0);
+            const long xoff = ((long)(r_b[j] * p.Ha + (x_ok ? ha : 0)) * p.Wa + (x_ok ? wa : 0)) * p.I + (x_ok ? ic : 0);
+            const char* gy = y_ok ? reinterpret_cast<const char*>(p.dY + yoff) : zero;
+            const char* gx = x_ok ? reinterpret_cast<const char*>(p.X + (row_ok ? xoff : 0)) : zero;
+            glds16_tn(gy, sy + j * 1024);
+            glds16_tn(gx, sx + j * 1024);
+            // advance this row by KP pixels: (b, ho, wo) += 64 with carries
+            r_m[j] += KP;
+            r_wo[j] += step_r;
+            r_ho[j] += step_q;
+            if (r_wo[j] >= p.Wo) {
+                r_wo[j] -= p.Wo;
+                ++r_ho[j];
+            }
+            while (r_ho[j] >= p.Ho) {
+                r_ho[j] -= p.Ho;
+                ++r_b[j];
+            }
         }
     };
 
@@ -91,18 +117,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradParams p) {
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // transposed-read addressing: 16-lane group g reads pixel rows ks*32 + half*16 + g*4 + q (q = (lane&15)>>2),
-    // 4 columns starting at 4*(lane&3) of the 16-column subtile; the same pixel<->k mapping on both operands.
+    // 4 columns (8 B) starting at column 4*(lane&3) of the 16-column subtile; same pixel<->k mapping on both operands.
     const int g = lane >> 4, q = (lane & 15) >> 2, pc = lane & 3;
-    const int lane_off = (g * 4 + q) * ROWB + pc * 8;
-    auto compute = [&](int stage) {
-        const char* sy = smem + stage * STAGE_BYTES;
+    const int rsw = (((g & 1) * 4 + q) << 1);                 // ((row & 7) << 1): ks*32 and half*16 are multiples of 8
+    const int row_off = (g * 4 + q) * ROWB + (pc & 1) * 8;
+    auto compute = [&](int buf) {
+        const char* sy = smem + buf * STAGE_BYTES;
         const char* sx = sy + TILE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 xf[4], yf[4];
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                const char* base = sx + lane_off + (ks * 32) * ROWB + (wi * 64 + a * 16) * 2;
+                const int ch = ((wi * 8 + a * 2 + (pc >> 1)) ^ rsw) << 4;
+                const char* base = sx + row_off + (ks * 32) * ROWB + ch;
                 const s16x4 lo = tr_read(base), hi = tr_read(base + 16 * ROWB);
                 union { bf16x8 v; s16x4 h[2]; } u;
                 u.h[0] = lo;
@@ -111,7 +139,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradParams p) {
             }
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const char* base = sy + lane_off + (ks * 32) * ROWB + (wo_ * 64 + b * 16) * 2;
+                const int ch = ((wo_ * 8 + b * 2 + (pc >> 1)) ^ rsw) << 4;
+                const char* base = sy + row_off + (ks * 32) * ROWB + ch;
                 const s16x4 lo = tr_read(base), hi = tr_read(base + 16 * ROWB);
                 union { bf16x8 v; s16x4 h[2]; } u;
                 u.h[0] = lo;
@@ -126,15 +155,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradParams p) {
     };
 
     if (nk > 0) {
-        load_tile(0);
-        store_tile(0);
+        stage(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
-            const bool more = (kt + 1) < nk;
-            if (more) load_tile(kt + 1);
+            if (kt + 1 < nk) stage(cur ^ 1);
             compute(cur);
-            if (more) store_tile(cur ^ 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
     }
@@ -155,39 +183,59 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradParams p) {
     }
 }
 
-// dw[o][i][t] = scale[o] * sum_s slab[s][t][o][i]   (fixed summation order -> reproducible)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, const float* __restrict__ scale,
-                                    int S, int T, int O, int I, int accumulate, int out_map, int o_real, int ncls) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)o_real * I) return;
-    const int o = (int)(idx / I), i = (int)(idx - (long)o * I);
+// dw[o][i][t] = scale[o] * sum_s slab[s][t][o][i]   (fixed summation order -> reproducible).
+// One workgroup per (o, 64 consecutive i): threads (t-major) read slab rows coalesced over i, the T x 64 block is
+// transposed through LDS and written out as 64*T contiguous floats (OIHW keeps t fastest).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                           const float* __restrict__ scale, int S, int T, int O, int I,
+                                                           int accumulate, int out_map, int ncls) {
+    __shared__ float tile[9 * 64];
+    const int IB = (T == 1) ? 256 : 64;            // i-columns per workgroup: T * IB <= 576 items
+    const int o = blockIdx.y, ib = blockIdx.x * IB;
     const long plane = (long)O * I;
     const float sc = scale ? scale[o] : 1.f;
-    for (int t = 0; t < T; ++t) {
+    const int ni = min(IB, I - ib);
+    for (int item = threadIdx.x; item < T * IB; item += 256) {
+        const int t = item / IB, ii = item - t * IB;
         float s = 0.f;
-        const float* src = slab + (long)t * plane + (long)o * I + i;
-        for (int k = 0; k < S; ++k) s += src[(long)k * T * plane];
-        s *= sc;
-        long dst;
-        if (out_map == 0) {
-            dst = ((long)o * I + i) * T + t;
-        } else {  // ASPP: o = (r*9+tap)*ncls + cls  ->  dw[r][cls][i][tap]
-            const int grp = o / ncls, cls = o - grp * ncls;
-            const int r = grp / 9, tap = grp - r * 9;
-            dst = (((long)r * ncls + cls) * I + i) * 9 + tap;
+        if (ii < ni) {
+            const float* src = slab + (long)t * plane + (long)o * I + ib + ii;
+            for (int k = 0; k < S; ++k) s += src[(long)k * T * plane];
         }
-        dw[dst] = accumulate ? dw[dst] + s : s;
+        tile[ii * T + t] = s * sc;
+    }
+    __syncthreads();
+    if (out_map == 0) {
+        float* dst = dw + ((long)o * I + ib) * T;
+        for (int e = threadIdx.x; e < ni * T; e += 256) dst[e] = accumulate ? dst[e] + tile[e] : tile[e];
+    } else {  // ASPP: o = (r*9+tap)*ncls + cls  ->  dw[r][cls][i][tap]   (T == 1)
+        const int grp = o / ncls, cls = o - grp * ncls;
+        const int r = grp / 9, tap = grp - r * 9;
+        for (int e = threadIdx.x; e < ni; e += 256) {
+            const long d = (((long)r * ncls + cls) * I + ib + e) * 9 + tap;
+            dw[d] = accumulate ? dw[d] + tile[e] : tile[e];
+        }
     }
 }
 
 int pick_splits(long M, int tiles) {
-    // aim for ~1024 workgroups (4 per CU at 2 resident) but keep >= 8 K-steps of 64 pixels per split
-    int s = (int)((1024 + tiles - 1) / tiles);
-    const long max_s = (M + 8 * KP - 1) / (8 * KP);
-    if (s > max_s) s = (int)max_s;
-    if (s < 1) s = 1;
-    if (s > 64) s = 64;
-    return s;
+    // 512 workgroup slots (256 CUs x 2 resident).  Minimise rounds x (K-steps per split + ~6 steps of fixed cost per
+    // workgroup: prologue, pipeline fill, slab write); never fewer than 8 K-steps per split.
+    const long steps = (M + KP - 1) / KP;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= 64; ++s) {
+        const long per = (steps + s - 1) / s;
+        if (s > 1 && per < 8) break;
+        const long blocks = (long)tiles * s;
+        const long rounds = (blocks + 511) / 512;
+        const double cost = (double)rounds * (double)(per + 6);
+        if (cost < best_cost - 1e-9) {
+            best_cost = cost;
+            best = s;
+        }
+    }
+    return best;
 }
 
 }  // namespace
@@ -247,9 +295,8 @@ extern "C" int mi_conv_wgrad(const void* dy, const void* x, float* dw, int B, in
         o_real = 36 * ncls;
         MI_REQUIRE(O >= o_real, "mi_conv_wgrad: out_map 1 needs O >= 684");
     }
-    const long n = (long)o_real * I;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p.slab, dw, scale_o,
-                       p.S, p.T, O, I, accumulate, out_map, o_real, ncls);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((I + (p.T == 1 ? 255 : 63)) / (p.T == 1 ? 256 : 64)), (unsigned)o_real), dim3(256), 0, (hipStream_t)stream, p.slab, dw,
+                       scale_o, p.S, p.T, O, I, accumulate, out_map, ncls);
     MI_CHECK_LAUNCH("mi_conv_wgrad reduce");
     return MI_OK;
 }
