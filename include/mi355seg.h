@@ -57,6 +57,12 @@ int mi_pack_weight_fwd(const float* w_oihw, void* wp_bf16, int O, int I, int ksi
  * FrozenBN scale of the conv's output channel is folded in (scale is a constant buffer). */
 int mi_pack_weight_dgrad(const float* w_oihw, const float* scale_o, void* wp_bf16, int O, int I, int ksize, void* stream);
 
+/* Every conv weight of a module in one launch.  table (device, int64[n_desc][8]) rows:
+ * {w_off, scale_off or -1, wp_off, wpt_off or -1 (skip the dgrad pack), O, I, k*k, first_block}; offsets in elements
+ * into wflat / sflat / wp / wpt; a block packs 256 (o,i) pairs, total_blocks = sum ceil(O*I/256). */
+int mi_pack_weights_multi(const float* wflat, const float* sflat, void* wp_bf16, void* wpt_bf16,
+                          const int64_t* table_dev, int n_desc, int total_blocks, void* stream);
+
 /* ---- implicit-GEMM convolution, MFMA bf16 -> fp32 accumulate ----------------------------------
  * Replaces nn.Conv2d forward and the data-gradient half of convolution_backward for every
  * conv of reference core/components/resnet.py:22-30 (conv3x3 with dilation, conv1x1) and, through

@@ -21,6 +21,7 @@ SIGNATURES = {
     "mi_last_error": (c_char_p, []),
     "mi_pack_weight_fwd": (I, [P, P, I, I, I, P]),
     "mi_pack_weight_dgrad": (I, [P, P, P, I, I, I, P]),
+    "mi_pack_weights_multi": (I, [P, P, P, P, P, I, I, P]),
     "mi_conv_gemm": (I, [P, P, P] + [I] * 12 + [P, P, P, P, I, I, P]),
     "mi_conv_wgrad_workspace": (Z, [I] * 6),
     "mi_conv_wgrad": (I, [P, P, P] + [I] * 11 + [P, I, I, P, Z, P]),

@@ -19,10 +19,17 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + B
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;       // double buffer = 64 KiB
+// Tile height is a template parameter: MT 16-row MFMA tiles per wave in M -> BM = 32*MT rows (128 or 160).  The
+// launcher picks the one with fewer (rounds x rows) on the 512 resident workgroup slots: at M = 75 272, N = 256 the
+// 128-row tile needs 1178 workgroups = 3 rounds, the 160-row tile 942 = 2 rounds.
+constexpr int BN = 128, BK = 64;
+constexpr int WTILE_BYTES = BN * BK * 2;         // 16 KiB weight tile
+template <int MT> struct Geo {
+    static constexpr int BM = 32 * MT;
+    static constexpr int ATILE_BYTES = BM * BK * 2;
+    static constexpr int STAGE_BYTES = ATILE_BYTES + WTILE_BYTES;
+    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;       // double buffer: 64 KiB (MT 4) / 72 KiB (MT 5)
+};
 
 __device__ __attribute__((aligned(256))) uint32_t g_zero_page[64];   // source of every padded / out-of-range chunk
 
@@ -64,7 +71,9 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+template <int MT>
 __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
+    constexpr int BM = Geo<MT>::BM, ATILE_BYTES = Geo<MT>::ATILE_BYTES, STAGE_BYTES = Geo<MT>::STAGE_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -77,11 +86,11 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
     //      lane -> (row = piece*8 + lane>>3, physical chunk = lane&7); it fetches logical chunk physical ^ s(row).
     const int prow = lane >> 3, pch = lane & 7;
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
-    int a_img[4], a_ho[4], a_wo[4];
+    int a_img[MT], a_ho[MT], a_wo[MT];
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + (wave * 4 + i) * 8 + prow;
+    for (int i = 0; i < MT; ++i) {
+        const int m = m0 + (wave * MT + i) * 8 + prow;
         if (m < p.M) {
             const int b = m / HoWo, rem = m - b * HoWo;
             a_ho[i] = rem / p.Wo;
@@ -103,14 +112,14 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
     const int cpt = p.Ca >> 6;          // 64-channel chunks per tap
     const int nk = p.T * cpt;
     int ld_t = 0, ld_cc = 0;            // tap / chunk of the NEXT tile to stage
-    const char* a_ptr[4];
+    const char* a_ptr[MT];
     const char* w_ptr[4];
-    int a_inc[4], w_inc[4];
+    int a_inc[MT], w_inc[4];
 
     auto set_tap = [&](int t) {
         const int ky = t / p.ksz, kx = t - ky * p.ksz;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MT; ++i) {
             int ha, wa;
             if (a_img[i] >= 0 && tap_src(p, a_ho[i], a_wo[i], ky, kx, ha, wa)) {
                 a_ptr[i] = reinterpret_cast<const char*>(p.A + ((long)(a_img[i] + ha * p.Wa + wa)) * p.Ca) + a_chunk;
@@ -119,6 +128,9 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
                 a_ptr[i] = zero;
                 a_inc[i] = 0;
             }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
             if (w_row[i] < p.N) {
                 w_ptr[i] = reinterpret_cast<const char*>(p.Wp + ((long)t * p.N + w_row[i]) * p.Ca) + w_chunk[i];
                 w_inc[i] = 128;
@@ -131,10 +143,10 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
     set_tap(0);
 
     auto stage = [&](int buf) {
-        char* sa = smem + buf * STAGE_BYTES + wave * 4096;
-        char* sb = sa + TILE_BYTES;
+        char* sa = smem + buf * STAGE_BYTES + wave * (MT * 1024);
+        char* sb = smem + buf * STAGE_BYTES + ATILE_BYTES + wave * 4096;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MT; ++i) {
             glds16(a_ptr[i], sa + i * 1024);
             a_ptr[i] += a_inc[i];
         }
@@ -151,29 +163,29 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
     };
 
     const int wm = wave & 1, wn = wave >> 1;
-    f32x4 acc[4][4];
+    f32x4 acc[4][MT];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fq = lane >> 4;
     const int wrow0 = wn * 64 + 16 * (frow >> 2) + (frow & 3);          // + 4*i : permuted weight row of MFMA tile i
     auto compute = [&](int buf) {
         const char* sa = smem + buf * STAGE_BYTES;
-        const char* sb = sa + TILE_BYTES;
+        const char* sb = sa + ATILE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int sw = (((kk * 4 + fq) ^ (frow & 7)) << 4);         // same expression for both operands (see header)
-            bf16x8 wf[4], af[4];
+            bf16x8 wf[4], af[MT];
 #pragma unroll
             for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sb + (wrow0 + 4 * i) * 128 + sw);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const bf16x8*>(sa + (wm * 64 + j * 16 + frow) * 128 + sw);
+            for (int j = 0; j < MT; ++j) af[j] = *reinterpret_cast<const bf16x8*>(sa + (wm * (MT * 16) + j * 16 + frow) * 128 + sw);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < MT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
         }
     };
 
@@ -192,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+            for (int j = 0; j < MT; ++j) asm volatile("" ::"v"(acc[i][j]));
         return;
     }
     // ---- epilogue: lane owns pixel m (D col) and the 16 contiguous channels nb .. nb+15 (4 per MFMA tile i) -------
@@ -208,8 +220,8 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
         }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + wm * 64 + j * 16 + frow;
+    for (int j = 0; j < MT; ++j) {
+        const int m = m0 + wm * (MT * 16) + j * 16 + frow;
         if (m >= p.M) continue;
         const long o = (long)m * p.N + nb;
         f32x4 v[4];
@@ -318,14 +330,26 @@ extern "C" int mi_conv_gemm(const void* a, const void* wp, void* out, int B, int
     p.mode = gather_mode;
     p.flags = flags;
     p.zgw = zgw > 0 ? zgw : 4;
-    p.m_tiles = (int)((M + BM - 1) / BM);
     p.n_tiles = (N + BN - 1) / BN;
+    // tile height: fewer (rounds x rows) on the 512 resident workgroup slots wins; ties go to the smaller tile
+    auto cost = [&](int bm) {
+        const long tiles = ((M + bm - 1) / bm) * p.n_tiles;
+        return ((tiles + 511) / 512) * bm;
+    };
+    const bool tall = cost(160) < cost(128);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<4>::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<5>::LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(igemm_nt_kernel, dim3(p.m_tiles * p.n_tiles), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
+    if (tall) {
+        p.m_tiles = (int)((M + 159) / 160);
+        hipLaunchKernelGGL(igemm_nt_kernel<5>, dim3(p.m_tiles * p.n_tiles), dim3(256), Geo<5>::LDS_BYTES, (hipStream_t)stream, p);
+    } else {
+        p.m_tiles = (int)((M + 127) / 128);
+        hipLaunchKernelGGL(igemm_nt_kernel<4>, dim3(p.m_tiles * p.n_tiles), dim3(256), Geo<4>::LDS_BYTES, (hipStream_t)stream, p);
+    }
     MI_CHECK_LAUNCH("mi_conv_gemm");
     return MI_OK;
 }

@@ -53,6 +53,32 @@ __global__ void aspp_pack_dgrad_kernel(const float* __restrict__ w4, __bf16* __r
     wallT[idx] = (__bf16)v;
 }
 
+// All conv weights of a module in ONE launch: table row = {w_off, scale_off(-1: none), wp_off, wpt_off(-1: skip), O, I, T,
+// first_block}; a block handles 256 (o,i) pairs of one tensor, reads the k*k taps once and writes both packs.
+__global__ void pack_multi_kernel(const float* __restrict__ wflat, const float* __restrict__ sflat, __bf16* __restrict__ wp,
+                                  __bf16* __restrict__ wpt, const long* __restrict__ table, int n_desc) {
+    int lo = 0, hi = n_desc - 1;                     // last row whose first_block <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid * 8 + 7] <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const long* d = table + lo * 8;
+    const int O = (int)d[4], I = (int)d[5], T = (int)d[6];
+    const long idx = ((long)blockIdx.x - d[7]) * 256 + threadIdx.x;
+    if (idx >= (long)O * I) return;
+    const int o = (int)(idx / I), i = (int)(idx - (long)o * I);
+    const float* src = wflat + d[0] + idx * T;
+    const float sc = d[1] >= 0 ? sflat[d[1] + o] : 1.f;
+    const long plane = (long)O * I;
+    __bf16* f = wp + d[2] + idx;
+    __bf16* b = d[3] >= 0 ? wpt + d[3] + (long)i * O + o : nullptr;
+    for (int t = 0; t < T; ++t) {
+        const float v = src[t];
+        f[t * plane] = (__bf16)v;
+        if (b) b[t * plane] = (__bf16)(v * sc);
+    }
+}
+
 struct Rates { int d[4]; };
 
 // low[m][n] = sum_r bias[r][n] + sum_g Z[g][m + shift_g][n]; thread per (m, n) with n fastest (20 lanes per pixel)
@@ -149,6 +175,15 @@ extern "C" int mi_pack_weight_dgrad(const float* w, const float* scale_o, void* 
     hipLaunchKernelGGL(pack_dgrad_kernel, dim3(nblk((long)O * I, 256)), dim3(256), 0, (hipStream_t)stream, w, scale_o, (__bf16*)wp, O, I,
                        ksize * ksize);
     MI_CHECK_LAUNCH("mi_pack_weight_dgrad");
+    return MI_OK;
+}
+
+extern "C" int mi_pack_weights_multi(const float* wflat, const float* sflat, void* wp, void* wpt, const int64_t* table_dev, int n_desc,
+                                     int total_blocks, void* stream) {
+    MI_REQUIRE(wflat && wp && table_dev && n_desc > 0 && total_blocks > 0, "mi_pack_weights_multi: bad argument");
+    hipLaunchKernelGGL(pack_multi_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, wflat, sflat, (__bf16*)wp, (__bf16*)wpt,
+                       (const long*)table_dev, n_desc);
+    MI_CHECK_LAUNCH("mi_pack_weights_multi");
     return MI_OK;
 }
 

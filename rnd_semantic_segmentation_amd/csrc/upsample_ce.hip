@@ -191,6 +191,7 @@ __global__ __launch_bounds__(256) void upce_pass1_kernel(const float* __restrict
     float* lam = sh + (long)npx_max * K;            // [npx_max]  lambda_x
     int* x0s = reinterpret_cast<int*>(lam + npx_max);  // [npx_max]  x0
     float* red = reinterpret_cast<float*>(x0s + npx_max);  // [512]
+    float* vrow = red + 512;                        // [JT+2][K] low-res row already interpolated along y
     const int H = ay.n_out, W = ax.n_out, h = ay.n_in, w = ax.n_in;
     const int jt = blockIdx.x, y = blockIdx.y, b = blockIdx.z;
     const int j0 = jt * JT, j1 = min(w, j0 + JT);
@@ -201,6 +202,12 @@ __global__ __launch_bounds__(256) void upce_pass1_kernel(const float* __restrict
     ay.src(y, y0, y1, ly);
     const float* row0 = low + ((long)b * h + y0) * w * K;
     const float* row1 = low + ((long)b * h + y1) * w * K;
+    const int cbase = max(j0 - 1, 0), ncol = min(j1, w - 1) - cbase + 1;          // source columns this tile touches
+    for (int e = threadIdx.x; e < ncol * K; e += 256) {
+        const long o = (long)cbase * K + e;
+        vrow[e] = (1.f - ly) * row0[o] + ly * row1[o];
+    }
+    __syncthreads();
     float loss = 0.f, cnt = 0.f;
     for (int px = threadIdx.x; px < npx; px += 256) {
         const int x = xa + px;
@@ -215,12 +222,14 @@ __global__ __launch_bounds__(256) void upce_pass1_kernel(const float* __restrict
             for (int k = 0; k < K; ++k) d[k] = 0.f;
             continue;
         }
+        const float* c0 = vrow + (x0 - cbase) * K;
+        const float* c1 = vrow + (x1 - cbase) * K;
         float v[KMAX];
         float mx = -3.0e38f;
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
             if (k < K) {
-                v[k] = lerp2(row0[(long)x0 * K + k], row0[(long)x1 * K + k], row1[(long)x0 * K + k], row1[(long)x1 * K + k], lx, ly);
+                v[k] = (1.f - lx) * c0[k] + lx * c1[k];
                 mx = fmaxf(mx, v[k]);
             }
         }
@@ -408,7 +417,7 @@ extern "C" int mi_upsample_ce(const float* low, const int64_t* labels, float* lo
     const size_t poff = (((size_t)B * H * tiles * 2 * sizeof(float)) + 255) & ~(size_t)255;
     float* tmp = dlow ? (float*)((char*)workspace + poff) : nullptr;
     const int npx_max = pass1_npx_max(ax);
-    const size_t lds = (size_t)npx_max * K * 4 + (size_t)npx_max * 8 + 512 * 4;
+    const size_t lds = (size_t)npx_max * K * 4 + (size_t)npx_max * 8 + 512 * 4 + (size_t)(JT + 2) * K * 4;
     MI_REQUIRE(lds <= 160 * 1024, "mi_upsample_ce: upsample factor too large for one LDS tile (%zu B)", lds);
     static size_t lds_set = 0;
     if (lds > lds_set) {

@@ -114,21 +114,53 @@ class StageEngine:
         gen = store.generation if store is not None else -1
         return (gen, sum(rt.weight._version for rt in self.convs), self.convs[0].weight.data_ptr())
 
+    def _build_pack_plan(self, store):
+        """Flat bf16 buffers for all packed operands + the device table of mi_pack_weights_multi."""
+        dev = store.data.device
+        n = sum(rt.weight.numel() for rt in self.convs)
+        self._wp_flat = torch.empty(n, dtype=torch.bfloat16, device=dev)
+        self._wpt_flat = torch.empty(n, dtype=torch.bfloat16, device=dev)
+        self._scale_flat = torch.empty(sum(rt.spec.cout for rt in self.convs), dtype=torch.float32, device=dev)
+        self._shift_flat = torch.empty_like(self._scale_flat)
+        rows, off, soff, blk = [], 0, 0, 0
+        for rt in self.convs:
+            c = rt.spec
+            T = c.k * c.k
+            rows.append([rt.weight._mi_off, soff, off, off, c.cout, c.cin, T, blk])
+            rt.wp = self._wp_flat[off:off + rt.weight.numel()].view(T, c.cout, c.cin)
+            rt.wpt = self._wpt_flat[off:off + rt.weight.numel()].view(T, c.cin, c.cout)
+            rt.scale = self._scale_flat[soff:soff + c.cout]
+            rt.shift = self._shift_flat[soff:soff + c.cout]
+            off += rt.weight.numel()
+            soff += c.cout
+            blk += -(-(c.cout * c.cin) // 256)
+        self._pack_blocks = blk
+        self._table_train = torch.tensor(rows, dtype=torch.int64, device=dev)
+        for r in rows:
+            r[3] = -1
+        self._table_eval = torch.tensor(rows, dtype=torch.int64, device=dev)
+        self._plan_store = store
+
     def prepare(self, train):
+        store = getattr(self.convs[0].weight, "_mi_store", None)
+        if store is None or not store.intact():
+            raise RuntimeError("backbone parameters are not in their flat store; call ensure_flat() after moving the module")
+        if getattr(self, "_plan_store", None) is not store:
+            self._build_pack_plan(store)
+            self._bn_sig = self._pack_sig = None
         bn_sig = sum(b._version for rt in self.convs for b in (rt.bn.weight, rt.bn.bias, rt.bn.running_mean, rt.bn.running_var))
         bn_sig = (bn_sig, self.convs[0].bn.weight.data_ptr())
         refold = bn_sig != self._bn_sig
         if refold:
             for rt in self.convs:
-                rt.scale, rt.shift = K.frozen_bn_fold(rt.bn.weight, rt.bn.bias, rt.bn.running_mean, rt.bn.running_var)
+                sc, sh = K.frozen_bn_fold(rt.bn.weight, rt.bn.bias, rt.bn.running_mean, rt.bn.running_var)
+                rt.scale.copy_(sc)
+                rt.shift.copy_(sh)
             self._bn_sig = bn_sig
         sig = self._signature()
         if sig != self._pack_sig or refold or (train and not self._have_dgrad):
-            for rt in self.convs:
-                w = rt.weight.detach()
-                rt.wp = K.pack_weight_fwd(w, out=rt.wp)
-                if train:
-                    rt.wpt = K.pack_weight_dgrad(w, rt.scale, out=rt.wpt)
+            K.pack_weights_multi(store.data, self._scale_flat, self._wp_flat, self._wpt_flat,
+                                 self._table_train if train else self._table_eval, len(self.convs), self._pack_blocks)
             self._pack_sig = sig
             self._have_dgrad = train
 

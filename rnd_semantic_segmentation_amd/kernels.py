@@ -70,6 +70,12 @@ def pack_weight_dgrad(w, scale=None, out=None):
     return out
 
 
+def pack_weights_multi(wflat, sflat, wp, wpt, table_dev, n_desc, total_blocks):
+    """One launch packing every conv weight described by `table_dev` (see include/mi355seg.h)."""
+    check(_lib.lib().mi_pack_weights_multi(_p(wflat), _p(sflat), _p(wp), _p(wpt), _p(table_dev), n_desc, total_blocks, _stream()),
+          "mi_pack_weights_multi")
+
+
 def conv_gemm(a, wp, out_hw, ksize=1, stride=1, pad=0, dil=1, mode=GATHER_FWD, scale=None, bias=None, res=None,
               msk=None, relu=False, out_f32=False, zsplit=0, out=None):
     """out[b,ho,wo,n] = epi(sum_{t,c} a[b,src(ho,wo,t),c] * wp[t,n,c]);  a [B,Ha,Wa,Ca] bf16, wp [k*k,N,Ca] bf16."""

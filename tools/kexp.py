@@ -11,8 +11,8 @@ def run(ci,co,k,d,flags_extra,label):
     pad=d if k==3 else 0
     L=_lib.lib(); st=ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     P=lambda t: ctypes.c_void_p(t.data_ptr())
-    for fl,name in ((0,'plain'),(1|4,'bn+relu'),(1<<30,'nostore')):
-        f=lambda: L.mi_conv_gemm(P(x),P(wp),P(out),B,H,H,ci,H,H,co,k,1,pad,d,0,P(sc),P(sh),None,None,fl,0,st)
+    for fl,name,z in ((1|4,'bn+relu',0),(1|4|(1<<29),'stagger1',1),(1|4|(1<<29),'stagger2',2),(1|4|(1<<29),'stagger4',4),(1<<30,'nostore',0)):
+        f=lambda: L.mi_conv_gemm(P(x),P(wp),P(out),B,H,H,ci,H,H,co,k,1,pad,d,0,P(sc),P(sh),None,None,fl,z,st)
         t=timeit(f,30); print('%-18s %-8s %7.1f us  %6.0f TF'%(label,name,t*1e6,2.0*B*H*H*ci*co*k*k/t/1e12))
 run(256,1024,1,1,0,'1x1 256->1024')
 run(1024,256,1,1,0,'1x1 1024->256')
