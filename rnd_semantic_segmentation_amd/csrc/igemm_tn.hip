@@ -45,13 +45,19 @@ __device__ __forceinline__ void glds16_tn(const char* gsrc, char* lds_wave_base)
 // The LDS image is lane-linear per DMA; 16-B chunk c of pixel row r sits at physical chunk c ^ ((r & 7) << 1), applied to
 // the per-lane SOURCE address and to the transposed-read address.  With that XOR the 32 lanes of a
 // ds_read_b64_tr_b16 half-wave (8 pixel rows x 32 B) hit 64 distinct banks.
+template <bool UNIT_STRIDE>
 __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ot = blockIdx.x / p.i_tiles, it = blockIdx.x - ot * p.i_tiles;
+    // XCD-aware flattening: consecutive logical ids (= the output tiles of ONE K-split and tap, which all stream the same
+    // pixel rows) land on the same XCD, so the rows are fetched into one L2 instead of eight.
+    const int tiles = p.o_tiles * p.i_tiles;
+    const int logical = mi_xcd_remap(blockIdx.x, tiles * p.T * p.S);
+    const int tile = logical % tiles, rest = logical / tiles;
+    const int t = rest % p.T, split = rest / p.T;
+    const int ot = tile / p.i_tiles, it = tile - ot * p.i_tiles;
     const int o0 = ot * TO, i0 = it * TI;
-    const int t = blockIdx.y, split = blockIdx.z;
     const int ky = t / p.ksz, kx = t - ky * p.ksz;
     const int m_begin = split * p.rows_per_split;
     const int m_end = min(p.M, m_begin + p.rows_per_split);
@@ -60,21 +66,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradParams p) {
 
     // DMA assignment: wave w moves pieces 4w..4w+3 (4 rows each) of both tiles; lane -> (row, physical chunk)
     const int prow = lane >> 4, pch = lane & 15;
-    int r_m[4], r_b[4], r_ho[4], r_wo[4], r_lch[4];
     const int HoWo = p.Ho * p.Wo;
+    const int dys = ky * p.dil - p.pad, dxs = kx * p.dil - p.pad;
+    int r_m[4], r_b[4], r_ho[4], r_wo[4], r_lch[4];
+    const char* y_ptr[4];
+    const char* x_ptr[4];
+    bool y_col[4], x_col[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int row = (wave * 4 + j) * 4 + prow;
         const int m = m_begin + row;
         r_m[j] = m;
-        const int mm = m < p.M ? m : 0;
-        r_b[j] = mm / HoWo;
-        const int rem = mm - r_b[j] * HoWo;
+        r_b[j] = m / HoWo;
+        const int rem = m - r_b[j] * HoWo;
         r_ho[j] = rem / p.Wo;
         r_wo[j] = rem - r_ho[j] * p.Wo;
         r_lch[j] = pch ^ ((row & 7) << 1);            // logical chunk this lane fetches
+        const int oc = o0 + r_lch[j] * 8, ic = i0 + r_lch[j] * 8;
+        y_col[j] = oc < p.O;
+        x_col[j] = ic < p.I;
+        // with stride 1 the source pixel of tap (ky,kx) is m + dys*Wa + dxs: linear in m, only its validity is not
+        y_ptr[j] = reinterpret_cast<const char*>(p.dY + (long)m * p.O + oc);
+        x_ptr[j] = reinterpret_cast<const char*>(p.X + ((long)m + (long)dys * p.Wa + dxs) * p.I + ic);
     }
     const int step_q = KP / p.Wo, step_r = KP - step_q * p.Wo;
+    const long y_step = (long)KP * p.O * 2, x_step = (long)KP * p.I * 2;
 
     auto stage = [&](int buf) {
         char* sy = smem + buf * STAGE_BYTES + wave * 4096;
@@ -82,19 +98,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool row_ok = r_m[j] < m_end;
-            const int oc = o0 + r_lch[j] * 8, ic = i0 + r_lch[j] * 8;
-            const int ha = r_ho[j] * p.stride + ky * p.dil - p.pad, wa = r_wo[j] * p.stride + kx * p.dil - p.pad;
-            const bool y_ok = row_ok && oc < p.O;
-            const bool x_ok = row_ok && ic < p.I && (unsigned)ha < (unsigned)p.Ha && (unsigned)wa < (unsigned)p.Wa;
-            // branch-free: form the address from clamped coordinates, then select the zero page
-            const long yoff = (long)(row_ok ? r_m[j] : 0) * p.O + (y_ok ? oc : 0);
-            const long xoff = ((long)(r_b[j] * p.Ha + (x_ok ? ha : 0)) * p.Wa + (x_ok ? wa : 0)) * p.I + (x_ok ? ic : 0);
-            const char* gy = y_ok ? reinterpret_cast<const char*>(p.dY + yoff) : zero;
-            const char* gx = x_ok ? reinterpret_cast<const char*>(p.X + (row_ok ? xoff : 0)) : zero;
+            const char* gy = (row_ok && y_col[j]) ? y_ptr[j] : zero;
+            const char* gx = zero;
+            if (UNIT_STRIDE) {
+                const int hs = r_ho[j] + dys, ws = r_wo[j] + dxs;
+                if (row_ok && x_col[j] && (unsigned)hs < (unsigned)p.Ha && (unsigned)ws < (unsigned)p.Wa) gx = x_ptr[j];
+            } else {
+                const int ha = r_ho[j] * p.stride + dys, wa = r_wo[j] * p.stride + dxs;
+                const bool ok = row_ok && x_col[j] && (unsigned)ha < (unsigned)p.Ha && (unsigned)wa < (unsigned)p.Wa;
+                const long xoff = ((long)(r_b[j] * p.Ha + (ok ? ha : 0)) * p.Wa + (ok ? wa : 0)) * p.I + i0 + r_lch[j] * 8;
+                if (ok) gx = reinterpret_cast<const char*>(p.X + xoff);
+            }
             glds16_tn(gy, sy + j * 1024);
             glds16_tn(gx, sx + j * 1024);
-            // advance this row by KP pixels: (b, ho, wo) += 64 with carries
+            // advance this row by KP pixels
             r_m[j] += KP;
+            y_ptr[j] += y_step;
+            x_ptr[j] += x_step;
             r_wo[j] += step_r;
             r_ho[j] += step_q;
             if (r_wo[j] >= p.Wo) {
@@ -284,10 +304,15 @@ extern "C" int mi_conv_wgrad(const void* dy, const void* x, float* dw, int B, in
     p.rows_per_split = (int)(((steps + p.S - 1) / p.S) * KP);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)wgrad_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)wgrad_tn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)wgrad_tn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(wgrad_tn_kernel, dim3(p.o_tiles * p.i_tiles, p.T, p.S), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
+    const unsigned nblocks = (unsigned)(p.o_tiles * p.i_tiles * p.T * p.S);
+    if (stride == 1 && Ha == Ho && Wa == Wo)
+        hipLaunchKernelGGL(wgrad_tn_kernel<true>, dim3(nblocks), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(wgrad_tn_kernel<false>, dim3(nblocks), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
     MI_CHECK_LAUNCH("mi_conv_wgrad");
     int o_real = O, ncls = 1;
     if (out_map == 1) {
