@@ -144,6 +144,15 @@ int mi_upsample_softmax(const float* low, float* probs, uint8_t* pred, int B, in
  * g' = g + wd*p; buf = mu*buf + g'; p -= lr*buf  (buf zero-initialised == torch's first-step buf = g'). */
 int mi_sgd_step(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float weight_decay, void* stream);
 
+/* ---- stem tail: FrozenBN + ReLU + 3x3/stride 2/pad 1 max-pool fused (resnet.py:138-141) ----------------------
+ * y: conv1 output [B][Hc][Wc][C] bf16 NHWC; pool [B][Hp][Wp][C] bf16; idx one byte per pooled element: the winning
+ * tap 0..8 (first maximum in scan order, like ATen) or 9 when the pooled value is 0 (no gradient through ReLU).
+ * backward: dy[b][h][w][c] = scale[c] * sum of dpool over the windows whose idx points at (h,w).  C % 8 == 0. */
+int mi_stem_pool_fwd(const void* y, const float* scale, const float* shift, void* pool, uint8_t* idx,
+                     int B, int Hc, int Wc, int C, int Hp, int Wp, void* stream);
+int mi_stem_pool_bwd(const void* dpool, const uint8_t* idx, const float* scale, void* dy,
+                     int B, int Hc, int Wc, int C, int Hp, int Wp, void* stream);
+
 /* ---- elementwise helpers ------------------------------------------------------------------------ */
 /* y = msk > 0 ? x : 0 (bf16, n % 8 == 0): ReLU backward across an autograd boundary */
 int mi_relu_mask(const void* x_bf16, const void* msk_bf16, void* y_bf16, size_t n, void* stream);

@@ -38,6 +38,8 @@ SIGNATURES = {
     "mi_upsample_ce_workspace": (Z, [I] * 6),
     "mi_upsample_ce": (I, [P, P, P, P] + [I] * 7 + [F, P, Z, P]),
     "mi_upsample_softmax": (I, [P, P, P] + [I] * 6 + [P]),
+    "mi_stem_pool_fwd": (I, [P, P, P, P, P] + [I] * 6 + [P]),
+    "mi_stem_pool_bwd": (I, [P, P, P, P] + [I] * 6 + [P]),
     "mi_sgd_step": (I, [P, P, P, Z, F, F, F, P]),
     "mi_relu_mask": (I, [P, P, P, Z, P]),
     "mi_frozen_bn_fold": (I, [P, P, P, P, P, P, I, P]),

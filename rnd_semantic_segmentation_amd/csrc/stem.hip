@@ -1,0 +1,110 @@
+// Stem tail of the dilated ResNet: FrozenBN + ReLU + 3x3 / stride 2 / pad 1 max-pool, fused (forward and backward).
+// Reference: core/components/resnet.py:138-141 (bn1, relu, maxpool after the 7x7 conv), core/components/layers.py:18-23.
+// HBM-bound: forward reads the conv output once (152 MB at B=8, 769x769) and writes the pooled map (38 MB) plus one
+// argmax byte per output; backward reads dpool + the bytes and writes d(conv out).  The eager form is ~10 passes.
+#include "mi_common.h"
+
+namespace {
+
+// thread = (b, ho, wo, 8 channels).  idx byte: winning tap 0..8 (first maximum in (ky,kx) scan order, like ATen), or 9 when
+// the maximum of relu(bn(y)) is 0, i.e. no gradient flows (ReLU backward is x > 0).
+__global__ void stem_pool_fwd_kernel(const bf16x8* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+                                     bf16x8* __restrict__ pool, uint8_t* __restrict__ idx, int B, int Hc, int Wc, int C8, int Hp, int Wp) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (long)B * Hp * Wp * C8) return;
+    const int c8 = (int)(id % C8);
+    const int wo = (int)((id / C8) % Wp), ho = (int)((id / ((long)C8 * Wp)) % Hp), b = (int)(id / ((long)C8 * Wp * Hp));
+    float sc[8], sh[8], best[8];
+    int bi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = scale[c8 * 8 + e];
+        sh[e] = shift[c8 * 8 + e];
+        best[e] = -3.0e38f;
+        bi[e] = 9;
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int h = 2 * ho - 1 + ky;
+        if ((unsigned)h >= (unsigned)Hc) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int w = 2 * wo - 1 + kx;
+            if ((unsigned)w >= (unsigned)Wc) continue;
+            const bf16x8 v = y[(((long)b * Hc + h) * Wc + w) * C8 + c8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = (float)v[e] * sc[e] + sh[e];
+                f = (float)(__bf16)(f > 0.f ? f : 0.f);      // the eager path stores relu(bn(y)) as bf16 before pooling
+                if (f > best[e]) {
+                    best[e] = f;
+                    bi[e] = ky * 3 + kx;
+                }
+            }
+        }
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        o[e] = (__bf16)best[e];
+        idx[id * 8 + e] = (uint8_t)(best[e] > 0.f ? bi[e] : 9);
+    }
+    pool[id] = o;
+}
+
+// thread = (b, h, w, 8 channels) of the conv output: sums dpool over the (<= 4) windows that elected this pixel.
+__global__ void stem_pool_bwd_kernel(const bf16x8* __restrict__ dpool, const uint8_t* __restrict__ idx, const float* __restrict__ scale,
+                                     bf16x8* __restrict__ dy, int B, int Hc, int Wc, int C8, int Hp, int Wp) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (long)B * Hc * Wc * C8) return;
+    const int c8 = (int)(id % C8);
+    const int w = (int)((id / C8) % Wc), h = (int)((id / ((long)C8 * Wc)) % Hc), b = (int)(id / ((long)C8 * Wc * Hc));
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int ho_lo = h >> 1, ho_hi = (h + 1) >> 1, wo_lo = w >> 1, wo_hi = (w + 1) >> 1;   // windows covering h: ho_lo..ho_hi
+    for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+        if (ho >= Hp) continue;
+        const int ky = h - (2 * ho - 1);
+        for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+            if (wo >= Wp) continue;
+            const int tap = ky * 3 + (w - (2 * wo - 1));
+            const long p = (((long)b * Hp + ho) * Wp + wo) * C8 + c8;
+            const bf16x8 g = dpool[p];
+            const uint2 ib = *reinterpret_cast<const uint2*>(idx + p * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const unsigned byte = ((e < 4 ? ib.x : ib.y) >> (8 * (e & 3))) & 0xffu;
+                if ((int)byte == tap) acc[e] += (float)g[e];
+            }
+        }
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)(acc[e] * scale[c8 * 8 + e]);
+    dy[id] = o;
+}
+
+}  // namespace
+
+extern "C" int mi_stem_pool_fwd(const void* y, const float* scale, const float* shift, void* pool, uint8_t* idx, int B, int Hc, int Wc, int C,
+                                int Hp, int Wp, void* stream) {
+    MI_REQUIRE(y && scale && shift && pool && idx && B > 0 && Hc > 0 && Wc > 0 && C > 0 && C % 8 == 0, "mi_stem_pool_fwd: bad argument");
+    MI_REQUIRE(Hp == (Hc + 2 - 3) / 2 + 1 && Wp == (Wc + 2 - 3) / 2 + 1, "mi_stem_pool_fwd: pooled size must be that of a 3x3/2/1 max-pool");
+    MI_REQUIRE(mi_aligned16(y) && mi_aligned16(pool) && ((uintptr_t)idx & 7) == 0, "mi_stem_pool_fwd: alignment");
+    const long n = (long)B * Hp * Wp * (C / 8);
+    hipLaunchKernelGGL(stem_pool_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)y, scale, shift,
+                       (bf16x8*)pool, idx, B, Hc, Wc, C / 8, Hp, Wp);
+    MI_CHECK_LAUNCH("mi_stem_pool_fwd");
+    return MI_OK;
+}
+
+extern "C" int mi_stem_pool_bwd(const void* dpool, const uint8_t* idx, const float* scale, void* dy, int B, int Hc, int Wc, int C, int Hp, int Wp,
+                                void* stream) {
+    MI_REQUIRE(dpool && idx && scale && dy && B > 0 && Hc > 0 && Wc > 0 && C > 0 && C % 8 == 0, "mi_stem_pool_bwd: bad argument");
+    MI_REQUIRE(Hp == (Hc + 2 - 3) / 2 + 1 && Wp == (Wc + 2 - 3) / 2 + 1, "mi_stem_pool_bwd: pooled size must be that of a 3x3/2/1 max-pool");
+    MI_REQUIRE(mi_aligned16(dpool) && mi_aligned16(dy) && ((uintptr_t)idx & 7) == 0, "mi_stem_pool_bwd: alignment");
+    const long n = (long)B * Hc * Wc * (C / 8);
+    hipLaunchKernelGGL(stem_pool_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)dpool, idx, scale,
+                       (bf16x8*)dy, B, Hc, Wc, C / 8, Hp, Wp);
+    MI_CHECK_LAUNCH("mi_stem_pool_bwd");
+    return MI_OK;
+}

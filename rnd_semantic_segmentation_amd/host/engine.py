@@ -225,6 +225,28 @@ class StageEngine:
         return g
 
 
+class StemFn(torch.autograd.Function):
+    """Stem: 7x7/2 conv on the PyTorch-ROCm library + fused FrozenBN/ReLU/max-pool HIP kernel.
+    x [B,3,H,W] bf16 channels_last, weight fp32 [64,3,7,7] -> pooled [B,Hp,Wp,64] bf16 NHWC."""
+
+    @staticmethod
+    def forward(ctx, x, weight, scale, shift):
+        w16 = weight.detach().to(torch.bfloat16)
+        y = torch.nn.functional.conv2d(x, w16, None, 2, 3)                    # [B,64,Hc,Wc] channels_last
+        y = y.permute(0, 2, 3, 1).contiguous()                               # NHWC view (no copy when channels_last)
+        pool, idx = K.stem_pool_fwd(y, scale, shift)
+        ctx.save_for_backward(x, w16, idx, scale)
+        ctx.conv_hw = (y.shape[1], y.shape[2])
+        return pool
+
+    @staticmethod
+    def backward(ctx, dpool):
+        x, w16, idx, scale = ctx.saved_tensors
+        dy = K.stem_pool_bwd(dpool.contiguous(), idx, scale, ctx.conv_hw).permute(0, 3, 1, 2)   # NCHW-shaped, channels_last
+        dw = torch.ops.aten.convolution_backward(dy, x, w16, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        return None, dw.float(), None, None
+
+
 class StagesFn(torch.autograd.Function):
     """pooled stem output [B,H,W,64] bf16 NHWC -> layer4 feature [B,h,w,2048] bf16 NHWC."""
 

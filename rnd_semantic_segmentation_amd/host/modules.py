@@ -112,18 +112,25 @@ class resnet_feature_extractor(nn.Module):
             self._store = engine.FlatStore(self.engine_parameters(), dev)
         return self._store
 
+    def _stem_fold(self):
+        bn = self.backbone.bn1
+        sig = (bn.weight._version + bn.bias._version + bn.running_mean._version + bn.running_var._version, bn.weight.data_ptr())
+        if getattr(self, "_stem_sig", None) != sig:
+            from .. import kernels
+            self._stem_scale, self._stem_shift = kernels.frozen_bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var)
+            self._stem_sig = sig
+        return self._stem_scale, self._stem_shift
+
     def forward(self, x):
         _require_gpu(x, "resnet_feature_extractor")
         self.ensure_flat()
         bb = self.backbone
-        # stem on PyTorch-ROCm ops (A6): conv 7x7/2 -> FrozenBN -> ReLU -> maxpool 3x3/2, bf16 channels_last
+        # stem: 7x7/2 conv on the PyTorch-ROCm library (A6), then FrozenBN + ReLU + 3x3/2 max-pool in one HIP kernel
         xb = x.to(dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        y = F.conv2d(xb, bb.conv1.weight.to(torch.bfloat16), None, 2, 3)
-        scale, shift = bb.bn1.fold()
-        y = F.relu(y.float() * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)).to(torch.bfloat16)
-        y = F.max_pool2d(y, 3, 2, 1).contiguous(memory_format=torch.channels_last)
+        scale, shift = self._stem_fold()
+        y = engine.StemFn.apply(xb, bb.conv1.weight, scale, shift)                       # [B,Hp,Wp,64] bf16 NHWC
         weights = [rt.weight for rt in self._engine.convs]
-        feat = engine.StagesFn.apply(y.permute(0, 2, 3, 1), self._engine, *weights)
+        feat = engine.StagesFn.apply(y, self._engine, *weights)
         return feat.permute(0, 3, 1, 2)                  # NCHW-shaped view of NHWC memory (channels_last)
 
 

@@ -266,6 +266,27 @@ def upsample_softmax(low, size, want_pred=True):
     return probs, pred
 
 
+def stem_pool_fwd(y, scale, shift):
+    """y [B,Hc,Wc,C] bf16 (conv1 output) -> (pool [B,Hp,Wp,C] bf16, idx uint8): FrozenBN + ReLU + maxpool 3x3/2/1."""
+    _chk(y, torch.bfloat16, "y")
+    B, Hc, Wc, C = y.shape
+    Hp, Wp = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
+    pool = torch.empty((B, Hp, Wp, C), dtype=torch.bfloat16, device=y.device)
+    idx = torch.empty((B, Hp, Wp, C), dtype=torch.uint8, device=y.device)
+    check(_lib.lib().mi_stem_pool_fwd(_p(y), _p(scale), _p(shift), _p(pool), _p(idx), B, Hc, Wc, C, Hp, Wp, _stream()), "mi_stem_pool_fwd")
+    return pool, idx
+
+
+def stem_pool_bwd(dpool, idx, scale, conv_hw):
+    _chk(dpool, torch.bfloat16, "dpool")
+    _chk(idx, torch.uint8, "idx")
+    B, Hp, Wp, C = dpool.shape
+    Hc, Wc = conv_hw
+    dy = torch.empty((B, Hc, Wc, C), dtype=torch.bfloat16, device=dpool.device)
+    check(_lib.lib().mi_stem_pool_bwd(_p(dpool), _p(idx), _p(scale), _p(dy), B, Hc, Wc, C, Hp, Wp, _stream()), "mi_stem_pool_bwd")
+    return dy
+
+
 def sgd_step(p, g, buf, lr, momentum, weight_decay):
     for t, n in ((p, "p"), (g, "g"), (buf, "buf")):
         _chk(t, torch.float32, n)

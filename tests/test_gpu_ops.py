@@ -274,3 +274,28 @@ def test_errors_are_reported_not_thrown_across_the_abi():
         K.conv_gemm(a, wp, (4, 4))
     with pytest.raises(_lib.MiError, match="GPU"):
         K.relu_mask(torch.zeros(8, dtype=torch.bfloat16), torch.zeros(8, dtype=torch.bfloat16))
+
+
+def test_stem_bn_relu_maxpool_fused_vs_torch_ops():
+    """Fused FrozenBN + ReLU + 3x3/2/1 max-pool (reference resnet.py:138-141) against the same chain of PyTorch ops on
+    the GPU: forward bit-exact (bf16), backward within one bf16 ulp (up to 4 window contributions are summed)."""
+    import torch.nn.functional as F
+    B, C, Hc, Wc = 2, 64, 37, 41                       # odd sizes: windows hang over the border
+    g = torch.Generator(device="cpu").manual_seed(11)
+    y = torch.randn((B, Hc, Wc, C), generator=g).to(DEV).to(torch.bfloat16)
+    scale = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    shift = (torch.randn(C, generator=g) * 0.3).to(DEV)
+    pool, idx = K.stem_pool_fwd(y, scale, shift)
+    yr = y.permute(0, 3, 1, 2).float().requires_grad_(True)
+    act = F.relu(yr * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).to(torch.bfloat16)
+    ref = F.max_pool2d(act, 3, 2, 1)
+    assert torch.equal(pool.permute(0, 3, 1, 2), ref)
+    assert int(idx.max()) <= 9
+    dpool = torch.randn(ref.shape, generator=g).to(DEV).to(torch.bfloat16)
+    ref.backward(dpool)
+    dy = K.stem_pool_bwd(dpool.permute(0, 2, 3, 1).contiguous(), idx, scale, (Hc, Wc))
+    want = yr.grad.permute(0, 2, 3, 1)
+    err = (dy.float() - want).abs().max().item()
+    assert err <= 2.0 ** -7 * want.abs().max().item()
+    # gradient only where the activation is positive
+    assert not (dy.float().abs() > 0)[(act.permute(0, 2, 3, 1) <= 0)].any()
