@@ -16,6 +16,7 @@
 // permuted (row rho of tile i is channel 16*(rho>>2) + 4*i + (rho&3) of the wave's 64), so that a lane ends up with
 // 16 CONTIGUOUS channels of one pixel: 4 lanes store a whole 128-B line, and residual / mask loads are 16-B wide.
 #include "mi_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -28,7 +29,7 @@ template <int MT> struct Geo {
     static constexpr int BM = 32 * MT;
     static constexpr int ATILE_BYTES = BM * BK * 2;
     static constexpr int STAGE_BYTES = ATILE_BYTES + WTILE_BYTES;
-    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;       // double buffer: 64 KiB (MT 4) / 72 KiB (MT 5)
+    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;       // double buffer: 64 KiB (MT 4) / 72 KiB (MT 5) / 80 KiB (MT 6)
 };
 
 __device__ __attribute__((aligned(256))) uint32_t g_zero_page[64];   // source of every padded / out-of-range chunk
@@ -332,24 +333,37 @@ extern "C" int mi_conv_gemm(const void* a, const void* wp, void* out, int B, int
     p.zgw = zgw > 0 ? zgw : 4;
     p.n_tiles = (N + BN - 1) / BN;
     // tile height: fewer (rounds x rows) on the 512 resident workgroup slots wins; ties go to the smaller tile
+    // cost ~ rounds x rows, discounted by the L2 bytes a taller tile saves per flop (the kernel is L2->LDS bound:
+    // bytes per K-step ~ (bm + 128) for bm*128 outputs)
     auto cost = [&](int bm) {
         const long tiles = ((M + bm - 1) / bm) * p.n_tiles;
-        return ((tiles + 511) / 512) * bm;
+        return (double)(((tiles + 511) / 512) * bm) * (0.5 + 0.5 * (double)(bm + 128) / (2.0 * bm));
     };
-    const bool tall = cost(160) < cost(128);
+    int mt_sel = 4;
+    if (cost(160) < cost(128) * 0.999) mt_sel = 5;
+    if (cost(192) < cost(mt_sel * 32) * 0.999) mt_sel = 6;
+    static int force_mt = -1;
+    if (force_mt < 0) {
+        const char* e = getenv("MI_IGEMM_MT");
+        force_mt = e ? atoi(e) : 0;
+    }
+    if (force_mt >= 4 && force_mt <= 6) mt_sel = force_mt;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<4>::LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<5>::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<6>::LDS_BYTES);
         attr_set = true;
     }
-    if (tall) {
-        p.m_tiles = (int)((M + 159) / 160);
-        hipLaunchKernelGGL(igemm_nt_kernel<5>, dim3(p.m_tiles * p.n_tiles), dim3(256), Geo<5>::LDS_BYTES, (hipStream_t)stream, p);
-    } else {
-        p.m_tiles = (int)((M + 127) / 128);
-        hipLaunchKernelGGL(igemm_nt_kernel<4>, dim3(p.m_tiles * p.n_tiles), dim3(256), Geo<4>::LDS_BYTES, (hipStream_t)stream, p);
-    }
+    const int bm = mt_sel * 32;
+    p.m_tiles = (int)((M + bm - 1) / bm);
+    const dim3 grid(p.m_tiles * p.n_tiles);
+    if (mt_sel == 6)
+        hipLaunchKernelGGL(igemm_nt_kernel<6>, grid, dim3(256), Geo<6>::LDS_BYTES, (hipStream_t)stream, p);
+    else if (mt_sel == 5)
+        hipLaunchKernelGGL(igemm_nt_kernel<5>, grid, dim3(256), Geo<5>::LDS_BYTES, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(igemm_nt_kernel<4>, grid, dim3(256), Geo<4>::LDS_BYTES, (hipStream_t)stream, p);
     MI_CHECK_LAUNCH("mi_conv_gemm");
     return MI_OK;
 }
