@@ -42,6 +42,8 @@ extern "C" {
 #define MI_EPI_MASK 8        /* v = msk[m][n] > 0 ? v : 0      ReLU backward of the producer of msk */
 #define MI_EPI_OUT_F32 16    /* store fp32 instead of bf16 */
 #define MI_EPI_ZSPLIT 32     /* fp32 store to [n/zgw][M][zgw] (ASPP tap planes) */
+#define MI_EPI_WRITE_MASK 64 /* also store sign bits of the result: bit n%16 of uint16 mask_out[m][n/16] = (v > 0)   (N % 16 == 0) */
+#define MI_EPI_BITMASK 128   /* like MI_EPI_MASK but `msk` points at such packed bits: 1/16 of the bytes of the bf16 tensor */
 
 /* gather modes */
 #define MI_GATHER_FWD 0      /* src = out*stride + tap*dil - pad            (forward conv, wgrad) */
@@ -73,7 +75,7 @@ int mi_pack_weights_multi(const float* wflat, const float* sflat, void* wp_bf16,
 int mi_conv_gemm(const void* a, const void* wp, void* out,
                  int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N,
                  int ksize, int stride, int pad, int dil, int gather_mode,
-                 const float* scale, const float* bias, const void* res, const void* msk,
+                 const float* scale, const float* bias, const void* res, const void* msk, void* mask_out,
                  int flags, int zgw, void* stream);
 
 /* ---- weight gradient (contraction over pixels), split-K with deterministic reduction ------------
@@ -154,8 +156,9 @@ int mi_stem_pool_bwd(const void* dpool, const uint8_t* idx, const float* scale, 
                      int B, int Hc, int Wc, int C, int Hp, int Wp, void* stream);
 
 /* ---- elementwise helpers ------------------------------------------------------------------------ */
-/* y = msk > 0 ? x : 0 (bf16, n % 8 == 0): ReLU backward across an autograd boundary */
-int mi_relu_mask(const void* x_bf16, const void* msk_bf16, void* y_bf16, size_t n, void* stream);
+/* y = msk > 0 ? x : 0 (bf16, n % 8 == 0): ReLU backward across an autograd boundary.  bits != 0: `msk` is the packed
+ * sign-bit tensor written by MI_EPI_WRITE_MASK (same element order). */
+int mi_relu_mask(const void* x_bf16, const void* msk, void* y_bf16, size_t n, int bits, void* stream);
 /* FrozenBN fold: scale = w*rsqrt(var) (no eps), shift = b - mean*scale (layers.py:18-20) */
 int mi_frozen_bn_fold(const float* w, const float* b, const float* mean, const float* var, float* scale, float* shift, int n, void* stream);
 

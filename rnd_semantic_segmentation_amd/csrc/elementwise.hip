@@ -64,7 +64,6 @@ __global__ void bn_fold_kernel(const float* w, const float* b, const float* mean
     shift[i] = b[i] - mean[i] * s;
 }
 
-}  // namespace
 
 extern "C" int mi_sgd_step(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float weight_decay, void* stream) {
     MI_REQUIRE(p && g && buf && n > 0, "mi_sgd_step: bad argument");
@@ -78,12 +77,33 @@ extern "C" int mi_sgd_step(float* p, const float* g, float* buf, size_t n, float
     return MI_OK;
 }
 
-extern "C" int mi_relu_mask(const void* x, const void* msk, void* y, size_t n, void* stream) {
+__global__ void relu_mask_bits_kernel(const bf16x8* __restrict__ x, const uint8_t* __restrict__ m, bf16x8* __restrict__ y, size_t n8) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        const bf16x8 xv = x[i];
+        const unsigned bits = m[i];              // 8 elements <-> one byte of the little-endian uint16 words
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = ((bits >> e) & 1u) ? xv[e] : (__bf16)0.f;
+        y[i] = o;
+    }
+}
+
+}  // namespace
+
+extern "C" int mi_relu_mask(const void* x, const void* msk, void* y, size_t n, int bits, void* stream) {
     MI_REQUIRE(x && msk && y && n > 0 && n % 8 == 0, "mi_relu_mask: bad argument (n %% 8 == 0)");
-    MI_REQUIRE(mi_aligned16(x) && mi_aligned16(msk) && mi_aligned16(y), "mi_relu_mask: alignment");
+    MI_REQUIRE(mi_aligned16(x) && mi_aligned16(y) && (bits || mi_aligned16(msk)), "mi_relu_mask: alignment");
     const size_t n8 = n >> 3;
     size_t blocks = (n8 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
+    if (bits) {
+        MI_REQUIRE(n % 16 == 0, "mi_relu_mask: packed mask needs n %% 16 == 0");
+        hipLaunchKernelGGL(relu_mask_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)x,
+                           (const uint8_t*)msk, (bf16x8*)y, n8);
+        MI_CHECK_LAUNCH("mi_relu_mask (bits)");
+        return MI_OK;
+    }
     hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)x, (const bf16x8*)msk,
                        (bf16x8*)y, n8);
     MI_CHECK_LAUNCH("mi_relu_mask");

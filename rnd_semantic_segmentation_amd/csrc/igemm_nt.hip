@@ -41,7 +41,8 @@ struct IgemmParams {
     const float* scale;
     const float* bias;
     const __bf16* res;
-    const __bf16* msk;
+    const __bf16* msk;            // bf16 tensor (MI_EPI_MASK) or packed sign bits, uint16 per 16 channels (MI_EPI_BITMASK)
+    uint16_t* mask_out;           // MI_EPI_WRITE_MASK: bit c%16 of word [m][c/16] = (out[m][c] > 0)
     int M, N, Ca, T;
     int Ho, Wo, Ha, Wa;
     int ksz, stride, pad, dil, mode;
@@ -259,6 +260,21 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
                 }
             }
         }
+        if (flags & MI_EPI_BITMASK) {
+            if (nb < p.N) {
+                const unsigned bits = reinterpret_cast<const uint16_t*>(p.msk)[(o >> 4)];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) v[c >> 2][c & 3] = ((bits >> c) & 1u) ? v[c >> 2][c & 3] : 0.f;
+            }
+        }
+        if (flags & MI_EPI_WRITE_MASK) {
+            if (nb < p.N) {
+                unsigned bits = 0;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) bits |= (v[c >> 2][c & 3] > 0.f ? 1u : 0u) << c;
+                p.mask_out[o >> 4] = (uint16_t)bits;
+            }
+        }
         if (flags & MI_EPI_ZSPLIT) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -290,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
 
 extern "C" int mi_conv_gemm(const void* a, const void* wp, void* out, int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N,
                             int ksize, int stride, int pad, int dil, int gather_mode, const float* scale, const float* bias,
-                            const void* res, const void* msk, int flags, int zgw, void* stream) {
+                            const void* res, const void* msk, void* mask_out, int flags, int zgw, void* stream) {
     MI_REQUIRE(a && wp && out, "mi_conv_gemm: null operand");
     MI_REQUIRE(B > 0 && Ha > 0 && Wa > 0 && Ho > 0 && Wo > 0 && N > 0, "mi_conv_gemm: non-positive dimension");
     MI_REQUIRE(Ca > 0 && Ca % 64 == 0, "mi_conv_gemm: Ca=%d must be a multiple of 64", Ca);
@@ -302,6 +318,8 @@ extern "C" int mi_conv_gemm(const void* a, const void* wp, void* out, int B, int
     MI_REQUIRE(!(flags & MI_EPI_SCALE_BIAS) || (scale && bias && mi_aligned16(scale) && mi_aligned16(bias)), "mi_conv_gemm: scale/bias");
     MI_REQUIRE(!(flags & MI_EPI_RESIDUAL) || (res && mi_aligned16(res)), "mi_conv_gemm: residual");
     MI_REQUIRE(!(flags & MI_EPI_MASK) || (msk && mi_aligned16(msk)), "mi_conv_gemm: mask");
+    MI_REQUIRE(!(flags & MI_EPI_BITMASK) || (msk && N % 16 == 0 && !(flags & MI_EPI_MASK)), "mi_conv_gemm: bit mask needs N %% 16 == 0");
+    MI_REQUIRE(!(flags & MI_EPI_WRITE_MASK) || (mask_out && N % 16 == 0), "mi_conv_gemm: mask_out needs N %% 16 == 0");
     MI_REQUIRE(!(flags & MI_EPI_ZSPLIT) || (zgw > 0 && zgw % 4 == 0 && N % zgw == 0), "mi_conv_gemm: zgw");
     const long M = (long)B * Ho * Wo;
     MI_REQUIRE(M < (1L << 31) && (long)B * Ha * Wa < (1L << 31), "mi_conv_gemm: pixel count overflows int32");
@@ -316,6 +334,7 @@ extern "C" int mi_conv_gemm(const void* a, const void* wp, void* out, int B, int
     p.bias = bias;
     p.res = (const __bf16*)res;
     p.msk = (const __bf16*)msk;
+    p.mask_out = (uint16_t*)mask_out;
     p.M = (int)M;
     p.N = N;
     p.Ca = Ca;

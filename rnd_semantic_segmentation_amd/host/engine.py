@@ -166,22 +166,37 @@ class StageEngine:
 
     # -- forward
     @staticmethod
-    def _fwd_conv(x, rt, relu, res=None):
+    def _fwd_conv(x, rt, relu, res=None, want_mask=False):
+        """conv + FrozenBN (+ residual) (+ ReLU).  want_mask: also return the packed sign bits of the output (1 bit per
+        element), which is all the backward pass needs of a ReLU'd activation when it is used only as a mask."""
         c = rt.spec
         hw = arch.out_hw(x.shape[1], x.shape[2], c)
-        return K.conv_gemm(x, rt.wp, hw, c.k, c.stride, c.pad, c.dil, K.GATHER_FWD, scale=rt.scale, bias=rt.shift, res=res, relu=relu)
+        bits = torch.empty((x.shape[0], hw[0], hw[1], c.cout // 16), dtype=torch.int16, device=x.device) if want_mask else None
+        y = K.conv_gemm(x, rt.wp, hw, c.k, c.stride, c.pad, c.dil, K.GATHER_FWD, scale=rt.scale, bias=rt.shift, res=res, relu=relu,
+                        mask_out=bits)
+        return (y, bits) if want_mask else y
 
     def forward(self, x, save):
+        """Returns (feature, saved, feature sign bits).  saved[i] = (x, a1, a2, bits(x) or None, bits(a1), bits(a2))."""
         saved = []
+        xbits = None
         for blk, rts in self.blocks:
-            a1 = self._fwd_conv(x, rts[0], True)
-            a2 = self._fwd_conv(a1, rts[1], True)
-            idn = self._fwd_conv(x, rts[3], False) if blk.down else x
-            out = self._fwd_conv(a2, rts[2], True, res=idn)
             if save:
-                saved.append((x, a1, a2))
+                a1, b1 = self._fwd_conv(x, rts[0], True, want_mask=True)
+                a2, b2 = self._fwd_conv(a1, rts[1], True, want_mask=True)
+            else:
+                a1 = self._fwd_conv(x, rts[0], True)
+                a2 = self._fwd_conv(a1, rts[1], True)
+                b1 = b2 = None
+            idn = self._fwd_conv(x, rts[3], False) if blk.down else x
+            if save:
+                out, obits = self._fwd_conv(a2, rts[2], True, res=idn, want_mask=True)
+                saved.append((x, a1, a2, xbits, b1, b2))
+                xbits = obits
+            else:
+                out = self._fwd_conv(a2, rts[2], True, res=idn)
             x = out
-        return x, saved
+        return x, saved, xbits
 
     # -- backward
     @staticmethod
@@ -191,24 +206,24 @@ class StageEngine:
         K.conv_wgrad(dy, xin, dw, c.k, c.stride, c.pad, c.dil, scale=rt.scale, accumulate=acc)
 
     @staticmethod
-    def _dgrad(dy, rt, in_hw, res=None, msk=None):
+    def _dgrad(dy, rt, in_hw, res=None, bits=None):
         c = rt.spec
-        return K.conv_gemm(dy, rt.wpt, in_hw, c.k, c.stride, c.pad, c.dil, K.GATHER_DGRAD, res=res, msk=msk)
+        return K.conv_gemm(dy, rt.wpt, in_hw, c.k, c.stride, c.pad, c.dil, K.GATHER_DGRAD, res=res, bits=bits)
 
-    def backward(self, saved, feat, dfeat, need_dx):
-        """dfeat: d loss / d feat (bf16 NHWC).  Returns d loss / d x of the first block (true gradient)."""
-        g = K.relu_mask(dfeat, feat)                      # through the last block's ReLU
+    def backward(self, saved, fbits, dfeat, need_dx):
+        """dfeat: d loss / d feat (bf16 NHWC); fbits: sign bits of feat.  Returns d loss / d x of the first block."""
+        g = K.relu_mask(dfeat, fbits)                     # through the last block's ReLU
         store = getattr(self.convs[0].weight, "_mi_store", None)
         for bi in range(len(self.blocks) - 1, -1, -1):
             blk, rts = self.blocks[bi]
-            x, a1, a2 = saved[bi]
+            x, a1, a2, xb, b1, b2 = saved[bi]
             first = bi == 0
             hw_in = (x.shape[1], x.shape[2])
             hw_mid = (a1.shape[1], a1.shape[2])
             self._wgrad(g, a2, rts[2])
-            ga2 = self._dgrad(g, rts[2], (a2.shape[1], a2.shape[2]), msk=a2)
+            ga2 = self._dgrad(g, rts[2], (a2.shape[1], a2.shape[2]), bits=b2)
             self._wgrad(ga2, a1, rts[1])
-            ga1 = self._dgrad(ga2, rts[1], hw_mid, msk=a1)
+            ga1 = self._dgrad(ga2, rts[1], hw_mid, bits=b1)
             self._wgrad(ga1, x, rts[0])
             if blk.down:
                 self._wgrad(g, x, rts[3])
@@ -216,7 +231,7 @@ class StageEngine:
                 g = None
             else:
                 skip = self._dgrad(g, rts[3], hw_in) if blk.down else g
-                g = self._dgrad(ga1, rts[0], hw_in, res=skip, msk=None if first else x)
+                g = self._dgrad(ga1, rts[0], hw_in, res=skip, bits=None if first else xb)
             saved[bi] = None                              # release activations as we go
             if store is not None and store.grad_hooks:
                 lo, hi = store.span([rt.weight for rt in rts])
@@ -254,15 +269,15 @@ class StagesFn(torch.autograd.Function):
     def forward(ctx, x, eng, *weights):
         train = any(ctx.needs_input_grad)            # (grad mode is off inside Function.forward)
         eng.prepare(train)
-        feat, saved = eng.forward(x, save=train)
-        ctx.eng, ctx.saved, ctx.feat = eng, saved, feat
+        feat, saved, fbits = eng.forward(x, save=train)
+        ctx.eng, ctx.saved, ctx.fbits = eng, saved, fbits
         return feat
 
     @staticmethod
     def backward(ctx, dfeat):
         dfeat = dfeat.contiguous()
-        dx = ctx.eng.backward(ctx.saved, ctx.feat, dfeat, ctx.needs_input_grad[0])
-        ctx.saved = ctx.feat = None
+        dx = ctx.eng.backward(ctx.saved, ctx.fbits, dfeat, ctx.needs_input_grad[0])
+        ctx.saved = ctx.fbits = None
         return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 

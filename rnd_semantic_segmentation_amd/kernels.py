@@ -11,7 +11,7 @@ import torch
 from . import _lib
 from ._lib import check
 
-EPI_SCALE_BIAS, EPI_RESIDUAL, EPI_RELU, EPI_MASK, EPI_OUT_F32, EPI_ZSPLIT = 1, 2, 4, 8, 16, 32
+EPI_SCALE_BIAS, EPI_RESIDUAL, EPI_RELU, EPI_MASK, EPI_OUT_F32, EPI_ZSPLIT, EPI_WRITE_MASK, EPI_BITMASK = 1, 2, 4, 8, 16, 32, 64, 128
 GATHER_FWD, GATHER_DGRAD = 0, 1
 ASPP_ZGW, ASPP_KPAD = 20, 704
 
@@ -77,8 +77,10 @@ def pack_weights_multi(wflat, sflat, wp, wpt, table_dev, n_desc, total_blocks):
 
 
 def conv_gemm(a, wp, out_hw, ksize=1, stride=1, pad=0, dil=1, mode=GATHER_FWD, scale=None, bias=None, res=None,
-              msk=None, relu=False, out_f32=False, zsplit=0, out=None):
-    """out[b,ho,wo,n] = epi(sum_{t,c} a[b,src(ho,wo,t),c] * wp[t,n,c]);  a [B,Ha,Wa,Ca] bf16, wp [k*k,N,Ca] bf16."""
+              msk=None, relu=False, out_f32=False, zsplit=0, out=None, bits=None, mask_out=None):
+    """out[b,ho,wo,n] = epi(sum_{t,c} a[b,src(ho,wo,t),c] * wp[t,n,c]);  a [B,Ha,Wa,Ca] bf16, wp [k*k,N,Ca] bf16.
+    msk: bf16 [B,Ho,Wo,N] ReLU mask source; bits: the same mask as packed sign bits (int16 [B,Ho,Wo,N/16]);
+    mask_out: int16 [B,Ho,Wo,N/16] receiving the sign bits of the result."""
     _chk(a, torch.bfloat16, "a")
     _chk(wp, torch.bfloat16, "wp")
     B, Ha, Wa, Ca = a.shape
@@ -101,6 +103,15 @@ def conv_gemm(a, wp, out_hw, ksize=1, stride=1, pad=0, dil=1, mode=GATHER_FWD, s
         flags |= EPI_MASK
         _chk(msk, torch.bfloat16, "msk")
         assert tuple(msk.shape) == (B, Ho, Wo, N)
+    if bits is not None:
+        flags |= EPI_BITMASK
+        _chk(bits, torch.int16, "bits")
+        assert tuple(bits.shape) == (B, Ho, Wo, N // 16) and msk is None
+        msk = bits
+    if mask_out is not None:
+        flags |= EPI_WRITE_MASK
+        _chk(mask_out, torch.int16, "mask_out")
+        assert tuple(mask_out.shape) == (B, Ho, Wo, N // 16)
     if zsplit:
         flags |= EPI_ZSPLIT | EPI_OUT_F32
         if out is None:
@@ -117,7 +128,7 @@ def conv_gemm(a, wp, out_hw, ksize=1, stride=1, pad=0, dil=1, mode=GATHER_FWD, s
     flops = 2.0 * B * Ho * Wo * n_real * ca_real * ksize * ksize
     check(_timed("igemm_nt_kernel", flops, lambda: _lib.lib().mi_conv_gemm(
         _p(a), _p(wp), _p(out), B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, pad, dil, mode,
-        _p(scale), _p(bias), _p(res), _p(msk), flags, zsplit, _stream())), "mi_conv_gemm")
+        _p(scale), _p(bias), _p(res), _p(msk), _p(mask_out), flags, zsplit, _stream())), "mi_conv_gemm")
     return out
 
 
@@ -295,11 +306,13 @@ def sgd_step(p, g, buf, lr, momentum, weight_decay):
 
 
 def relu_mask(x, msk, out=None):
+    """y = msk > 0 ? x : 0;  msk is a bf16 tensor of x's shape, or packed sign bits (int16, x.numel()/16 words)."""
     _chk(x, torch.bfloat16, "x")
-    _chk(msk, torch.bfloat16, "msk")
+    bits = msk.dtype == torch.int16
+    _chk(msk, torch.int16 if bits else torch.bfloat16, "msk")
     if out is None:
         out = torch.empty_like(x)
-    check(_lib.lib().mi_relu_mask(_p(x), _p(msk), _p(out), x.numel(), _stream()), "mi_relu_mask")
+    check(_lib.lib().mi_relu_mask(_p(x), _p(msk), _p(out), x.numel(), int(bits), _stream()), "mi_relu_mask")
     return out
 
 

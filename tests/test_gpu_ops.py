@@ -100,6 +100,16 @@ def test_conv_fused_epilogue_bn_residual_relu_mask():
     ym = K.conv_gemm(xd, wp, (H, W), 3, 1, d, d, res=resd, msk=y16, out_f32=True)
     want_m = (conv + res) * (to_nchw(y16) > 0)
     assert relmax(to_nchw(ym), want_m) < 2e-5
+    # packed sign bits: written by the forward epilogue, consumed by the backward epilogue (1/16 of the bf16 mask's bytes)
+    bits = torch.empty((B, H, W, Co // 16), dtype=torch.int16, device=DEV)
+    y16b = K.conv_gemm(xd, wp, (H, W), 3, 1, d, d, scale=sc, bias=sh, res=resd, relu=True, mask_out=bits)
+    assert torch.equal(y16b, y16)
+    unpacked = ((bits.view(B, H, W, Co // 16, 1).int() >> torch.arange(16, device=DEV).int()) & 1).bool().reshape(B, H, W, Co)
+    assert torch.equal(unpacked, y16 > 0)
+    ymb = K.conv_gemm(xd, wp, (H, W), 3, 1, d, d, res=resd, bits=bits, out_f32=True)
+    assert torch.equal(ymb, ym)
+    gtest = torch.randn((B, H, W, Co), device=DEV).to(torch.bfloat16)
+    assert torch.equal(K.relu_mask(gtest, bits), K.relu_mask(gtest, y16))
     # scale folded into the dgrad pack and into the wgrad reduce
     dy = synth.bf16_round(synth.uniform("t.dy", (B, Co, H, W)))
     wpt = K.pack_weight_dgrad(dev(w), sc)
