@@ -51,21 +51,15 @@ struct IgemmParams {
 };
 
 __device__ __forceinline__ bool tap_src(const IgemmParams& p, int ho, int wo, int ky, int kx, int& ha, int& wa) {
-    if (p.mode == MI_GATHER_FWD) {
-        ha = ho * p.stride + ky * p.dil - p.pad;
-        wa = wo * p.stride + kx * p.dil - p.pad;
-        return (unsigned)ha < (unsigned)p.Ha && (unsigned)wa < (unsigned)p.Wa;
-    }
-    int nh = ho + p.pad - ky * p.dil, nw = wo + p.pad - kx * p.dil;
-    if (nh < 0 || nw < 0) return false;
-    if (p.stride > 1) {
-        if ((nh % p.stride) | (nw % p.stride)) return false;
-        nh /= p.stride;
-        nw /= p.stride;
-    }
-    ha = nh;
-    wa = nw;
-    return nh < p.Ha && nw < p.Wa;
+    // general gather (any stride), branch-free
+    const bool fwd = p.mode == MI_GATHER_FWD;
+    const int fh = ho * p.stride + ky * p.dil - p.pad, fw = wo * p.stride + kx * p.dil - p.pad;
+    const int nh = ho + p.pad - ky * p.dil, nw = wo + p.pad - kx * p.dil;
+    const int qh = nh / p.stride, qw = nw / p.stride;              // stride >= 1; exactness checked below
+    const bool dg_ok = (nh >= 0) & (nw >= 0) & (qh * p.stride == nh) & (qw * p.stride == nw);
+    ha = fwd ? fh : qh;
+    wa = fwd ? fw : qw;
+    return (fwd | dg_ok) & ((unsigned)ha < (unsigned)p.Ha) & ((unsigned)wa < (unsigned)p.Wa);
 }
 
 __device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
@@ -73,7 +67,7 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int MT>
+template <int MT, bool UNIT>
 __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
     constexpr int BM = Geo<MT>::BM, ATILE_BYTES = Geo<MT>::ATILE_BYTES, STAGE_BYTES = Geo<MT>::STAGE_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -88,27 +82,45 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
     //      lane -> (row = piece*8 + lane>>3, physical chunk = lane&7); it fetches logical chunk physical ^ s(row).
     const int prow = lane >> 3, pch = lane & 7;
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
+    // Per-row state.  UNIT (stride 1, the 100+ launches per step that matter): the source pixel of tap t is the row's own
+    // pixel plus a tap offset that is THE SAME for every row, so a tap change costs a handful of VALU ops per row:
+    // a 64-bit base pointer per row, one scalar byte offset per tap, and a 9-bit per-row validity mask computed once.
+    // (General path, stride 2: coordinates are kept and the source recomputed per tap.)
     int a_img[MT], a_ho[MT], a_wo[MT];
+    const char* a_base[MT];
+    unsigned a_mask[MT];
     const int HoWo = p.Ho * p.Wo;
+    const int a_chunk = (pch ^ (prow & 7)) * 16;                       // s_A(row) = row & 7
+    const int sgn = (p.mode == MI_GATHER_FWD) ? 1 : -1;                // FWD: src = out + tap*dil - pad ; DGRAD: out + pad - tap*dil
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int m = m0 + (wave * MT + i) * 8 + prow;
-        if (m < p.M) {
-            const int b = m / HoWo, rem = m - b * HoWo;
-            a_ho[i] = rem / p.Wo;
-            a_wo[i] = rem - a_ho[i] * p.Wo;
-            a_img[i] = b * p.Ha * p.Wa;
-        } else {
-            a_img[i] = -1;
-            a_ho[i] = a_wo[i] = 0;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int b = mm / HoWo, rem = mm - b * HoWo;
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        a_ho[i] = ho;
+        a_wo[i] = wo;
+        a_img[i] = ok ? b * p.Ha * p.Wa : -1;
+        if (UNIT) {
+            const int h0 = ho - sgn * p.pad, w0 = wo - sgn * p.pad;   // tap (0,0) source; Ha == Ho, Wa == Wo here
+            a_base[i] = reinterpret_cast<const char*>(p.A + ((long)b * p.Ha * p.Wa + (long)h0 * p.Wa + w0) * p.Ca) + a_chunk;
+            unsigned msk = 0;
+            for (int t = 0; t < p.T; ++t) {
+                const int ky = t / p.ksz, kx = t - ky * p.ksz;
+                const int hs = h0 + sgn * ky * p.dil, ws = w0 + sgn * kx * p.dil;
+                msk |= (unsigned)(ok & ((unsigned)hs < (unsigned)p.Ha) & ((unsigned)ws < (unsigned)p.Wa)) << t;
+            }
+            a_mask[i] = msk;
         }
     }
-    const int a_chunk = (pch ^ (prow & 7)) * 16;                       // s_A(row) = row & 7
     int w_row[4], w_chunk[4];
+    const char* w_base[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         w_row[i] = n0 + (wave * 4 + i) * 8 + prow;
         w_chunk[i] = (pch ^ ((prow & 3) | ((i >> 1) << 2))) * 16;      // s_W(row) = (row&3) | ((row>>4)&1)<<2
+        w_base[i] = reinterpret_cast<const char*>(p.Wp + (long)(w_row[i] < p.N ? w_row[i] : 0) * p.Ca) + w_chunk[i];
     }
 
     const int cpt = p.Ca >> 6;          // 64-channel chunks per tap
@@ -117,29 +129,34 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
     const char* a_ptr[MT];
     const char* w_ptr[4];
     int a_inc[MT], w_inc[4];
+    const long w_tap_bytes = (long)p.N * p.Ca * 2;
 
-    auto set_tap = [&](int t) {
+    auto set_tap = [&](int t) __attribute__((always_inline)) {
         const int ky = t / p.ksz, kx = t - ky * p.ksz;
+        if (UNIT) {
+            const long toff = (long)sgn * ((long)ky * p.dil * p.Wa + (long)kx * p.dil) * p.Ca * 2;   // wave-uniform
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            int ha, wa;
-            if (a_img[i] >= 0 && tap_src(p, a_ho[i], a_wo[i], ky, kx, ha, wa)) {
-                a_ptr[i] = reinterpret_cast<const char*>(p.A + ((long)(a_img[i] + ha * p.Wa + wa)) * p.Ca) + a_chunk;
-                a_inc[i] = 128;
-            } else {
-                a_ptr[i] = zero;
-                a_inc[i] = 0;
+            for (int i = 0; i < MT; ++i) {
+                const bool ok = (a_mask[i] >> t) & 1u;
+                a_ptr[i] = ok ? a_base[i] + toff : zero;
+                a_inc[i] = ok ? 128 : 0;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                int ha = 0, wa = 0;
+                const bool ok = tap_src(p, a_ho[i], a_wo[i], ky, kx, ha, wa) && a_img[i] >= 0;
+                const char* ptr = reinterpret_cast<const char*>(p.A + ((long)((ok ? a_img[i] : 0) + (ok ? ha : 0) * p.Wa + (ok ? wa : 0))) * p.Ca) + a_chunk;
+                a_ptr[i] = ok ? ptr : zero;
+                a_inc[i] = ok ? 128 : 0;
             }
         }
+        const long woff = (long)t * w_tap_bytes;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (w_row[i] < p.N) {
-                w_ptr[i] = reinterpret_cast<const char*>(p.Wp + ((long)t * p.N + w_row[i]) * p.Ca) + w_chunk[i];
-                w_inc[i] = 128;
-            } else {
-                w_ptr[i] = zero;
-                w_inc[i] = 0;
-            }
+            const bool ok = w_row[i] < p.N;
+            w_ptr[i] = ok ? w_base[i] + woff : zero;
+            w_inc[i] = ok ? 128 : 0;
         }
     };
     set_tap(0);
@@ -369,20 +386,25 @@ extern "C" int mi_conv_gemm(const void* a, const void* wp, void* out, int B, int
     if (force_mt >= 4 && force_mt <= 6) mt_sel = force_mt;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<4>::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<5>::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<6>::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<4>::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<5>::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<6>::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<4>::LDS_BYTES);
         attr_set = true;
     }
+    const bool unit = stride == 1 && Ha == Ho && Wa == Wo && ksize * ksize <= 9;
+    if (!unit) mt_sel = 4;                               // the general (strided) gather exists in the 128-row shape only
     const int bm = mt_sel * 32;
     p.m_tiles = (int)((M + bm - 1) / bm);
     const dim3 grid(p.m_tiles * p.n_tiles);
-    if (mt_sel == 6)
-        hipLaunchKernelGGL(igemm_nt_kernel<6>, grid, dim3(256), Geo<6>::LDS_BYTES, (hipStream_t)stream, p);
+    if (!unit)
+        hipLaunchKernelGGL((igemm_nt_kernel<4, false>), grid, dim3(256), Geo<4>::LDS_BYTES, (hipStream_t)stream, p);
+    else if (mt_sel == 6)
+        hipLaunchKernelGGL((igemm_nt_kernel<6, true>), grid, dim3(256), Geo<6>::LDS_BYTES, (hipStream_t)stream, p);
     else if (mt_sel == 5)
-        hipLaunchKernelGGL(igemm_nt_kernel<5>, grid, dim3(256), Geo<5>::LDS_BYTES, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((igemm_nt_kernel<5, true>), grid, dim3(256), Geo<5>::LDS_BYTES, (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL(igemm_nt_kernel<4>, grid, dim3(256), Geo<4>::LDS_BYTES, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((igemm_nt_kernel<4, true>), grid, dim3(256), Geo<4>::LDS_BYTES, (hipStream_t)stream, p);
     MI_CHECK_LAUNCH("mi_conv_gemm");
     return MI_OK;
 }
