@@ -45,8 +45,10 @@ __device__ __forceinline__ void glds16_tn(const char* gsrc, char* lds_wave_base)
 // The LDS image is lane-linear per DMA; 16-B chunk c of pixel row r sits at physical chunk c ^ ((r & 7) << 1), applied to
 // the per-lane SOURCE address and to the transposed-read address.  With that XOR the 32 lanes of a
 // ds_read_b64_tr_b16 half-wave (8 pixel rows x 32 B) hit 64 distinct banks.
-template <bool UNIT_STRIDE>
+// MODE 0: general (any stride)   1: unit stride, k x k taps   2: 1x1, stride 1 (no pixel coordinates needed at all)
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradParams p) {
+    constexpr bool UNIT_STRIDE = MODE >= 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -100,7 +102,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradParams p) {
             const bool row_ok = r_m[j] < m_end;
             const char* gy = (row_ok && y_col[j]) ? y_ptr[j] : zero;
             const char* gx = zero;
-            if (UNIT_STRIDE) {
+            if (MODE == 2) {
+                gx = (row_ok && x_col[j]) ? x_ptr[j] : zero;
+            } else if (MODE == 1) {
                 const int hs = r_ho[j] + dys, ws = r_wo[j] + dxs;
                 if (row_ok && x_col[j] && (unsigned)hs < (unsigned)p.Ha && (unsigned)ws < (unsigned)p.Wa) gx = x_ptr[j];
             } else {
@@ -115,15 +119,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradParams p) {
             r_m[j] += KP;
             y_ptr[j] += y_step;
             x_ptr[j] += x_step;
-            r_wo[j] += step_r;
-            r_ho[j] += step_q;
-            if (r_wo[j] >= p.Wo) {
-                r_wo[j] -= p.Wo;
-                ++r_ho[j];
-            }
-            while (r_ho[j] >= p.Ho) {
-                r_ho[j] -= p.Ho;
-                ++r_b[j];
+            if (MODE != 2) {
+                r_wo[j] += step_r;
+                r_ho[j] += step_q;
+                if (r_wo[j] >= p.Wo) {
+                    r_wo[j] -= p.Wo;
+                    ++r_ho[j];
+                }
+                while (r_ho[j] >= p.Ho) {
+                    r_ho[j] -= p.Ho;
+                    ++r_b[j];
+                }
             }
         }
     };
@@ -304,15 +310,19 @@ extern "C" int mi_conv_wgrad(const void* dy, const void* x, float* dw, int B, in
     p.rows_per_split = (int)(((steps + p.S - 1) / p.S) * KP);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)wgrad_tn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)wgrad_tn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)wgrad_tn_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)wgrad_tn_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)wgrad_tn_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
     const unsigned nblocks = (unsigned)(p.o_tiles * p.i_tiles * p.T * p.S);
-    if (stride == 1 && Ha == Ho && Wa == Wo)
-        hipLaunchKernelGGL(wgrad_tn_kernel<true>, dim3(nblocks), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
+    const bool unit = stride == 1 && Ha == Ho && Wa == Wo;
+    if (unit && ksize == 1 && pad == 0)
+        hipLaunchKernelGGL(wgrad_tn_kernel<2>, dim3(nblocks), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
+    else if (unit)
+        hipLaunchKernelGGL(wgrad_tn_kernel<1>, dim3(nblocks), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL(wgrad_tn_kernel<false>, dim3(nblocks), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(wgrad_tn_kernel<0>, dim3(nblocks), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
     MI_CHECK_LAUNCH("mi_conv_wgrad");
     int o_real = O, ncls = 1;
     if (out_map == 1) {
