@@ -172,7 +172,12 @@ def main():
         if events:
             inst_steps = (args.steps + 3) // 4
             by = {}
-            for name, e0, e1, flops in events:
+            shapes = {}
+            for name, e0, e1, flops, tag in events:
+                sh = shapes.setdefault(tag, [0.0, 0.0, 0])
+                sh[0] += e0.elapsed_time(e1) * 1e-3
+                sh[1] += flops
+                sh[2] += 1
                 d = by.setdefault(name, [0.0, 0.0, 0])
                 d[0] += e0.elapsed_time(e1) * 1e-3
                 d[1] += flops
@@ -186,6 +191,10 @@ def main():
                                "instrumented_steps": inst_steps}
             out["kernels"] = {k: {"ms_per_step": round(1e3 * v[0] / inst_steps, 3), "tflops": round(v[1] / v[0] / 1e12, 2),
                                   "launches_per_step": v[2] // inst_steps} for k, v in by.items()}
+        if events and os.environ.get("MI_BENCH_SHAPES"):
+            note("in-step per-shape table: kind k Cin N M flags | launches/step  us/launch  TFLOP/s  ms/step")
+            for tag, (tsec, fl, n) in sorted(shapes.items(), key=lambda kv: -kv[1][0]):
+                note("%-6s k%d Cin%-5d N%-5d M%-7d f%-4d | %3d  %8.1f  %7.0f  %6.3f" % (tag + (n // inst_steps, 1e6 * tsec / n, fl / tsec / 1e12, 1e3 * tsec / inst_steps)))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.size)
         print(json.dumps(out), flush=True)

@@ -67,7 +67,9 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int MT, bool UNIT>
+// PREF: the epilogue's residual rows and mask bits are requested BEFORE the main loop (they are 150-300 MB of HBM traffic
+// per launch on the 1024/2048-channel tensors) so that they land behind the MFMA work instead of after it.
+template <int MT, bool UNIT, bool PREF>
 __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
     constexpr int BM = Geo<MT>::BM, ATILE_BYTES = Geo<MT>::ATILE_BYTES, STAGE_BYTES = Geo<MT>::STAGE_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -190,6 +192,21 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
 
     const int frow = lane & 15, fq = lane >> 4;
     const int wrow0 = wn * 64 + 16 * (frow >> 2) + (frow & 3);          // + 4*i : permuted weight row of MFMA tile i
+    bf16x8 pres[PREF ? MT : 1][2];
+    unsigned pbits[PREF ? MT : 1];
+    if (PREF) {
+        const int nbp = n0 + wn * 64 + 16 * fq;
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int m = m0 + wm * (MT * 16) + j * 16 + frow;
+            const long o = (long)(m < p.M ? m : 0) * p.N + (nbp < p.N ? nbp : 0);
+            if (p.flags & MI_EPI_RESIDUAL) {
+                pres[j][0] = *reinterpret_cast<const bf16x8*>(p.res + o);
+                pres[j][1] = *reinterpret_cast<const bf16x8*>(p.res + o + 8);
+            }
+            if (p.flags & MI_EPI_BITMASK) pbits[j] = reinterpret_cast<const uint16_t*>(p.msk)[o >> 4];
+        }
+    }
     auto compute = [&](int buf) {
         const char* sa = smem + buf * STAGE_BYTES;
         const char* sb = sa + ATILE_BYTES;
@@ -254,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 if (nb + 8 * h < p.N) {
-                    const bf16x8 r = *reinterpret_cast<const bf16x8*>(p.res + o + 8 * h);
+                    const bf16x8 r = PREF ? pres[PREF ? j : 0][h] : *reinterpret_cast<const bf16x8*>(p.res + o + 8 * h);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[2 * h + (e >> 2)][e & 3] += (float)r[e];
                 }
@@ -279,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
         }
         if (flags & MI_EPI_BITMASK) {
             if (nb < p.N) {
-                const unsigned bits = reinterpret_cast<const uint16_t*>(p.msk)[(o >> 4)];
+                const unsigned bits = PREF ? pbits[PREF ? j : 0] : reinterpret_cast<const uint16_t*>(p.msk)[(o >> 4)];
 #pragma unroll
                 for (int c = 0; c < 16; ++c) v[c >> 2][c & 3] = ((bits >> c) & 1u) ? v[c >> 2][c & 3] : 0.f;
             }
@@ -386,25 +403,38 @@ extern "C" int mi_conv_gemm(const void* a, const void* wp, void* out, int B, int
     if (force_mt >= 4 && force_mt <= 6) mt_sel = force_mt;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<4>::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<5>::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<6>::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<4>::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<4, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<4>::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<5, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<5>::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<6, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<6>::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<4>::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<5, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<5>::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<4, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<4>::LDS_BYTES);
         attr_set = true;
     }
     const bool unit = stride == 1 && Ha == Ho && Wa == Wo && ksize * ksize <= 9;
+    static int pref_on = -1;
+    if (pref_on < 0) {
+        const char* e = getenv("MI_IGEMM_PREF");
+        pref_on = e ? atoi(e) : 1;
+    }
+    const bool pref = pref_on && unit && (flags & MI_EPI_RESIDUAL) && N % 16 == 0;
     if (!unit) mt_sel = 4;                               // the general (strided) gather exists in the 128-row shape only
+    if (pref && mt_sel == 6) mt_sel = 5;                 // the prefetched rows cost 8 VGPRs per 16-row MFMA tile
     const int bm = mt_sel * 32;
     p.m_tiles = (int)((M + bm - 1) / bm);
     const dim3 grid(p.m_tiles * p.n_tiles);
     if (!unit)
-        hipLaunchKernelGGL((igemm_nt_kernel<4, false>), grid, dim3(256), Geo<4>::LDS_BYTES, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((igemm_nt_kernel<4, false, false>), grid, dim3(256), Geo<4>::LDS_BYTES, (hipStream_t)stream, p);
+    else if (pref && mt_sel == 5)
+        hipLaunchKernelGGL((igemm_nt_kernel<5, true, true>), grid, dim3(256), Geo<5>::LDS_BYTES, (hipStream_t)stream, p);
+    else if (pref)
+        hipLaunchKernelGGL((igemm_nt_kernel<4, true, true>), grid, dim3(256), Geo<4>::LDS_BYTES, (hipStream_t)stream, p);
     else if (mt_sel == 6)
-        hipLaunchKernelGGL((igemm_nt_kernel<6, true>), grid, dim3(256), Geo<6>::LDS_BYTES, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((igemm_nt_kernel<6, true, false>), grid, dim3(256), Geo<6>::LDS_BYTES, (hipStream_t)stream, p);
     else if (mt_sel == 5)
-        hipLaunchKernelGGL((igemm_nt_kernel<5, true>), grid, dim3(256), Geo<5>::LDS_BYTES, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((igemm_nt_kernel<5, true, false>), grid, dim3(256), Geo<5>::LDS_BYTES, (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL((igemm_nt_kernel<4, true>), grid, dim3(256), Geo<4>::LDS_BYTES, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((igemm_nt_kernel<4, true, false>), grid, dim3(256), Geo<4>::LDS_BYTES, (hipStream_t)stream, p);
     MI_CHECK_LAUNCH("mi_conv_gemm");
     return MI_OK;
 }

@@ -25,14 +25,14 @@ def _stream():
 PROFILE = None
 
 
-def _timed(name, flops, launch):
+def _timed(name, flops, launch, tag=None):
     if PROFILE is None:
         return launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     rc = launch()
     e1.record()
-    PROFILE.append((name, e0, e1, flops))
+    PROFILE.append((name, e0, e1, flops, tag))
     return rc
 
 
@@ -128,7 +128,8 @@ def conv_gemm(a, wp, out_hw, ksize=1, stride=1, pad=0, dil=1, mode=GATHER_FWD, s
     flops = 2.0 * B * Ho * Wo * n_real * ca_real * ksize * ksize
     check(_timed("igemm_nt_kernel", flops, lambda: _lib.lib().mi_conv_gemm(
         _p(a), _p(wp), _p(out), B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, pad, dil, mode,
-        _p(scale), _p(bias), _p(res), _p(msk), _p(mask_out), flags, zsplit, _stream())), "mi_conv_gemm")
+        _p(scale), _p(bias), _p(res), _p(msk), _p(mask_out), flags, zsplit, _stream()),
+        tag=("dgrad" if mode == GATHER_DGRAD else "fwd", ksize, Ca, N, B * Ho * Wo, flags)), "mi_conv_gemm")
     return out
 
 
@@ -158,7 +159,7 @@ def conv_wgrad(dy, x, dw, ksize=1, stride=1, pad=0, dil=1, scale=None, accumulat
     flops = 2.0 * B * Ho * Wo * o_real * I * ksize * ksize
     check(_timed("wgrad_tn_kernel+reduce", flops, lambda: L.mi_conv_wgrad(
         _p(dy), _p(x), _p(dw), B, Ha, Wa, I, Ho, Wo, O, ksize, stride, pad, dil, _p(scale),
-        int(accumulate), out_map, _p(ws), ws.numel(), _stream())), "mi_conv_wgrad")
+        int(accumulate), out_map, _p(ws), ws.numel(), _stream()), tag=("wgrad", ksize, I, O, B * Ho * Wo, 0)), "mi_conv_wgrad")
     return dw
 
 
