@@ -184,8 +184,13 @@ def main():
                 d[2] += 1
             dom = max(by, key=lambda k: by[k][0])
             tsec, fl, n = by[dom]
+            traffic = None     # HBM bytes per launch from the committed PMC passes (profiles/pmc.json, see profiles/make_pmc_json.py)
+            try:
+                traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc.json")))[dom]["hbm_bytes_per_launch"]
+            except (OSError, KeyError, ValueError):
+                pass
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(fl / tsec / 1e12, 2), "peak": PEAK_BF16_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(fl / tsec / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                               "unit": "TFLOP/s", "frac": round(fl / tsec / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                                "launches_per_step": n // inst_steps, "avg_launch_us": round(1e6 * tsec / n, 2),
                                "alg_gflop_per_launch": round(fl / n / 1e9, 3), "ms_per_step_in_kernel": round(1e3 * tsec / inst_steps, 3),
                                "instrumented_steps": inst_steps}

@@ -309,3 +309,31 @@ def test_stem_bn_relu_maxpool_fused_vs_torch_ops():
     assert err <= 2.0 ** -7 * want.abs().max().item()
     # gradient only where the activation is positive
     assert not (dy.float().abs() > 0)[(act.permute(0, 2, 3, 1) <= 0)].any()
+
+
+@pytest.mark.parametrize("cin,cout,k,d", [(256, 256, 3, 2), (1024, 256, 1, 1), (512, 512, 3, 4)])
+def test_conv_full_size_vs_pytorch_fp32_conv(cin, cout, k, d):
+    """BASELINE shapes (B=8, 97x97 -> M = 75 272 GEMM rows): forward, data gradient and weight gradient against PyTorch's own
+    fp32 convolution on the GPU, fed the same bf16-rounded operands.  Tolerance 1e-3 of the tensor's max (BASELINE.json's
+    bar); both sides accumulate in fp32, so the measured difference is ~1e-5."""
+    import torch.nn.functional as F
+    B, H = 8, 97
+    g = torch.Generator(device="cpu").manual_seed(cin + cout + k)
+    x = torch.randn((B, H, H, cin), generator=g).to(DEV).to(torch.bfloat16)
+    dy = torch.randn((B, H, H, cout), generator=g).to(DEV).to(torch.bfloat16)
+    w = (torch.randn((cout, cin, k, k), generator=g) * (2.0 / (cin * k * k)) ** 0.5).to(DEV).to(torch.bfloat16).float()
+    pad = d if k == 3 else 0
+    prev = torch.backends.cudnn.allow_tf32
+    xr = x.permute(0, 3, 1, 2).float().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, 1, pad, d)
+    yr.backward(dy.permute(0, 3, 1, 2).float())
+    torch.backends.cudnn.allow_tf32 = prev
+    rel = lambda a, b: ((a.float() - b.float()).abs().max() / b.float().abs().max()).item()
+    y = K.conv_gemm(x, K.pack_weight_fwd(w), (H, H), k, 1, pad, d, out_f32=True)
+    assert rel(y, yr.detach().permute(0, 2, 3, 1)) < 1e-3
+    dx = K.conv_gemm(dy, K.pack_weight_dgrad(w), (H, H), k, 1, pad, d, K.GATHER_DGRAD, out_f32=True)
+    assert rel(dx, xr.grad.permute(0, 2, 3, 1)) < 1e-3
+    dw = torch.empty_like(w)
+    K.conv_wgrad(dy, x, dw, k, 1, pad, d)
+    assert rel(dw, wr.grad) < 1e-3
