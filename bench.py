@@ -91,7 +91,7 @@ def main():
         raise SystemExit("bench.py measures the MI355X path; no GPU is visible")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or os.environ.get("MI_DDP_FORCE") == "1":
         dist.init_process_group(backend="nccl", init_method="env://")       # RCCL
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
@@ -203,7 +203,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.size)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

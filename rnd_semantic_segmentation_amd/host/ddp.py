@@ -10,6 +10,8 @@ losses, as DistributedDataParallel does); FrozenBN needs no cross-rank statistic
 Backward produces weight gradients in reverse layer order and the flat buffer is laid out in forward order, so
 finished gradients form a growing suffix of the buffer: buckets are contiguous ranges cut from the end.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -27,6 +29,8 @@ class GradAllReducer:
         self.stores = list(stores)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # MI_DDP_FORCE=1: issue the collectives even in a single-rank group (exercises the side-stream / RCCL path on one GPU)
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("MI_DDP_FORCE") == "1")
         self.overlap = overlap
         self.buckets = {}
         self.lowwater = {}
@@ -47,7 +51,7 @@ class GradAllReducer:
         self.side = torch.cuda.Stream(device=dev) if self.cuda else None
 
     def _launch(self, st, b):
-        if b.launched or self.world == 1:
+        if b.launched or not self.active:
             b.launched = True
             return
         b.launched = True
@@ -98,12 +102,12 @@ class GradAllReducer:
                     b.work = None
                 b.launched = False
             self.lowwater[id(st)] = st.total
-        if self.cuda and self.world > 1:
+        if self.cuda and self.active:
             torch.cuda.current_stream().wait_stream(self.side)
 
     def broadcast_parameters(self, src=0):
         """Rank-0 weights everywhere before the first step (what DDP's constructor does)."""
-        if self.world == 1:
+        if not self.active:
             return
         for st in self.stores:
             dist.broadcast(st.data, src=src, group=self.pg)

@@ -52,7 +52,7 @@ class ASPPTrainer(BaseTrainer):
         self.rank = dist.get_rank() if self.world_size > 1 else 0
         self.distributed = self.world_size > 1
         self.reducer = None
-        if self.distributed:
+        if self.distributed or (dist.is_available() and dist.is_initialized() and os.environ.get("MI_DDP_FORCE") == "1"):
             stores = [m.ensure_flat() if hasattr(m, "ensure_flat") else _cpu_store(m) for m in (self.classifier, self.feature_extractor)]
             self.reducer = ddp.GradAllReducer(stores)
             self.reducer.broadcast_parameters(0)

@@ -40,3 +40,20 @@ def test_train_src_then_test_py_roundtrip(tmp_path):
     cm = json.load(open(os.path.join(out, "aspp_confusion_matrix.json")))
     assert len(cm["cmt"]) == 19 and cm["classes"][0] == "road" and sum(map(sum, cm["cmt"])) > 0
     assert "Micro metric, val result: mIoU/mF1" in r.stderr + r.stdout
+
+
+def test_bench_under_torchrun_nccl_single_rank_exercises_the_reducer():
+    """The data-parallel code path (RCCL process group, bucketed all-reduce on a side HIP stream behind events, barrier,
+    max-over-ranks timing) on the one GPU available: a single-rank `nccl` job with MI_DDP_FORCE=1 issues every collective."""
+    import math
+    r = run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29533",
+             "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1", "--size", "161", "--batch", "2", "--no-cpu-baseline"],
+            {"MI_DDP_FORCE": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["value"] > 0 and math.isfinite(out["config"]["final_loss"])
+    # same run without the process group gives the same loss (the reducer averaged over one rank)
+    r2 = run(["bench.py", "--steps", "3", "--warmup", "1", "--size", "161", "--batch", "2", "--no-cpu-baseline"], {})
+    out2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
+    assert abs(out2["config"]["final_loss"] - out["config"]["final_loss"]) < 1e-4
