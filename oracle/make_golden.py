@@ -93,6 +93,7 @@ def import_reference():
     from core.models.classifiers.aspp.classifier import ASPP_Classifier_V2
     from core.utils.adapt_lr import adjust_learning_rate
     from core.utils import utility as ref_utility
+    from core.models.discriminator import PixelDiscriminator
 
     # extra tiny architecture registered at run time (no file is modified):
     def resnet_tiny(pretrained=False, progress=True, pretrained_weights=None, **kw):
@@ -101,7 +102,7 @@ def import_reference():
 
     ref_resnet.__dict__["resnet_tiny"] = resnet_tiny
     return types.SimpleNamespace(resnet=ref_resnet, FrozenBN=FrozenBatchNorm2d, fe=resnet_feature_extractor,
-                                 ASPP=ASPP_Classifier_V2, adjust_lr=adjust_learning_rate, util=ref_utility)
+                                 ASPP=ASPP_Classifier_V2, adjust_lr=adjust_learning_rate, util=ref_utility, PixelD=PixelDiscriminator)
 
 
 # ------------------------------------------------------------------ helpers
@@ -370,6 +371,79 @@ def g_metrics(ref, out):
          strip_keys=np.array(list(sdk.keys())))
 
 
+# ------------------------------------------------------------------ G10 FADA adversarial step
+def g_fada(ref, out):
+    """reference core/models/discriminator.py:31-50 (PixelDiscriminator), core/utils/utility.py:172-177
+    (soft_label_cross_entropy) and the iteration of core/combos/aspp_fada.py:66-127, run with the reference's own classes
+    (AsppFada.train itself hard-codes .cuda(), so its body is driven from here in the same order of operations)."""
+    B, S, K = 2, 65, 19
+    fe, cls = build_ref_net(ref, "resnet_tiny")
+    D = ref.PixelD(2048, 256, num_classes=K)
+    synth.load_formula_weights(D)
+    d_keys = list(D.state_dict().keys())
+    xs, ys = synth.synth_image(B, S, S, seed=51), synth.synth_label(B, S, S, K, seed=51)
+    xt = synth.synth_image(B, S, S, seed=52)
+    # (a) discriminator forward/backward alone on a fixed feature map
+    feat = bf16(np.maximum(synth.uniform("g10.feat", (B, 2048, 9, 9)) * 2, 0))
+    ft = t(feat).requires_grad_(True)
+    dlow = D(ft)
+    soft = F.softmax(t(synth.uniform("g10.soft", (B, K, S, S)).astype(np.float32) * 6), 1)
+    soft[soft > 0.9] = 0.9
+    dup = D(ft, (S, S))
+    l0 = ref.util.soft_label_cross_entropy(dup, torch.cat((soft, torch.zeros_like(soft)), 1))
+    l0.backward()
+    grads = {k: p.grad.clone().numpy() for k, p in D.named_parameters()}
+    save(out, "g10_discriminator", d_low=dlow.detach().numpy(), loss_src_side=l0.item(), dfeat_crop=ft.grad.numpy()[:, :64], dfeat_norm=float(ft.grad.double().norm()),
+         **{"grad_" + k.replace(".", "_"): (v if v.size < 40000 else v.reshape(-1)[:4096]) for k, v in grads.items()},
+         **{"gnorm_" + k.replace(".", "_"): float(np.sqrt((v.astype(np.float64) ** 2).sum())) for k, v in grads.items()})
+    with open(os.path.join(out, "g10_discriminator_keys.json"), "w") as f:
+        json.dump(d_keys, f)
+    # (b) two full FADA iterations
+    D = ref.PixelD(2048, 256, num_classes=K)
+    synth.load_formula_weights(D)
+    opt_fea = torch.optim.SGD(fe.parameters(), lr=5e-4, momentum=0.9, weight_decay=5e-4)
+    opt_cls = torch.optim.SGD(cls.parameters(), lr=5e-3, momentum=0.9, weight_decay=5e-4)
+    opt_d = torch.optim.Adam(D.parameters(), lr=1e-4, betas=(0.9, 0.99))          # fada_adapter.py:24
+    crit = nn.CrossEntropyLoss(ignore_index=255)
+    rec = {k: [] for k in ("loss_seg", "loss_adv_tgt", "loss_D_src", "loss_D_tgt")}
+    max_iter, it = 40, 0
+    for step in range(2):
+        it += 1
+        lr = ref.adjust_lr("poly", 5e-4, it, max_iter, power=0.9)
+        lr_d = ref.adjust_lr("poly", 1e-4, it, max_iter, power=0.9)
+        for g in opt_fea.param_groups:
+            g["lr"] = lr
+        for g in opt_cls.param_groups:
+            g["lr"] = lr * 10
+        for g in opt_d.param_groups:
+            g["lr"] = lr_d
+        opt_fea.zero_grad(); opt_cls.zero_grad(); opt_d.zero_grad()
+        src_fea = fe(t(xs))
+        src_pred = cls(src_fea, (S, S)).div(1.8)
+        loss_seg = crit(src_pred, t(ys).long())
+        loss_seg.backward()
+        src_soft = F.softmax(src_pred, dim=1).detach()
+        src_soft[src_soft > 0.9] = 0.9
+        tgt_fea = fe(t(xt))
+        tgt_pred = cls(tgt_fea, (S, S)).div(1.8)
+        tgt_soft = F.softmax(tgt_pred, dim=1).detach()
+        tgt_soft[tgt_soft > 0.9] = 0.9
+        tgt_D = D(tgt_fea, (S, S))
+        loss_adv = 0.001 * ref.util.soft_label_cross_entropy(tgt_D, torch.cat((tgt_soft, torch.zeros_like(tgt_soft)), 1))
+        loss_adv.backward()
+        opt_fea.step(); opt_cls.step()
+        opt_d.zero_grad()
+        loss_ds = 0.5 * ref.util.soft_label_cross_entropy(D(src_fea.detach(), (S, S)), torch.cat((src_soft, torch.zeros_like(src_soft)), 1))
+        loss_ds.backward()
+        loss_dt = 0.5 * ref.util.soft_label_cross_entropy(D(tgt_fea.detach(), (S, S)), torch.cat((torch.zeros_like(tgt_soft), tgt_soft), 1))
+        loss_dt.backward()
+        opt_d.step()
+        for k, v in (("loss_seg", loss_seg), ("loss_adv_tgt", loss_adv), ("loss_D_src", loss_ds), ("loss_D_tgt", loss_dt)):
+            rec[k].append(v.item())
+    save(out, "g10_fada_steps", **{k: np.array(v) for k, v in rec.items()}, d_cls1_bias_after=D.cls1.bias.detach().numpy(),
+         d_param_norm_after=np.array([float(p.detach().double().norm()) for p in D.parameters()]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
@@ -382,7 +456,8 @@ def main():
     ref = import_reference()
     jobs = dict(conv=lambda: g_conv(ref, args.out), aspp=lambda: g_aspp(ref, args.out),
                 frozenbn=lambda: g_frozenbn(ref, args.out), tinynet=lambda: g_tinynet(ref, args.out),
-                r101=lambda: g_r101(ref, args.out, not args.skip_big), metrics=lambda: g_metrics(ref, args.out))
+                r101=lambda: g_r101(ref, args.out, not args.skip_big), metrics=lambda: g_metrics(ref, args.out),
+                fada=lambda: g_fada(ref, args.out))
     for name, fn in jobs.items():
         if args.only and name not in args.only.split(","):
             continue

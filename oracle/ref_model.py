@@ -174,3 +174,86 @@ def make_optimizers(fe, cls, base_lr, momentum=0.9, weight_decay=5e-4):
     """reference aspp_trainer.py:25-26."""
     return (torch.optim.SGD(fe.parameters(), lr=base_lr, momentum=momentum, weight_decay=weight_decay),
             torch.optim.SGD(cls.parameters(), lr=base_lr * 10, momentum=momentum, weight_decay=weight_decay))
+
+
+# ------------------------------------------------------------------------------------------------ FADA (SURVEY 8f, row N1)
+class RefPixelDiscriminator(nn.Module):
+    """reference core/models/discriminator.py:31-50: D = Conv3x3(C->ndf) LeakyReLU(.2) Conv3x3(ndf->ndf/2) LeakyReLU(.2);
+    cls1, cls2 = Conv3x3(ndf/2 -> K); output cat(cls1, cls2) [B,2K,h,w], optional bilinear(align_corners) upsample.
+    state_dict keys: D.0.*, D.2.*, cls1.*, cls2.*"""
+
+    def __init__(self, input_nc=2048, ndf=256, num_classes=19):
+        super().__init__()
+        self.D = _Box()
+        for idx, (o, c) in (("0", (ndf, input_nc)), ("2", (ndf // 2, ndf))):
+            box = _Box()
+            box.weight = nn.Parameter(torch.empty(o, c, 3, 3))
+            box.bias = nn.Parameter(torch.empty(o))
+            self.D.add_module(idx, box)
+        for name in ("cls1", "cls2"):
+            box = _Box()
+            box.weight = nn.Parameter(torch.empty(num_classes, ndf // 2, 3, 3))
+            box.bias = nn.Parameter(torch.empty(num_classes))
+            self.add_module(name, box)
+        for p in self.parameters():                       # nn.Conv2d default init
+            if p.dim() == 4:
+                nn.init.kaiming_uniform_(p, a=math.sqrt(5))
+            else:
+                nn.init.uniform_(p, -0.05, 0.05)
+
+    def forward(self, x, size=None):
+        d0, d2 = getattr(self.D, "0"), getattr(self.D, "2")
+        y = F.leaky_relu(F.conv2d(x, d0.weight, d0.bias, 1, 1), 0.2)
+        y = F.leaky_relu(F.conv2d(y, d2.weight, d2.bias, 1, 1), 0.2)
+        out = torch.cat((F.conv2d(y, self.cls1.weight, self.cls1.bias, 1, 1), F.conv2d(y, self.cls2.weight, self.cls2.bias, 1, 1)), 1)
+        if size is not None:
+            out = F.interpolate(out, size=size, mode="bilinear", align_corners=True)
+        return out
+
+
+def ref_soft_label_cross_entropy(pred, soft_label):
+    """reference core/utils/utility.py:172-177 (pixel_weights=None): mean over pixels of -sum_c soft * log_softmax(pred)."""
+    return torch.mean(torch.sum(-soft_label.float() * F.log_softmax(pred, dim=1), dim=1))
+
+
+def ref_fada_step(fe, cls, model_d, opt_fea, opt_cls, opt_d, src_x, src_y, tgt_x, it, max_iter, base_lr, base_lr_d, power=0.9):
+    """reference core/combos/aspp_fada.py:66-127 restated (one iteration; `it` is the already incremented iteration, :68)."""
+    lr = base_lr * ((1 - float(it) / max_iter) ** power)
+    lr_d = base_lr_d * ((1 - float(it) / max_iter) ** power)
+    for g in opt_fea.param_groups:
+        g["lr"] = lr
+    for g in opt_cls.param_groups:
+        g["lr"] = lr * 10
+    for g in opt_d.param_groups:
+        g["lr"] = lr_d
+    opt_fea.zero_grad()
+    opt_cls.zero_grad()
+    opt_d.zero_grad()
+    src_y = src_y.long()
+    src_size, tgt_size = src_x.shape[-2:], tgt_x.shape[-2:]
+    T = 1.8
+    src_fea = fe(src_x)
+    src_pred = cls(src_fea, src_size).div(T)
+    loss_seg = F.cross_entropy(src_pred, src_y, ignore_index=255)
+    loss_seg.backward()
+    src_soft = F.softmax(src_pred, dim=1).detach()
+    src_soft[src_soft > 0.9] = 0.9
+    tgt_fea = fe(tgt_x)
+    tgt_pred = cls(tgt_fea, tgt_size).div(T)
+    tgt_soft = F.softmax(tgt_pred, dim=1).detach()
+    tgt_soft[tgt_soft > 0.9] = 0.9
+    tgt_d = model_d(tgt_fea, tgt_size)
+    loss_adv_tgt = 0.001 * ref_soft_label_cross_entropy(tgt_d, torch.cat((tgt_soft, torch.zeros_like(tgt_soft)), 1))
+    loss_adv_tgt.backward()
+    opt_fea.step()
+    opt_cls.step()
+    opt_d.zero_grad()
+    src_d = model_d(src_fea.detach(), src_size)
+    loss_d_src = 0.5 * ref_soft_label_cross_entropy(src_d, torch.cat((src_soft, torch.zeros_like(src_soft)), 1))
+    loss_d_src.backward()
+    tgt_d = model_d(tgt_fea.detach(), tgt_size)
+    loss_d_tgt = 0.5 * ref_soft_label_cross_entropy(tgt_d, torch.cat((torch.zeros_like(tgt_soft), tgt_soft), 1))
+    loss_d_tgt.backward()
+    opt_d.step()
+    return dict(loss_seg=loss_seg.item(), loss_adv_tgt=loss_adv_tgt.item(), loss_D_src=loss_d_src.item(), loss_D_tgt=loss_d_tgt.item(),
+                lr=lr, lr_d=lr_d)

@@ -65,6 +65,11 @@ def formula_tensor(key, shape):
     """
     shape = tuple(int(s) for s in shape)
     u = uniform(key, shape)
+    if key.startswith(("D.", "cls1.", "cls2.")):            # PixelDiscriminator (reference core/models/discriminator.py:31-50)
+        if key.endswith(".weight"):
+            fan_in = shape[1] * shape[2] * shape[3]
+            return (u * _SQRT12 * np.sqrt(1.0 / fan_in)).astype(np.float32)
+        return (u * 0.1).astype(np.float32)
     if key.startswith("conv2d_list."):
         if key.endswith(".weight"):
             return (u * _SQRT12 * 0.01).astype(np.float32)
