@@ -43,6 +43,7 @@ extern "C" {
 #define MI_EPI_OUT_F32 16    /* store fp32 instead of bf16 */
 #define MI_EPI_ZSPLIT 32     /* fp32 store to [n/zgw][M][zgw] (ASPP tap planes) */
 #define MI_EPI_WRITE_MASK 64 /* also store sign bits of the result: bit n%16 of uint16 mask_out[m][n/16] = (v > 0)   (N % 16 == 0) */
+#define MI_EPI_LEAKY 256     /* with MI_EPI_RELU: LeakyReLU(alpha); with MI_EPI_BITMASK: its backward (v *= alpha where the bit is 0) */
 #define MI_EPI_BITMASK 128   /* like MI_EPI_MASK but `msk` points at such packed bits: 1/16 of the bytes of the bf16 tensor */
 
 /* gather modes */
@@ -76,7 +77,7 @@ int mi_conv_gemm(const void* a, const void* wp, void* out,
                  int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N,
                  int ksize, int stride, int pad, int dil, int gather_mode,
                  const float* scale, const float* bias, const void* res, const void* msk, void* mask_out,
-                 int flags, int zgw, void* stream);
+                 int flags, int zgw, float alpha, void* stream);
 
 /* ---- weight gradient (contraction over pixels), split-K with deterministic reduction ------------
  * Replaces the weight-gradient half of convolution_backward.
@@ -154,6 +155,23 @@ int mi_stem_pool_fwd(const void* y, const float* scale, const float* shift, void
                      int B, int Hc, int Wc, int C, int Hp, int Wp, void* stream);
 int mi_stem_pool_bwd(const void* dpool, const uint8_t* idx, const float* scale, void* dy,
                      int B, int Hc, int Wc, int C, int Hp, int Wp, void* stream);
+
+/* ---- FADA adversarial step (reference core/combos/aspp_fada.py:80-127) ---------------------------
+ * db[n] (+)= sum_m dy[m][n]  (conv bias gradient; dy bf16 [M][N], N % 8 == 0; fixed summation order) */
+int mi_bias_grad_bf16(const void* dy_bf16, float* db, int M, int N, int accumulate, void* stream);
+/* Fused  soft = clip(softmax(upsample(seg_low) * inv_temperature), clip);  pred = upsample(d_low)[:, :2K];
+ *        loss = mean_pixels( -sum_c soft_c * log_softmax(pred)[c + domain*K] )
+ * = soft_label_cross_entropy(model_D(fea, size), cat(soft, 0) or cat(0, soft)) of aspp_fada.py:104-121 with the soft labels
+ * of :96-103, without materialising any [B,C,H,W] tensor.  seg_low [B][h][w][K], d_low [B][h][w][ldD] (first 2K channels
+ * used), dd_low (may be NULL) = d loss / d d_low * grad_scale, same layout (padding channels zeroed).  loss_out[0] = loss,
+ * loss_out[1] = pixel count.  K <= 32, 2K <= ldD. */
+size_t mi_upsample_softce_workspace(int B, int h, int w, int K, int H, int W);
+int mi_upsample_softce(const float* seg_low, float inv_temperature, float clip, const float* d_low, int ldD, int domain,
+                       float* loss_out, float* dd_low, int B, int h, int w, int K, int H, int W, float grad_scale,
+                       void* workspace, size_t workspace_bytes, void* stream);
+/* torch.optim.Adam (no amsgrad, weight_decay 0; fada_adapter.py:24) on flat fp32 buffers; step >= 1 is this update's index */
+int mi_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2,
+                 float eps, int step, void* stream);
 
 /* ---- elementwise helpers ------------------------------------------------------------------------ */
 /* y = msk > 0 ? x : 0 (bf16, n % 8 == 0): ReLU backward across an autograd boundary.  bits != 0: `msk` is the packed

@@ -22,7 +22,7 @@ SIGNATURES = {
     "mi_pack_weight_fwd": (I, [P, P, I, I, I, P]),
     "mi_pack_weight_dgrad": (I, [P, P, P, I, I, I, P]),
     "mi_pack_weights_multi": (I, [P, P, P, P, P, I, I, P]),
-    "mi_conv_gemm": (I, [P, P, P] + [I] * 12 + [P, P, P, P, P, I, I, P]),
+    "mi_conv_gemm": (I, [P, P, P] + [I] * 12 + [P, P, P, P, P, I, I, F, P]),
     "mi_conv_wgrad_workspace": (Z, [I] * 6),
     "mi_conv_wgrad": (I, [P, P, P] + [I] * 11 + [P, I, I, P, Z, P]),
     "mi_aspp_pack_fwd": (I, [P, P, I, I, P]),
@@ -40,6 +40,10 @@ SIGNATURES = {
     "mi_upsample_softmax": (I, [P, P, P] + [I] * 6 + [P]),
     "mi_stem_pool_fwd": (I, [P, P, P, P, P] + [I] * 6 + [P]),
     "mi_stem_pool_bwd": (I, [P, P, P, P] + [I] * 6 + [P]),
+    "mi_bias_grad_bf16": (I, [P, P, I, I, I, P]),
+    "mi_upsample_softce_workspace": (Z, [I] * 6),
+    "mi_upsample_softce": (I, [P, F, F, P, I, I, P, P] + [I] * 6 + [F, P, Z, P]),
+    "mi_adam_step": (I, [P, P, P, P, Z, F, F, F, F, I, P]),
     "mi_sgd_step": (I, [P, P, P, Z, F, F, F, P]),
     "mi_relu_mask": (I, [P, P, P, Z, I, P]),
     "mi_frozen_bn_fold": (I, [P, P, P, P, P, P, I, P]),

@@ -47,6 +47,7 @@ struct IgemmParams {
     int Ho, Wo, Ha, Wa;
     int ksz, stride, pad, dil, mode;
     int flags, zgw;
+    float alpha;                  // LeakyReLU negative slope (MI_EPI_LEAKY)
     int m_tiles, n_tiles;
 };
 
@@ -278,10 +279,11 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
             }
         }
         if (flags & MI_EPI_RELU) {
+            const float neg = (flags & MI_EPI_LEAKY) ? p.alpha : 0.f;       // LeakyReLU(alpha) when MI_EPI_LEAKY is set too
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[i][e] = v[i][e] > 0.f ? v[i][e] : 0.f;
+                for (int e = 0; e < 4; ++e) v[i][e] = v[i][e] > 0.f ? v[i][e] : neg * v[i][e];
         }
         if (flags & MI_EPI_MASK) {
 #pragma unroll
@@ -297,8 +299,9 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
         if (flags & MI_EPI_BITMASK) {
             if (nb < p.N) {
                 const unsigned bits = PREF ? pbits[PREF ? j : 0] : reinterpret_cast<const uint16_t*>(p.msk)[(o >> 4)];
+                const float neg = (flags & MI_EPI_LEAKY) ? p.alpha : 0.f;   // backward of LeakyReLU: gradient x alpha where the sign bit is 0
 #pragma unroll
-                for (int c = 0; c < 16; ++c) v[c >> 2][c & 3] = ((bits >> c) & 1u) ? v[c >> 2][c & 3] : 0.f;
+                for (int c = 0; c < 16; ++c) v[c >> 2][c & 3] = ((bits >> c) & 1u) ? v[c >> 2][c & 3] : neg * v[c >> 2][c & 3];
             }
         }
         if (flags & MI_EPI_WRITE_MASK) {
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
 
 extern "C" int mi_conv_gemm(const void* a, const void* wp, void* out, int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N,
                             int ksize, int stride, int pad, int dil, int gather_mode, const float* scale, const float* bias,
-                            const void* res, const void* msk, void* mask_out, int flags, int zgw, void* stream) {
+                            const void* res, const void* msk, void* mask_out, int flags, int zgw, float alpha, void* stream) {
     MI_REQUIRE(a && wp && out, "mi_conv_gemm: null operand");
     MI_REQUIRE(B > 0 && Ha > 0 && Wa > 0 && Ho > 0 && Wo > 0 && N > 0, "mi_conv_gemm: non-positive dimension");
     MI_REQUIRE(Ca > 0 && Ca % 64 == 0, "mi_conv_gemm: Ca=%d must be a multiple of 64", Ca);
@@ -384,6 +387,7 @@ extern "C" int mi_conv_gemm(const void* a, const void* wp, void* out, int B, int
     p.mode = gather_mode;
     p.flags = flags;
     p.zgw = zgw > 0 ? zgw : 4;
+    p.alpha = alpha;
     p.n_tiles = (N + BN - 1) / BN;
     // tile height: fewer (rounds x rows) on the 512 resident workgroup slots wins; ties go to the smaller tile
     // cost ~ rounds x rows, discounted by the L2 bytes a taller tile saves per flop (the kernel is L2->LDS bound:

@@ -3,8 +3,8 @@ so the reference's own scripts / plugins (`from core.configs import cfg`,
 `from core.trainers.aspp_trainer import ASPPTrainer`, `from base.base_trainer import BaseTrainer`, ...)
 run on the MI355X engine unchanged.  Installed by the tiny top-level `core/` and `base/` packages.
 
-Only the DeepLabV2 hot path is mapped; the other model families of the reference (gald, pranet, attn, vgg,
-FADA) are out of scope and raise ImportError with that message.
+Only the DeepLabV2 hot path and its FADA adversarial step are mapped; the other model families of the
+reference (gald, pranet, attn, vgg) are out of scope and raise ImportError with that message.
 """
 import importlib
 import importlib.abc
@@ -22,6 +22,9 @@ ALIASES = {
     "core.models.classifiers.aspp.classifier": _PKG + "modules",      # core/models/classifiers/aspp/classifier.py
     "core.components.layers": _PKG + "modules",                       # core/components/layers.py:5-23
     "core.trainers.aspp_trainer": _PKG + "trainer",                   # core/trainers/aspp_trainer.py
+    "core.models.discriminator": _PKG + "fada",                       # core/models/discriminator.py:31-50 (PixelDiscriminator)
+    "core.adapters.fada_adapter": _PKG + "fada",                      # core/adapters/fada_adapter.py:6-31
+    "core.combos.aspp_fada": _PKG + "fada",                           # core/combos/aspp_fada.py:13-198
     "core.testers.aspp_tester": _PKG + "tester",                      # core/testers/aspp_tester.py
     "core.utils.utility": _PKG + "metrics",                           # core/utils/utility.py (DeepLab subset)
     "core.utils.adapt_lr": _PKG + "metrics",                          # core/utils/adapt_lr.py:12-17
@@ -29,7 +32,7 @@ ALIASES = {
     "base.base_trainer": _PKG + "plugin",                             # base/base_trainer.py
     "base.base_model": _PKG + "plugin",                               # base/base_model.py
 }
-PACKAGES = {"core.models", "core.models.classifiers", "core.models.classifiers.aspp", "core.components", "core.trainers",
+PACKAGES = {"core.models", "core.models.classifiers", "core.models.classifiers.aspp", "core.components", "core.trainers", "core.adapters", "core.combos",
             "core.testers", "core.utils", "core.datasets"}
 
 

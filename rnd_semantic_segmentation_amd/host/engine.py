@@ -384,11 +384,16 @@ class AsppLossFn(torch.autograd.Function):
     [B,K,H,W] logits.  The loss gradient w.r.t. the low-resolution logits is produced in the same pass."""
 
     @staticmethod
-    def forward(ctx, x, labels, eng, ignore_index, *params):
+    def forward(ctx, x, labels, eng, ignore_index, temperature, *params):
         train = any(ctx.needs_input_grad)
         eng.prepare(train)
         low = eng.forward(x)
-        loss_out, dlow = K.upsample_ce(low, labels, want_grad=train, ignore_index=ignore_index)
+        eng.last_low = low                   # FADA derives its soft labels from these (aspp_fada.py:85-87)
+        if temperature != 1.0:               # criterion(pred.div(T), label): bilinear upsampling commutes with the scaling
+            loss_out, dlow = K.upsample_ce(low * (1.0 / temperature), labels, want_grad=train, grad_scale=1.0 / temperature,
+                                           ignore_index=ignore_index)
+        else:
+            loss_out, dlow = K.upsample_ce(low, labels, want_grad=train, ignore_index=ignore_index)
         ctx.eng, ctx.x, ctx.dlow = eng, (x if train else None), dlow
         ctx.loss_out = loss_out
         return loss_out[0].clone()
@@ -398,7 +403,7 @@ class AsppLossFn(torch.autograd.Function):
         dlow = ctx.dlow * gout
         dx = ctx.eng.backward(ctx.x, dlow, ctx.needs_input_grad[0])
         ctx.x = ctx.dlow = None
-        return (dx, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
+        return (dx, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 5)
 
 
 class UpsampleFn(torch.autograd.Function):

@@ -180,6 +180,15 @@ def inference(feature_extractor, classifier, image, label, flip=True):
 
 
 # ----------------------------------------------------------------------------- io / logging
+def soft_label_cross_entropy(pred, soft_label, pixel_weights=None):
+    """utility.py:172-177 on materialised [N,C,H,W] tensors (API parity: AsppFada uses the fused kernel
+    `PixelDiscriminator.soft_loss`, which never builds the full-resolution operands)."""
+    loss = -soft_label.float() * torch.nn.functional.log_softmax(pred, dim=1)
+    if pixel_weights is None:
+        return torch.mean(torch.sum(loss, dim=1))
+    return torch.mean(pixel_weights * torch.sum(loss, dim=1))
+
+
 def load_json(path):
     with open(path, "r") as f:
         return json.load(f)

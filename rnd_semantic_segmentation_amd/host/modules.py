@@ -183,11 +183,15 @@ class ASPP_Classifier_V2(nn.Module):
             return engine.UpsampleFn.apply(low, tuple(int(s) for s in size))           # [B,K,H,W] fp32
         return low.permute(0, 3, 1, 2)
 
-    def loss(self, x, label, ignore_index=255):
-        """criterion(self(x, label.shape[-2:]), label) fused (never writes the upsampled logits)."""
+    def loss(self, x, label, ignore_index=255, temperature=1.0):
+        """criterion(self(x, label.shape[-2:]).div(temperature), label) fused (never writes the upsampled logits).
+        Leaves the 1/8-resolution logits [B,K,h,w] (detached) in `self.last_low`."""
         _require_gpu(x, "ASPP_Classifier_V2")
         self.ensure_flat()
-        return engine.AsppLossFn.apply(self._nhwc(x), label.long().contiguous(), self._engine, int(ignore_index), *self._params())
+        out = engine.AsppLossFn.apply(self._nhwc(x), label.long().contiguous(), self._engine, int(ignore_index), float(temperature),
+                                      *self._params())
+        self.last_low = self._engine.last_low.detach().permute(0, 3, 1, 2)
+        return out
 
     def predict_probs(self, x, size):
         """softmax(interpolate(self(x), size)) of reference utility.py:183-186 in one kernel; [B,K,H,W] fp32."""
@@ -229,4 +233,5 @@ def build_classifier(cfg):
 
 
 def build_adversarial_discriminator(cfg, num_features=None, mid_nc=256):
-    raise NotImplementedError("FADA PixelDiscriminator (train_adv.py) is SURVEY 8f row N1: next, not built yet")
+    from .fada import build_adversarial_discriminator as build
+    return build(cfg, num_features, mid_nc)

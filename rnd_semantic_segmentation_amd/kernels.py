@@ -11,7 +11,7 @@ import torch
 from . import _lib
 from ._lib import check
 
-EPI_SCALE_BIAS, EPI_RESIDUAL, EPI_RELU, EPI_MASK, EPI_OUT_F32, EPI_ZSPLIT, EPI_WRITE_MASK, EPI_BITMASK = 1, 2, 4, 8, 16, 32, 64, 128
+EPI_SCALE_BIAS, EPI_RESIDUAL, EPI_RELU, EPI_MASK, EPI_OUT_F32, EPI_ZSPLIT, EPI_WRITE_MASK, EPI_BITMASK, EPI_LEAKY = 1, 2, 4, 8, 16, 32, 64, 128, 256
 GATHER_FWD, GATHER_DGRAD = 0, 1
 ASPP_ZGW, ASPP_KPAD = 20, 704
 
@@ -77,7 +77,7 @@ def pack_weights_multi(wflat, sflat, wp, wpt, table_dev, n_desc, total_blocks):
 
 
 def conv_gemm(a, wp, out_hw, ksize=1, stride=1, pad=0, dil=1, mode=GATHER_FWD, scale=None, bias=None, res=None,
-              msk=None, relu=False, out_f32=False, zsplit=0, out=None, bits=None, mask_out=None):
+              msk=None, relu=False, out_f32=False, zsplit=0, out=None, bits=None, mask_out=None, leaky=0.0):
     """out[b,ho,wo,n] = epi(sum_{t,c} a[b,src(ho,wo,t),c] * wp[t,n,c]);  a [B,Ha,Wa,Ca] bf16, wp [k*k,N,Ca] bf16.
     msk: bf16 [B,Ho,Wo,N] ReLU mask source; bits: the same mask as packed sign bits (int16 [B,Ho,Wo,N/16]);
     mask_out: int16 [B,Ho,Wo,N/16] receiving the sign bits of the result."""
@@ -99,6 +99,8 @@ def conv_gemm(a, wp, out_hw, ksize=1, stride=1, pad=0, dil=1, mode=GATHER_FWD, s
         assert tuple(res.shape) == (B, Ho, Wo, N)
     if relu:
         flags |= EPI_RELU
+    if leaky:
+        flags |= EPI_LEAKY          # LeakyReLU(leaky) forward (with relu=True) or its backward (with bits=...)
     if msk is not None:
         flags |= EPI_MASK
         _chk(msk, torch.bfloat16, "msk")
@@ -128,7 +130,7 @@ def conv_gemm(a, wp, out_hw, ksize=1, stride=1, pad=0, dil=1, mode=GATHER_FWD, s
     flops = 2.0 * B * Ho * Wo * n_real * ca_real * ksize * ksize
     check(_timed("igemm_nt_kernel", flops, lambda: _lib.lib().mi_conv_gemm(
         _p(a), _p(wp), _p(out), B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, pad, dil, mode,
-        _p(scale), _p(bias), _p(res), _p(msk), _p(mask_out), flags, zsplit, _stream()),
+        _p(scale), _p(bias), _p(res), _p(msk), _p(mask_out), flags, zsplit, float(leaky), _stream()),
         tag=("dgrad" if mode == GATHER_DGRAD else "fwd", ksize, Ca, N, B * Ho * Wo, flags)), "mi_conv_gemm")
     return out
 
@@ -297,6 +299,39 @@ def stem_pool_bwd(dpool, idx, scale, conv_hw):
     dy = torch.empty((B, Hc, Wc, C), dtype=torch.bfloat16, device=dpool.device)
     check(_lib.lib().mi_stem_pool_bwd(_p(dpool), _p(idx), _p(scale), _p(dy), B, Hc, Wc, C, Hp, Wp, _stream()), "mi_stem_pool_bwd")
     return dy
+
+
+def bias_grad_bf16(dy, db, accumulate=False):
+    """db[n] (+)= sum over pixels of dy[..., n];  dy bf16 [B,H,W,N]"""
+    _chk(dy, torch.bfloat16, "dy")
+    _chk(db, torch.float32, "db")
+    N = dy.shape[-1]
+    check(_lib.lib().mi_bias_grad_bf16(_p(dy), _p(db), dy.numel() // N, N, int(accumulate), _stream()), "mi_bias_grad_bf16")
+    return db
+
+
+def upsample_softce(seg_low, d_low, size, domain, temperature=1.8, clip=0.9, want_grad=True, grad_scale=1.0):
+    """Fused soft-label CE of the FADA step.  seg_low [B,h,w,K] fp32 (detached), d_low [B,h,w,ldD] fp32 (first 2K used).
+    Returns (loss_out[2], dd_low or None)."""
+    _chk(seg_low, torch.float32, "seg_low")
+    _chk(d_low, torch.float32, "d_low")
+    B, h, w, Kc = seg_low.shape
+    ldD = d_low.shape[-1]
+    H, W = size
+    L = _lib.lib()
+    ws = _workspace(L.mi_upsample_softce_workspace(B, h, w, Kc, H, W), seg_low.device, "softce")
+    out = torch.empty(2, dtype=torch.float32, device=seg_low.device)
+    dd = torch.empty_like(d_low) if want_grad else None
+    check(L.mi_upsample_softce(_p(seg_low), 1.0 / float(temperature), float(clip), _p(d_low), ldD, int(domain), _p(out), _p(dd), B, h, w, Kc,
+                               H, W, float(grad_scale), _p(ws), ws.numel(), _stream()), "mi_upsample_softce")
+    return out, dd
+
+
+def adam_step(p, g, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
+    for t, n in ((p, "p"), (g, "g"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _chk(t, torch.float32, n)
+    check(_lib.lib().mi_adam_step(_p(p), _p(g), _p(exp_avg), _p(exp_avg_sq), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+                                  int(step), _stream()), "mi_adam_step")
 
 
 def sgd_step(p, g, buf, lr, momentum, weight_decay):

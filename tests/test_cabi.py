@@ -41,7 +41,7 @@ def test_library_exports_every_declared_symbol(built):
 
 
 def test_argument_validation_needs_no_gpu(built):
-    rc = built.mi_conv_gemm(None, None, None, 1, 1, 1, 64, 1, 1, 4, 1, 1, 0, 1, 0, None, None, None, None, None, 0, 0, None)
+    rc = built.mi_conv_gemm(None, None, None, 1, 1, 1, 64, 1, 1, 4, 1, 1, 0, 1, 0, None, None, None, None, None, 0, 0, 0.0, None)
     assert rc == -22 and b"null operand" in built.mi_last_error()
     assert built.mi_conv_wgrad_workspace(8, 97, 97, 256, 256, 3) > 0
     assert built.mi_upsample_ce_workspace(8, 97, 97, 19, 769, 769) >= 8 * 769 * 97 * 19 * 4
