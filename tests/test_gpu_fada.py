@@ -305,7 +305,7 @@ def test_two_fada_iterations_track_reference_losses(tmp_path, monkeypatch):
     for k in ("loss_adv_tgt", "loss_D_src", "loss_D_tgt"):
         assert np.allclose(got[k], g[k], rtol=2e-2), k
     D = combo.fada.model_D
-    norms = [float(p.double().norm()) for p in D.parameters()]
+    norms = [float(p.detach().double().norm()) for p in D.parameters()]
     assert np.allclose(norms, g["d_param_norm_after"], rtol=1e-3)
     assert rel(D.cls1.bias, g["d_cls1_bias_after"]) < 5e-2                   # Adam's sign-like first steps: lr-sized moves agree
 
@@ -326,7 +326,10 @@ def test_fused_iteration_equals_literal_iteration_on_product_modules(tmp_path, m
     for a, b in zip(ra, rb):
         for k in ("loss_seg", "loss_adv_tgt", "loss_D_src", "loss_D_tgt"):
             assert abs(float(a[k]) - float(b[k])) < 2e-3 * abs(float(b[k])), k
+    # Adam's first steps move every weight by ~lr * sign(g): entries whose gradient is within rounding distance of zero may move
+    # in opposite directions in the two schedules, so compare the bulk (mean deviation << the 2e-4 total move), not the max
     for k in da:
-        assert rel(da[k], db[k]) < 2e-3, k
+        assert float((da[k] - db[k]).abs().mean()) < 0.05 * 2e-4, k
+        assert float((da[k] - db[k]).abs().max()) <= 2.1 * 2e-4, k
     for k in fa:
         assert rel(fa[k], fb[k]) < 1e-3, k
