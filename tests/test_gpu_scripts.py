@@ -1,5 +1,5 @@
 """Drop-in scripts on the GPU: `train_src.py` (reference flags) trains DeepLabV2-R101 for a few iterations on synthetic
-crops, writes Aspp-1.pth + aspp_chart_params.json; `test.py` resumes from it and writes aspp_confusion_matrix.json."""
+crops, writes Aspp-1.pth + aspp_chart_params.json; `test.py` resumes from it and writes aspp_confusion_matrix.json; `train_adv.py` continues from it with the FADA adversarial step."""
 import json
 import os
 import subprocess
@@ -40,6 +40,20 @@ def test_train_src_then_test_py_roundtrip(tmp_path):
     cm = json.load(open(os.path.join(out, "aspp_confusion_matrix.json")))
     assert len(cm["cmt"]) == 19 and cm["classes"][0] == "road" and sum(map(sum, cm["cmt"])) > 0
     assert "Micro metric, val result: mIoU/mF1" in r.stderr + r.stdout
+    # train_adv.py (FADA) resumes from the source-only checkpoint, as the reference's workflow does; run as a single-rank RCCL job
+    # with MI_DDP_FORCE=1 so that the generator-side and discriminator-side gradient reducers issue their collectives
+    adv = str(tmp_path / "adv")
+    r = run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29541",
+             "train_adv.py", "-cfg", "configs/deeplabv2_r101_adv.yaml", "OUTPUT_DIR", adv, "SOLVER.EPOCHS", "1", "MODEL.WEIGHTS", weights,
+             "resume", os.path.join(out, "Aspp-1.pth"), "SOLVER.BATCH_SIZE", "4", "INPUT.SOURCE_INPUT_SIZE_TRAIN", "(161, 129)",
+             "INPUT.TARGET_INPUT_SIZE_TRAIN", "(129, 129)"], {"MI_SYNTH_LEN": "6", "MI_DDP_FORCE": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    chart = json.load(open(os.path.join(adv, "aspp_fada_chart_params.json")))
+    assert len(chart["segmentation loss"]) == 3 and all(0 < v < 10 for v in chart["segmentation loss"])
+    assert all(0 < v < 10 for v in chart["source discriminator loss"] + chart["target discriminator loss"])
+    ck = torch.load(os.path.join(adv, "AsppFada-1.pth"), map_location="cpu")
+    assert ck["adv_epoch"] == 1 and ck["iteration"] == 3 and len(ck["model_D"]) == 8
+    assert set(ck["optimizer_D"]["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
 
 
 def test_bench_under_torchrun_nccl_single_rank_exercises_the_reducer():
