@@ -13,8 +13,10 @@
 // to the per-lane SOURCE address and to the ds_read_b128 address (never to the destination).  Zero padding of the
 // convolution (and M / N tails) is a per-lane source pointer into a zero page - never a materialised im2col.
 // MFMA orientation: D rows = n (weights are the "A" operand), D cols = m.  The weight rows feeding MFMA tile i are
-// permuted (row rho of tile i is channel 16*(rho>>2) + 4*i + (rho&3) of the wave's 64), so that a lane ends up with
-// 16 CONTIGUOUS channels of one pixel: 4 lanes store a whole 128-B line, and residual / mask loads are 16-B wide.
+// permuted (row rho of tile i is channel 32*(i>>1) + 8*(rho>>2) + 4*(i&1) + (rho&3) of the wave's 64), so that a lane
+// (pixel = lane&15, q = lane>>4) ends up with two groups of 8 CONTIGUOUS channels, 8q.. and 32+8q..: one 16-B store /
+// residual load / mask byte per group, and the 4 lanes of a pixel cover 64 CONTIGUOUS bytes per instruction (two full
+// 32-B sectors; two instructions fill the 128-B line).
 #include "mi_common.h"
 #include <stdlib.h>
 
@@ -23,13 +25,22 @@ namespace {
 // Tile height is a template parameter: MT 16-row MFMA tiles per wave in M -> BM = 32*MT rows (128 or 160).  The
 // launcher picks the one with fewer (rounds x rows) on the 512 resident workgroup slots: at M = 75 272, N = 256 the
 // 128-row tile needs 1178 workgroups = 3 rounds, the 160-row tile 942 = 2 rounds.
-constexpr int BN = 128, BK = 64;
-constexpr int WTILE_BYTES = BN * BK * 2;         // 16 KiB weight tile
-template <int MT> struct Geo {
+// BKT (channels per K-step) is 64 for the long-K shapes and 32 for the short-K ones (K <= 512, the 1x1 convs around the 256-
+// channel bottlenecks): those spend 70 % of a workgroup's life in the prologue / epilogue latency, so they trade the
+// deeper K-step for half the LDS and 3-4 resident workgroups per CU instead of 2.
+constexpr int BN = 128;
+template <int MT, int BKT = 64> struct Geo {
     static constexpr int BM = 32 * MT;
-    static constexpr int ATILE_BYTES = BM * BK * 2;
+    static constexpr int ROWB = BKT * 2;                    // bytes of one tile row in LDS
+    static constexpr int RPP = 1024 / ROWB;                 // rows per DMA piece (one 1-KiB wave instruction)
+    static constexpr int CPR = ROWB / 16;                   // 16-B chunks per row
+    static constexpr int NPA = BM / RPP / 4;                // A pieces per wave per stage
+    static constexpr int NPW = BN / RPP / 4;                // W pieces per wave per stage
+    static constexpr int ATILE_BYTES = BM * ROWB;
+    static constexpr int WTILE_BYTES = BN * ROWB;
     static constexpr int STAGE_BYTES = ATILE_BYTES + WTILE_BYTES;
-    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;       // double buffer: 64 KiB (MT 4) / 72 KiB (MT 5) / 80 KiB (MT 6)
+    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;       // double buffer, BKT 64: 64 / 72 / 80 KiB (MT 4 / 5 / 6); BKT 32: half
+    static constexpr int OCC = BKT == 64 ? 2 : (MT <= 4 ? 4 : 3);
 };
 
 __device__ __attribute__((aligned(256))) uint32_t g_zero_page[64];   // source of every padded / out-of-range chunk
@@ -70,9 +81,14 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
 
 // PREF: the epilogue's residual rows and mask bits are requested BEFORE the main loop (they are 150-300 MB of HBM traffic
 // per launch on the 1024/2048-channel tensors) so that they land behind the MFMA work instead of after it.
-template <int MT, bool UNIT, bool PREF>
-__global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
-    constexpr int BM = Geo<MT>::BM, ATILE_BYTES = Geo<MT>::ATILE_BYTES, STAGE_BYTES = Geo<MT>::STAGE_BYTES;
+// EPI >= 0: the epilogue flag set is a compile-time constant (the four sets the ResNet bottlenecks launch 200x per step get a
+// straight-line epilogue: no per-flag branches, no dead ZSPLIT / fp32 paths); EPI < 0: flags are read from the parameters.
+template <int MT, bool UNIT, bool PREF, int BKT, int EPI>
+__global__ __launch_bounds__(256, (Geo<MT, BKT>::OCC)) void igemm_nt_kernel(IgemmParams p) {
+    using G = Geo<MT, BKT>;
+    constexpr int BM = G::BM, ATILE_BYTES = G::ATILE_BYTES, STAGE_BYTES = G::STAGE_BYTES;
+    constexpr int ROWB = G::ROWB, RPP = G::RPP, CPR = G::CPR, NPA = G::NPA, NPW = G::NPW;
+    static_assert(BM % (RPP * 4) == 0, "tile height must split into whole DMA pieces per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -81,23 +97,26 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
     const int mt = tile / p.n_tiles, nt = tile - mt * p.n_tiles;
     const int m0 = mt * BM, n0 = nt * BN;
 
-    // ---- DMA assignment: wave w moves pieces 4w..4w+3 of each operand tile; a piece = 8 rows x 128 B.
-    //      lane -> (row = piece*8 + lane>>3, physical chunk = lane&7); it fetches logical chunk physical ^ s(row).
-    const int prow = lane >> 3, pch = lane & 7;
+    // ---- DMA assignment: wave w moves pieces w*NP .. w*NP+NP-1 of each operand tile; a piece = RPP rows x ROWB bytes = 1 KiB.
+    //      lane -> (row = piece*RPP + lane/CPR, physical chunk = lane%CPR); it fetches logical chunk physical ^ s(row).
+    //      Swizzles: BKT 64: s_A(row) = row&7, s_W(row) = (row&3) | ((row>>3)&1)<<2;  BKT 32: s_A(row) = (row>>2)&3,
+    //      s_W(row) = (row>>3)&3 - chosen so that, for the rows a quarter-wave reads (A: base + f, W: the permuted rows
+    //      below), both equal the same function of the lane (f&7, resp. (f>>2)&3) and the 16 lanes hit 16 distinct slots.
+    const int prow = lane / CPR, pch = lane % CPR;
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
     // Per-row state.  UNIT (stride 1, the 100+ launches per step that matter): the source pixel of tap t is the row's own
     // pixel plus a tap offset that is THE SAME for every row, so a tap change costs a handful of VALU ops per row:
     // a 64-bit base pointer per row, one scalar byte offset per tap, and a 9-bit per-row validity mask computed once.
     // (General path, stride 2: coordinates are kept and the source recomputed per tap.)
-    int a_img[MT], a_ho[MT], a_wo[MT];
-    const char* a_base[MT];
-    unsigned a_mask[MT];
+    int a_img[NPA], a_ho[NPA], a_wo[NPA];
+    const char* a_base[NPA];
+    unsigned a_mask[NPA];
     const int HoWo = p.Ho * p.Wo;
-    const int a_chunk = (pch ^ (prow & 7)) * 16;                       // s_A(row) = row & 7
+    const int a_chunk = (pch ^ (BKT == 64 ? (prow & 7) : ((prow >> 2) & 3))) * 16;
     const int sgn = (p.mode == MI_GATHER_FWD) ? 1 : -1;                // FWD: src = out + tap*dil - pad ; DGRAD: out + pad - tap*dil
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int m = m0 + (wave * MT + i) * 8 + prow;
+    for (int i = 0; i < NPA; ++i) {
+        const int m = m0 + (wave * NPA + i) * RPP + prow;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
         const int b = mm / HoWo, rem = mm - b * HoWo;
@@ -117,21 +136,22 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
             a_mask[i] = msk;
         }
     }
-    int w_row[4], w_chunk[4];
-    const char* w_base[4];
+    int w_row[NPW], w_chunk[NPW];
+    const char* w_base[NPW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        w_row[i] = n0 + (wave * 4 + i) * 8 + prow;
-        w_chunk[i] = (pch ^ ((prow & 3) | ((i >> 1) << 2))) * 16;      // s_W(row) = (row&3) | ((row>>4)&1)<<2
+    for (int i = 0; i < NPW; ++i) {
+        const int rl = (wave * NPW + i) * RPP + prow;                   // row within the weight tile
+        w_row[i] = n0 + rl;
+        w_chunk[i] = (pch ^ (BKT == 64 ? ((rl & 3) | (((rl >> 3) & 1) << 2)) : ((rl >> 3) & 3))) * 16;
         w_base[i] = reinterpret_cast<const char*>(p.Wp + (long)(w_row[i] < p.N ? w_row[i] : 0) * p.Ca) + w_chunk[i];
     }
 
-    const int cpt = p.Ca >> 6;          // 64-channel chunks per tap
+    const int cpt = p.Ca / BKT;         // K-steps per tap
     const int nk = p.T * cpt;
     int ld_t = 0, ld_cc = 0;            // tap / chunk of the NEXT tile to stage
-    const char* a_ptr[MT];
-    const char* w_ptr[4];
-    int a_inc[MT], w_inc[4];
+    const char* a_ptr[NPA];
+    const char* w_ptr[NPW];
+    int a_inc[NPA], w_inc[NPW];
     const long w_tap_bytes = (long)p.N * p.Ca * 2;
 
     auto set_tap = [&](int t) __attribute__((always_inline)) {
@@ -139,41 +159,41 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
         if (UNIT) {
             const long toff = (long)sgn * ((long)ky * p.dil * p.Wa + (long)kx * p.dil) * p.Ca * 2;   // wave-uniform
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
+            for (int i = 0; i < NPA; ++i) {
                 const bool ok = (a_mask[i] >> t) & 1u;
                 a_ptr[i] = ok ? a_base[i] + toff : zero;
-                a_inc[i] = ok ? 128 : 0;
+                a_inc[i] = ok ? ROWB : 0;
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
+            for (int i = 0; i < NPA; ++i) {
                 int ha = 0, wa = 0;
                 const bool ok = tap_src(p, a_ho[i], a_wo[i], ky, kx, ha, wa) && a_img[i] >= 0;
                 const char* ptr = reinterpret_cast<const char*>(p.A + ((long)((ok ? a_img[i] : 0) + (ok ? ha : 0) * p.Wa + (ok ? wa : 0))) * p.Ca) + a_chunk;
                 a_ptr[i] = ok ? ptr : zero;
-                a_inc[i] = ok ? 128 : 0;
+                a_inc[i] = ok ? ROWB : 0;
             }
         }
         const long woff = (long)t * w_tap_bytes;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NPW; ++i) {
             const bool ok = w_row[i] < p.N;
             w_ptr[i] = ok ? w_base[i] + woff : zero;
-            w_inc[i] = ok ? 128 : 0;
+            w_inc[i] = ok ? ROWB : 0;
         }
     };
     set_tap(0);
 
     auto stage = [&](int buf) {
-        char* sa = smem + buf * STAGE_BYTES + wave * (MT * 1024);
-        char* sb = smem + buf * STAGE_BYTES + ATILE_BYTES + wave * 4096;
+        char* sa = smem + buf * STAGE_BYTES + wave * (NPA * 1024);
+        char* sb = smem + buf * STAGE_BYTES + ATILE_BYTES + wave * (NPW * 1024);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
+        for (int i = 0; i < NPA; ++i) {
             glds16(a_ptr[i], sa + i * 1024);
             a_ptr[i] += a_inc[i];
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NPW; ++i) {
             glds16(w_ptr[i], sb + i * 1024);
             w_ptr[i] += w_inc[i];
         }
@@ -192,33 +212,44 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
         for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fq = lane >> 4;
-    const int wrow0 = wn * 64 + 16 * (frow >> 2) + (frow & 3);          // + 4*i : permuted weight row of MFMA tile i
-    bf16x8 pres[PREF ? MT : 1][2];
-    unsigned pbits[PREF ? MT : 1];
-    if (PREF) {
-        const int nbp = n0 + wn * 64 + 16 * fq;
+    const int wrow0 = wn * 64 + 8 * (frow >> 2) + (frow & 3);           // + 32*(i>>1) + 4*(i&1): permuted weight row of MFMA tile i
+    const int flags = EPI >= 0 ? EPI : p.flags;
+    // The epilogue's residual rows and ReLU sign bits (150-300 MB of HBM traffic per launch on the 1024/2048-channel tensors) are
+    // fetched as ONE batch of independent loads per lane: before the main loop (PREF: they land behind the MFMA work) or right
+    // after it (registers of the operand fragments are free then).  Left inside the per-row loop they would be serialised
+    // behind the stores (out / res may alias as far as the compiler knows): one HBM round trip per 16 rows.
+    bf16x8 pres[MT][2];
+    unsigned pbits[MT];
+    auto fetch_epilogue_operands = [&]() __attribute__((always_inline)) {
+        const int nbp = n0 + wn * 64 + 8 * fq;
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
             const int m = m0 + wm * (MT * 16) + j * 16 + frow;
-            const long o = (long)(m < p.M ? m : 0) * p.N + (nbp < p.N ? nbp : 0);
-            if (p.flags & MI_EPI_RESIDUAL) {
-                pres[j][0] = *reinterpret_cast<const bf16x8*>(p.res + o);
-                pres[j][1] = *reinterpret_cast<const bf16x8*>(p.res + o + 8);
+            const long o0 = (long)(m < p.M ? m : 0) * p.N + (nbp < p.N ? nbp : 0);
+            const long o1 = (long)(m < p.M ? m : 0) * p.N + (nbp + 32 < p.N ? nbp + 32 : 0);
+            if (flags & MI_EPI_RESIDUAL) {
+                pres[j][0] = *reinterpret_cast<const bf16x8*>(p.res + o0);
+                pres[j][1] = *reinterpret_cast<const bf16x8*>(p.res + o1);
             }
-            if (p.flags & MI_EPI_BITMASK) pbits[j] = reinterpret_cast<const uint16_t*>(p.msk)[o >> 4];
+            if (flags & MI_EPI_BITMASK) {
+                const uint8_t* mb = reinterpret_cast<const uint8_t*>(p.msk);
+                pbits[j] = (unsigned)mb[o0 >> 3] | ((unsigned)mb[o1 >> 3] << 8);
+            }
         }
-    }
+    };
+    if (PREF) fetch_epilogue_operands();
     auto compute = [&](int buf) {
         const char* sa = smem + buf * STAGE_BYTES;
         const char* sb = sa + ATILE_BYTES;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int sw = (((kk * 4 + fq) ^ (frow & 7)) << 4);         // same expression for both operands (see header)
+        for (int kk = 0; kk < BKT / 32; ++kk) {
+            // same expression for both operands (see the swizzle note above)
+            const int sw = BKT == 64 ? (((kk * 4 + fq) ^ (frow & 7)) << 4) : ((fq ^ ((frow >> 2) & 3)) << 4);
             bf16x8 wf[4], af[MT];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sb + (wrow0 + 4 * i) * 128 + sw);
+            for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sb + (wrow0 + 32 * (i >> 1) + 4 * (i & 1)) * ROWB + sw);
 #pragma unroll
-            for (int j = 0; j < MT; ++j) af[j] = *reinterpret_cast<const bf16x8*>(sa + (wm * (MT * 16) + j * 16 + frow) * 128 + sw);
+            for (int j = 0; j < MT; ++j) af[j] = *reinterpret_cast<const bf16x8*>(sa + (wm * (MT * 16) + j * 16 + frow) * ROWB + sw);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -237,21 +268,23 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
         __syncthreads();
     }
 
-    if (p.flags & (1 << 30)) {   // perf experiment: main loop only (keeps the accumulators alive, stores nothing)
+    if (EPI < 0 && (p.flags & (1 << 30))) {   // perf experiment: main loop only (keeps the accumulators alive, stores nothing)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < MT; ++j) asm volatile("" ::"v"(acc[i][j]));
         return;
     }
-    // ---- epilogue: lane owns pixel m (D col) and the 16 contiguous channels nb .. nb+15 (4 per MFMA tile i) -------
-    const int flags = p.flags;
-    const int nb = n0 + wn * 64 + 16 * fq;
+    // ---- epilogue: lane owns pixel m (D col) and two groups of 8 contiguous channels: h = 0 -> nb .. nb+7 (MFMA tiles 0, 1),
+    //      h = 1 -> nb+32 .. nb+39 (tiles 2, 3); tile i holds channels nb + 32*(i>>1) + 4*(i&1) + (0..3) ------------------------
+    const int nb = n0 + wn * 64 + 8 * fq;
+    if (!PREF) fetch_epilogue_operands();
     f32x4 esc[4], ebi[4];               // FrozenBN scale / shift of this lane's 16 channels: loaded once, not per pixel
     if (flags & MI_EPI_SCALE_BIAS) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int n = (nb + 4 * i < p.N) ? nb + 4 * i : 0;
+            const int ni = nb + 32 * (i >> 1) + 4 * (i & 1);
+            const int n = (ni < p.N) ? ni : 0;
             esc[i] = *reinterpret_cast<const f32x4*>(p.scale + n);
             ebi[i] = *reinterpret_cast<const f32x4*>(p.bias + n);
         }
@@ -260,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
     for (int j = 0; j < MT; ++j) {
         const int m = m0 + wm * (MT * 16) + j * 16 + frow;
         if (m >= p.M) continue;
-        const long o = (long)m * p.N + nb;
+        const long o = (long)m * p.N + nb;       // group h starts at o + 32*h
         f32x4 v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = acc[i][j];
@@ -271,25 +304,31 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
         if (flags & MI_EPI_RESIDUAL) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                if (nb + 8 * h < p.N) {
-                    const bf16x8 r = PREF ? pres[PREF ? j : 0][h] : *reinterpret_cast<const bf16x8*>(p.res + o + 8 * h);
+                if (nb + 32 * h < p.N) {
+                    const bf16x8 r = pres[j][h];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[2 * h + (e >> 2)][e & 3] += (float)r[e];
                 }
             }
         }
         if (flags & MI_EPI_RELU) {
-            const float neg = (flags & MI_EPI_LEAKY) ? p.alpha : 0.f;       // LeakyReLU(alpha) when MI_EPI_LEAKY is set too
+            if (flags & MI_EPI_LEAKY) {                                     // LeakyReLU(alpha)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[i][e] = v[i][e] > 0.f ? v[i][e] : neg * v[i][e];
+                    for (int e = 0; e < 4; ++e) v[i][e] = v[i][e] > 0.f ? v[i][e] : p.alpha * v[i][e];
+            } else {                                                        // one v_max_f32 per value; the result is never -0
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) asm("v_max_f32 %0, 0, %1" : "=v"(v[i][e]) : "v"(v[i][e]));   // fmaxf() costs two (canonicalize)
+            }
         }
         if (flags & MI_EPI_MASK) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                if (nb + 8 * h < p.N) {
-                    const bf16x8 k = *reinterpret_cast<const bf16x8*>(p.msk + o + 8 * h);
+                if (nb + 32 * h < p.N) {
+                    const bf16x8 k = *reinterpret_cast<const bf16x8*>(p.msk + o + 32 * h);
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
                         v[2 * h + (e >> 2)][e & 3] = ((float)k[e] > 0.f) ? v[2 * h + (e >> 2)][e & 3] : 0.f;
@@ -297,25 +336,47 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
             }
         }
         if (flags & MI_EPI_BITMASK) {
-            if (nb < p.N) {
-                const unsigned bits = PREF ? pbits[PREF ? j : 0] : reinterpret_cast<const uint16_t*>(p.msk)[(o >> 4)];
-                const float neg = (flags & MI_EPI_LEAKY) ? p.alpha : 0.f;   // backward of LeakyReLU: gradient x alpha where the sign bit is 0
+            // the packed sign bits are addressed as bytes here: bit c%8 of byte c/8 == bit c%16 of the uint16 word c/16
+            const float neg = (flags & MI_EPI_LEAKY) ? p.alpha : 0.f;       // backward of LeakyReLU: gradient x alpha where the sign bit is 0
 #pragma unroll
-                for (int c = 0; c < 16; ++c) v[c >> 2][c & 3] = ((bits >> c) & 1u) ? v[c >> 2][c & 3] : neg * v[c >> 2][c & 3];
+            for (int h = 0; h < 2; ++h) {
+                if (nb + 32 * h < p.N) {
+                    const unsigned bits = (pbits[j] >> (8 * h)) & 0xffu;
+                    if (flags & MI_EPI_LEAKY) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) v[2 * h + (c >> 2)][c & 3] = ((bits >> c) & 1u) ? v[2 * h + (c >> 2)][c & 3] : neg * v[2 * h + (c >> 2)][c & 3];
+                    } else {      // two ops per value: sign-extend bit c to a word mask (v_bfe_i32), AND it onto the float
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            const unsigned keep = (unsigned)__builtin_amdgcn_sbfe((int)bits, c, 1);
+                            v[2 * h + (c >> 2)][c & 3] = __uint_as_float(__float_as_uint(v[2 * h + (c >> 2)][c & 3]) & keep);
+                        }
+                    }
+                }
             }
         }
         if (flags & MI_EPI_WRITE_MASK) {
-            if (nb < p.N) {
-                unsigned bits = 0;
 #pragma unroll
-                for (int c = 0; c < 16; ++c) bits |= (v[c >> 2][c & 3] > 0.f ? 1u : 0u) << c;
-                p.mask_out[o >> 4] = (uint16_t)bits;
+            for (int h = 0; h < 2; ++h) {
+                if (nb + 32 * h < p.N) {
+                    unsigned bits = 0;
+                    if ((flags & MI_EPI_RELU) && !(flags & MI_EPI_LEAKY)) {
+                        // after ReLU every value is >= +0, so (v > 0) == (bits of v != 0) == sign of (0 - bits): two ops per value,
+                        // v_sub_u32 and v_alignbit_b32 (shift the collected bits left by one and append that sign)
+#pragma unroll
+                        for (int c = 7; c >= 0; --c) bits = __builtin_amdgcn_alignbit(bits, 0u - __float_as_uint(v[2 * h + (c >> 2)][c & 3]), 31);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) bits |= (v[2 * h + (c >> 2)][c & 3] > 0.f ? 1u : 0u) << c;
+                    }
+                    reinterpret_cast<uint8_t*>(p.mask_out)[(o + 32 * h) >> 3] = (uint8_t)bits;
+                }
             }
         }
         if (flags & MI_EPI_ZSPLIT) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int n = nb + 4 * i;
+                const int n = nb + 32 * (i >> 1) + 4 * (i & 1);
                 if (n < p.N) {
                     const int g = n / p.zgw, nn = n - g * p.zgw;
                     *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + ((long)g * p.M + m) * p.zgw + nn) = v[i];
@@ -323,20 +384,46 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_kernel(IgemmParams p) {
             }
         } else if (flags & MI_EPI_OUT_F32) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (nb + 4 * i < p.N) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o + 4 * i) = v[i];
+            for (int i = 0; i < 4; ++i) {
+                const int n = nb + 32 * (i >> 1) + 4 * (i & 1);
+                if (n < p.N) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (long)m * p.N + n) = v[i];
+            }
         } else {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                if (nb + 8 * h < p.N) {
+                if (nb + 32 * h < p.N) {
                     bf16x8 hv;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) hv[e] = (__bf16)v[2 * h + (e >> 2)][e & 3];
-                    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.out) + o + 8 * h) = hv;
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.out) + o + 32 * h) = hv;
                 }
             }
         }
     }
+}
+
+template <int MT, bool UNIT, bool PREF, int BKT, int EPI>
+void launch_one(dim3 grid, hipStream_t stream, const IgemmParams& p) {
+    static bool attr_done = false;
+    auto kern = igemm_nt_kernel<MT, UNIT, PREF, BKT, EPI>;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (Geo<MT, BKT>::LDS_BYTES));
+        attr_done = true;
+    }
+    constexpr int lds = Geo<MT, BKT>::LDS_BYTES;
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
+}
+
+// hot epilogue sets: 69 = FrozenBN + ReLU + sign bits (conv1 / conv2 forward), 71 = the same + residual (conv3 forward),
+// 128 = ReLU-backward from sign bits (data gradients), 130 = the same + residual-gradient add (conv1 data gradient)
+template <int MT, bool UNIT, bool PREF, int BKT>
+void launch_variant(dim3 grid, hipStream_t stream, const IgemmParams& p) {
+    const int fl = p.flags;
+    if (UNIT && !PREF && fl == 69) return launch_one<MT, UNIT, PREF, BKT, 69>(grid, stream, p);
+    if (UNIT && !PREF && fl == 128) return launch_one<MT, UNIT, PREF, BKT, 128>(grid, stream, p);
+    if (UNIT && fl == 71) return launch_one<MT, UNIT, PREF, BKT, 71>(grid, stream, p);
+    if (UNIT && fl == 130) return launch_one<MT, UNIT, PREF, BKT, 130>(grid, stream, p);
+    launch_one<MT, UNIT, PREF, BKT, -1>(grid, stream, p);
 }
 
 }  // namespace
@@ -389,56 +476,60 @@ extern "C" int mi_conv_gemm(const void* a, const void* wp, void* out, int B, int
     p.zgw = zgw > 0 ? zgw : 4;
     p.alpha = alpha;
     p.n_tiles = (N + BN - 1) / BN;
-    // tile height: fewer (rounds x rows) on the 512 resident workgroup slots wins; ties go to the smaller tile
-    // cost ~ rounds x rows, discounted by the L2 bytes a taller tile saves per flop (the kernel is L2->LDS bound:
-    // bytes per K-step ~ (bm + 128) for bm*128 outputs)
-    auto cost = [&](int bm) {
-        const long tiles = ((M + bm - 1) / bm) * p.n_tiles;
-        return (double)(((tiles + 511) / 512) * bm) * (0.5 + 0.5 * (double)(bm + 128) / (2.0 * bm));
-    };
-    int mt_sel = 4;
-    if (cost(160) < cost(128) * 0.999) mt_sel = 5;
-    if (cost(192) < cost(mt_sel * 32) * 0.999) mt_sel = 6;
-    static int force_mt = -1;
+    const bool unit = stride == 1 && Ha == Ho && Wa == Wo && ksize * ksize <= 9;
+    static int force_mt = -1, force_bk = -1, pref_on = -1;
     if (force_mt < 0) {
         const char* e = getenv("MI_IGEMM_MT");
         force_mt = e ? atoi(e) : 0;
-    }
-    if (force_mt >= 4 && force_mt <= 6) mt_sel = force_mt;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<4, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<4>::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<5, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<5>::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<6, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<6>::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<4>::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<5, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<5>::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<4, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<4>::LDS_BYTES);
-        attr_set = true;
-    }
-    const bool unit = stride == 1 && Ha == Ho && Wa == Wo && ksize * ksize <= 9;
-    static int pref_on = -1;
-    if (pref_on < 0) {
-        const char* e = getenv("MI_IGEMM_PREF");
+        e = getenv("MI_IGEMM_BK");
+        force_bk = e ? atoi(e) : 0;
+        e = getenv("MI_IGEMM_PREF");
         pref_on = e ? atoi(e) : 1;
     }
-    const bool pref = pref_on && unit && (flags & MI_EPI_RESIDUAL) && N % 16 == 0;
+    // 32-channel K-steps (half the LDS, 3-4 resident workgroups per CU): measured equal or slower than the 64-channel variant on
+    // every shape of this network (the short-K 1x1 convs are bound by HBM/L2 traffic, not by per-workgroup latency), so it is
+    // only selected on request (MI_IGEMM_BK=32, experiments)
+    const bool short_k = unit && force_bk == 32;
+    // tile height: fewer (rounds x rows) on the resident workgroup slots wins; ties go to the smaller tile
+    // cost ~ rounds x rows, discounted by the L2 bytes a taller tile saves per flop (the kernel is L2->LDS bound:
+    // bytes per K-step ~ (bm + 128) for bm*128 outputs)
+    auto cost = [&](int bm, int slots) {
+        const long tiles = ((M + bm - 1) / bm) * p.n_tiles;
+        return (double)(((tiles + slots - 1) / slots) * bm) * (0.5 + 0.5 * (double)(bm + 128) / (2.0 * bm)) * 512.0 / slots;
+    };
+    int mt_sel = 4;
+    if (short_k) {
+        if (cost(192, 768) < cost(128, 1024) * 0.999) mt_sel = 6;
+        if (force_mt == 4 || force_mt == 6) mt_sel = force_mt;
+    } else {
+        if (cost(160, 512) < cost(128, 512) * 0.999) mt_sel = 5;
+        if (cost(192, 512) < cost(mt_sel * 32, 512) * 0.999) mt_sel = 6;
+        if (force_mt >= 4 && force_mt <= 6) mt_sel = force_mt;
+    }
+    const bool pref = !short_k && pref_on && unit && (flags & MI_EPI_RESIDUAL) && N % 16 == 0;
     if (!unit) mt_sel = 4;                               // the general (strided) gather exists in the 128-row shape only
     if (pref && mt_sel == 6) mt_sel = 5;                 // the prefetched rows cost 8 VGPRs per 16-row MFMA tile
     const int bm = mt_sel * 32;
     p.m_tiles = (int)((M + bm - 1) / bm);
     const dim3 grid(p.m_tiles * p.n_tiles);
+#define MI_LAUNCH(MT_, UNIT_, PREF_, BK_) launch_variant<MT_, UNIT_, PREF_, BK_>(grid, (hipStream_t)stream, p)
     if (!unit)
-        hipLaunchKernelGGL((igemm_nt_kernel<4, false, false>), grid, dim3(256), Geo<4>::LDS_BYTES, (hipStream_t)stream, p);
+        MI_LAUNCH(4, false, false, 64);
+    else if (short_k && mt_sel == 6)
+        MI_LAUNCH(6, true, false, 32);
+    else if (short_k)
+        MI_LAUNCH(4, true, false, 32);
     else if (pref && mt_sel == 5)
-        hipLaunchKernelGGL((igemm_nt_kernel<5, true, true>), grid, dim3(256), Geo<5>::LDS_BYTES, (hipStream_t)stream, p);
+        MI_LAUNCH(5, true, true, 64);
     else if (pref)
-        hipLaunchKernelGGL((igemm_nt_kernel<4, true, true>), grid, dim3(256), Geo<4>::LDS_BYTES, (hipStream_t)stream, p);
+        MI_LAUNCH(4, true, true, 64);
     else if (mt_sel == 6)
-        hipLaunchKernelGGL((igemm_nt_kernel<6, true, false>), grid, dim3(256), Geo<6>::LDS_BYTES, (hipStream_t)stream, p);
+        MI_LAUNCH(6, true, false, 64);
     else if (mt_sel == 5)
-        hipLaunchKernelGGL((igemm_nt_kernel<5, true, false>), grid, dim3(256), Geo<5>::LDS_BYTES, (hipStream_t)stream, p);
+        MI_LAUNCH(5, true, false, 64);
     else
-        hipLaunchKernelGGL((igemm_nt_kernel<4, true, false>), grid, dim3(256), Geo<4>::LDS_BYTES, (hipStream_t)stream, p);
+        MI_LAUNCH(4, true, false, 64);
+#undef MI_LAUNCH
     MI_CHECK_LAUNCH("mi_conv_gemm");
     return MI_OK;
 }
