@@ -22,25 +22,29 @@
 
 namespace {
 
-// Tile height is a template parameter: MT 16-row MFMA tiles per wave in M -> BM = 32*MT rows (128 or 160).  The
-// launcher picks the one with fewer (rounds x rows) on the 512 resident workgroup slots: at M = 75 272, N = 256 the
-// 128-row tile needs 1178 workgroups = 3 rounds, the 160-row tile 942 = 2 rounds.
-// BKT (channels per K-step) is 64 for the long-K shapes and 32 for the short-K ones (K <= 512, the 1x1 convs around the 256-
-// channel bottlenecks): those spend 70 % of a workgroup's life in the prologue / epilogue latency, so they trade the
-// deeper K-step for half the LDS and 3-4 resident workgroups per CU instead of 2.
-constexpr int BN = 128;
-template <int MT, int BKT = 64> struct Geo {
-    static constexpr int BM = 32 * MT;
+// Tile shape is a template parameter: MT 16-row MFMA tiles per wave in M and a 2 x NWN wave grid, each wave owning 16*MT x 64
+// outputs -> block tile BM = 32*MT rows x BNT = 64*NWN columns:
+//   NWN 2: 4 waves, 128/160/192 x 128, two workgroups per CU;
+//   NWN 4: 8 waves, 128/160/192 x 256, one workgroup per CU - 30 % fewer L2 bytes per FLOP, but slower with this loop structure
+//          (see the launcher); opt-in with MI_IGEMM_BN=256.
+// The launcher picks the shape with the lowest modelled time: rounds on the resident-workgroup slots x per-step tile time
+// (L2 bytes (BM+BNT)*128 at the per-CU L2 rate vs MFMA time) - at M = 75 272 the 160-row tiles waste the least of the last round.
+// BKT (channels per K-step) is 64; a 32-channel variant (half the LDS, 3-4 workgroups per CU) compiles from the same template
+// and measured equal or slower on every shape (the short-K convs are bound by L2/HBM traffic, not per-workgroup latency).
+template <int MT, int BKT = 64, int NWN = 2> struct Geo {
+    static constexpr int NW = 2 * NWN;                      // waves per workgroup
+    static constexpr int BM = 32 * MT, BNT = 64 * NWN;
     static constexpr int ROWB = BKT * 2;                    // bytes of one tile row in LDS
     static constexpr int RPP = 1024 / ROWB;                 // rows per DMA piece (one 1-KiB wave instruction)
     static constexpr int CPR = ROWB / 16;                   // 16-B chunks per row
-    static constexpr int NPA = BM / RPP / 4;                // A pieces per wave per stage
-    static constexpr int NPW = BN / RPP / 4;                // W pieces per wave per stage
+    static constexpr int PA = BM / RPP;                     // A pieces per stage; wave w moves PA/NW of them (+1 for w < PA%NW)
+    static constexpr int NPA = (PA + NW - 1) / NW;
+    static constexpr int NPW = BNT / RPP / NW;              // W pieces per wave per stage
     static constexpr int ATILE_BYTES = BM * ROWB;
-    static constexpr int WTILE_BYTES = BN * ROWB;
+    static constexpr int WTILE_BYTES = BNT * ROWB;
     static constexpr int STAGE_BYTES = ATILE_BYTES + WTILE_BYTES;
-    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;       // double buffer, BKT 64: 64 / 72 / 80 KiB (MT 4 / 5 / 6); BKT 32: half
-    static constexpr int OCC = BKT == 64 ? 2 : (MT <= 4 ? 4 : 3);
+    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;       // double buffer; NWN 2: 64 / 72 / 80 KiB (MT 4 / 5 / 6), NWN 4: 96 / 104 / 112 KiB
+    static constexpr int OCC = NWN == 4 ? 1 : (BKT == 64 ? 2 : (MT <= 4 ? 4 : 3));
 };
 
 __device__ __attribute__((aligned(256))) uint32_t g_zero_page[64];   // source of every padded / out-of-range chunk
@@ -83,12 +87,12 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
 // per launch on the 1024/2048-channel tensors) so that they land behind the MFMA work instead of after it.
 // EPI >= 0: the epilogue flag set is a compile-time constant (the four sets the ResNet bottlenecks launch 200x per step get a
 // straight-line epilogue: no per-flag branches, no dead ZSPLIT / fp32 paths); EPI < 0: flags are read from the parameters.
-template <int MT, bool UNIT, bool PREF, int BKT, int EPI>
-__global__ __launch_bounds__(256, (Geo<MT, BKT>::OCC)) void igemm_nt_kernel(IgemmParams p) {
-    using G = Geo<MT, BKT>;
-    constexpr int BM = G::BM, ATILE_BYTES = G::ATILE_BYTES, STAGE_BYTES = G::STAGE_BYTES;
-    constexpr int ROWB = G::ROWB, RPP = G::RPP, CPR = G::CPR, NPA = G::NPA, NPW = G::NPW;
-    static_assert(BM % (RPP * 4) == 0, "tile height must split into whole DMA pieces per wave");
+template <int MT, bool UNIT, bool PREF, int BKT, int EPI, int NWN>
+__global__ __launch_bounds__((Geo<MT, BKT, NWN>::NW * 64), (Geo<MT, BKT, NWN>::OCC)) void igemm_nt_kernel(IgemmParams p) {
+    using G = Geo<MT, BKT, NWN>;
+    constexpr int BM = G::BM, BN = G::BNT, ATILE_BYTES = G::ATILE_BYTES, STAGE_BYTES = G::STAGE_BYTES;
+    constexpr int ROWB = G::ROWB, RPP = G::RPP, CPR = G::CPR, NPA = G::NPA, NPW = G::NPW, NW = G::NW;
+    static_assert(BM % RPP == 0 && BN % (RPP * NW) == 0, "tiles must split into whole DMA pieces");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -113,11 +117,14 @@ __global__ __launch_bounds__(256, (Geo<MT, BKT>::OCC)) void igemm_nt_kernel(Igem
     unsigned a_mask[NPA];
     const int HoWo = p.Ho * p.Wo;
     const int a_chunk = (pch ^ (BKT == 64 ? (prow & 7) : ((prow >> 2) & 3))) * 16;
+    constexpr int PA_BASE = G::PA / NW, PA_REM = G::PA % NW;
+    const int a_first = wave * PA_BASE + (wave < PA_REM ? wave : PA_REM);      // first A piece of this wave
+    const int a_count = PA_BASE + (wave < PA_REM ? 1 : 0);                     // wave-uniform
     const int sgn = (p.mode == MI_GATHER_FWD) ? 1 : -1;                // FWD: src = out + tap*dil - pad ; DGRAD: out + pad - tap*dil
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
-        const int m = m0 + (wave * NPA + i) * RPP + prow;
-        const bool ok = m < p.M;
+        const int m = m0 + (a_first + i) * RPP + prow;
+        const bool ok = (m < p.M) & (i < a_count);
         const int mm = ok ? m : 0;
         const int b = mm / HoWo, rem = mm - b * HoWo;
         const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
@@ -185,11 +192,11 @@ __global__ __launch_bounds__(256, (Geo<MT, BKT>::OCC)) void igemm_nt_kernel(Igem
     set_tap(0);
 
     auto stage = [&](int buf) {
-        char* sa = smem + buf * STAGE_BYTES + wave * (NPA * 1024);
+        char* sa = smem + buf * STAGE_BYTES + a_first * 1024;
         char* sb = smem + buf * STAGE_BYTES + ATILE_BYTES + wave * (NPW * 1024);
 #pragma unroll
         for (int i = 0; i < NPA; ++i) {
-            glds16(a_ptr[i], sa + i * 1024);
+            if (PA_REM == 0 || i < a_count) glds16(a_ptr[i], sa + i * 1024);
             a_ptr[i] += a_inc[i];
         }
 #pragma unroll
@@ -402,28 +409,32 @@ __global__ __launch_bounds__(256, (Geo<MT, BKT>::OCC)) void igemm_nt_kernel(Igem
     }
 }
 
-template <int MT, bool UNIT, bool PREF, int BKT, int EPI>
+template <int MT, bool UNIT, bool PREF, int BKT, int EPI, int NWN>
 void launch_one(dim3 grid, hipStream_t stream, const IgemmParams& p) {
     static bool attr_done = false;
-    auto kern = igemm_nt_kernel<MT, UNIT, PREF, BKT, EPI>;
+    auto kern = igemm_nt_kernel<MT, UNIT, PREF, BKT, EPI, NWN>;
+    constexpr int lds = Geo<MT, BKT, NWN>::LDS_BYTES;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (Geo<MT, BKT>::LDS_BYTES));
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    constexpr int lds = Geo<MT, BKT>::LDS_BYTES;
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(kern, grid, dim3(Geo<MT, BKT, NWN>::NW * 64), lds, stream, p);
 }
 
 // hot epilogue sets: 69 = FrozenBN + ReLU + sign bits (conv1 / conv2 forward), 71 = the same + residual (conv3 forward),
 // 128 = ReLU-backward from sign bits (data gradients), 130 = the same + residual-gradient add (conv1 data gradient)
-template <int MT, bool UNIT, bool PREF, int BKT>
+template <int MT, bool UNIT, bool PREF, int BKT, int NWN>
 void launch_variant(dim3 grid, hipStream_t stream, const IgemmParams& p) {
     const int fl = p.flags;
-    if (UNIT && !PREF && fl == 69) return launch_one<MT, UNIT, PREF, BKT, 69>(grid, stream, p);
-    if (UNIT && !PREF && fl == 128) return launch_one<MT, UNIT, PREF, BKT, 128>(grid, stream, p);
-    if (UNIT && fl == 71) return launch_one<MT, UNIT, PREF, BKT, 71>(grid, stream, p);
-    if (UNIT && fl == 130) return launch_one<MT, UNIT, PREF, BKT, 130>(grid, stream, p);
-    launch_one<MT, UNIT, PREF, BKT, -1>(grid, stream, p);
+    if constexpr (UNIT) {
+        if constexpr (!PREF) {
+            if (fl == 69) return launch_one<MT, UNIT, PREF, BKT, 69, NWN>(grid, stream, p);
+            if (fl == 128) return launch_one<MT, UNIT, PREF, BKT, 128, NWN>(grid, stream, p);
+        }
+        if (fl == 71) return launch_one<MT, UNIT, PREF, BKT, 71, NWN>(grid, stream, p);
+        if (fl == 130) return launch_one<MT, UNIT, PREF, BKT, 130, NWN>(grid, stream, p);
+    }
+    launch_one<MT, UNIT, PREF, BKT, -1, NWN>(grid, stream, p);
 }
 
 }  // namespace
@@ -475,61 +486,69 @@ extern "C" int mi_conv_gemm(const void* a, const void* wp, void* out, int B, int
     p.flags = flags;
     p.zgw = zgw > 0 ? zgw : 4;
     p.alpha = alpha;
-    p.n_tiles = (N + BN - 1) / BN;
     const bool unit = stride == 1 && Ha == Ho && Wa == Wo && ksize * ksize <= 9;
-    static int force_mt = -1, force_bk = -1, pref_on = -1;
+    static int force_mt = -1, force_bn = -1, pref_on = -1;
     if (force_mt < 0) {
         const char* e = getenv("MI_IGEMM_MT");
         force_mt = e ? atoi(e) : 0;
-        e = getenv("MI_IGEMM_BK");
-        force_bk = e ? atoi(e) : 0;
+        e = getenv("MI_IGEMM_BN");
+        force_bn = e ? atoi(e) : 0;
         e = getenv("MI_IGEMM_PREF");
         pref_on = e ? atoi(e) : 1;
     }
-    // 32-channel K-steps (half the LDS, 3-4 resident workgroups per CU): measured equal or slower than the 64-channel variant on
-    // every shape of this network (the short-K 1x1 convs are bound by HBM/L2 traffic, not by per-workgroup latency), so it is
-    // only selected on request (MI_IGEMM_BK=32, experiments)
-    const bool short_k = unit && force_bk == 32;
-    // tile height: fewer (rounds x rows) on the resident workgroup slots wins; ties go to the smaller tile
-    // cost ~ rounds x rows, discounted by the L2 bytes a taller tile saves per flop (the kernel is L2->LDS bound:
-    // bytes per K-step ~ (bm + 128) for bm*128 outputs)
-    auto cost = [&](int bm, int slots) {
-        const long tiles = ((M + bm - 1) / bm) * p.n_tiles;
-        return (double)(((tiles + slots - 1) / slots) * bm) * (0.5 + 0.5 * (double)(bm + 128) / (2.0 * bm)) * 512.0 / slots;
+    // Modelled time of one launch with tile bm x bn: rounds on the resident-workgroup slots x workgroups sharing a CU x per-K-step
+    // tile time, where a CU's share of the L2 request rate serves (bm+bn)*128 B per step (~47.6 GB/s per CU measured) and its
+    // MFMA pipes need bm*bn*128 FLOP at ~9.8 TFLOP/s per CU; the two overlap imperfectly (20 % of the shorter one is exposed).
+    auto cost = [&](int bm, int bn) {
+        const int per_cu = bn == 256 ? 1 : 2;
+        const long tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+        const long rounds = (tiles + 256 * per_cu - 1) / (256 * per_cu);
+        const double t_l2 = (bm + bn) * 128.0 / 47.6e3, t_mfma = bm * (double)bn * 128.0 / 9.77e6;      // microseconds
+        return rounds * per_cu * ((t_l2 > t_mfma ? t_l2 : t_mfma) + 0.2 * (t_l2 > t_mfma ? t_mfma : t_l2));
     };
-    int mt_sel = 4;
-    if (short_k) {
-        if (cost(192, 768) < cost(128, 1024) * 0.999) mt_sel = 6;
-        if (force_mt == 4 || force_mt == 6) mt_sel = force_mt;
-    } else {
-        if (cost(160, 512) < cost(128, 512) * 0.999) mt_sel = 5;
-        if (cost(192, 512) < cost(mt_sel * 32, 512) * 0.999) mt_sel = 6;
-        if (force_mt >= 4 && force_mt <= 6) mt_sel = force_mt;
+    // The 256-wide tile is selectable (MI_IGEMM_BN=256) but not the default: with this loop structure (one barrier and a full
+    // vmcnt(0) drain per K-step) it measured 2-8 % slower than the 128-wide tiles on every shape of the network (bench 216 vs
+    // 223.5 images/s) although it moves 30 % fewer L2 bytes - the single resident workgroup has nothing to overlap its drains
+    // with.  It is the geometry a deeper-pipelined schedule (counted vmcnt, prefetch in flight across barriers) needs.
+    const bool wide_ok = unit && N % 256 == 0 && !(flags & MI_EPI_ZSPLIT) && force_bn == 256;
+    int mt_sel = 4, bn = 128;
+    double best = cost(128, 128);
+    for (int mt = 5; mt <= 6; ++mt)
+        if (cost(32 * mt, 128) < best * 0.999) best = cost(32 * mt, 128), mt_sel = mt;
+    if (force_mt >= 4 && force_mt <= 6) mt_sel = force_mt, best = cost(32 * mt_sel, 128);
+    if (wide_ok) {
+        int wmt = 0;
+        double wbest = force_bn == 256 ? 1e30 : best;
+        for (int mt = 4; mt <= 6; ++mt)
+            if ((force_mt == 0 || force_mt == mt) && cost(32 * mt, 256) < wbest * 0.999) wbest = cost(32 * mt, 256), wmt = mt;
+        if (wmt) mt_sel = wmt, bn = 256;
     }
-    const bool pref = !short_k && pref_on && unit && (flags & MI_EPI_RESIDUAL) && N % 16 == 0;
+    const bool pref = bn == 128 && pref_on && unit && (flags & MI_EPI_RESIDUAL) && N % 16 == 0;
     if (!unit) mt_sel = 4;                               // the general (strided) gather exists in the 128-row shape only
     if (pref && mt_sel == 6) mt_sel = 5;                 // the prefetched rows cost 8 VGPRs per 16-row MFMA tile
     const int bm = mt_sel * 32;
     p.m_tiles = (int)((M + bm - 1) / bm);
+    p.n_tiles = (N + bn - 1) / bn;
     const dim3 grid(p.m_tiles * p.n_tiles);
-#define MI_LAUNCH(MT_, UNIT_, PREF_, BK_) launch_variant<MT_, UNIT_, PREF_, BK_>(grid, (hipStream_t)stream, p)
+    const hipStream_t st = (hipStream_t)stream;
     if (!unit)
-        MI_LAUNCH(4, false, false, 64);
-    else if (short_k && mt_sel == 6)
-        MI_LAUNCH(6, true, false, 32);
-    else if (short_k)
-        MI_LAUNCH(4, true, false, 32);
+        launch_variant<4, false, false, 64, 2>(grid, st, p);
+    else if (bn == 256 && mt_sel == 6)
+        launch_variant<6, true, false, 64, 4>(grid, st, p);
+    else if (bn == 256 && mt_sel == 5)
+        launch_variant<5, true, false, 64, 4>(grid, st, p);
+    else if (bn == 256)
+        launch_variant<4, true, false, 64, 4>(grid, st, p);
     else if (pref && mt_sel == 5)
-        MI_LAUNCH(5, true, true, 64);
+        launch_variant<5, true, true, 64, 2>(grid, st, p);
     else if (pref)
-        MI_LAUNCH(4, true, true, 64);
+        launch_variant<4, true, true, 64, 2>(grid, st, p);
     else if (mt_sel == 6)
-        MI_LAUNCH(6, true, false, 64);
+        launch_variant<6, true, false, 64, 2>(grid, st, p);
     else if (mt_sel == 5)
-        MI_LAUNCH(5, true, false, 64);
+        launch_variant<5, true, false, 64, 2>(grid, st, p);
     else
-        MI_LAUNCH(4, true, false, 64);
-#undef MI_LAUNCH
+        launch_variant<4, true, false, 64, 2>(grid, st, p);
     MI_CHECK_LAUNCH("mi_conv_gemm");
     return MI_OK;
 }

@@ -8,9 +8,9 @@ L = _lib.lib()
 P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def run(ci, co, label, res=True):
+def run(ci, co, label, res=True, k=1, d=1):
     x = torch.randn((B, H, H, ci), device='cuda').to(torch.bfloat16)
-    w = torch.randn((co, ci, 1, 1), device='cuda') * 0.05
+    w = torch.randn((co, ci, k, k), device='cuda') * 0.05
     wp = K.pack_weight_fwd(w)
     out = torch.empty((B, H, H, co), device='cuda', dtype=torch.bfloat16)
     r = torch.randn((B, H, H, co), device='cuda').to(torch.bfloat16)
@@ -23,12 +23,15 @@ def run(ci, co, label, res=True):
     cases += [(1 | 4 | 64, 'no-res')] if res else []
     cases += [(1 << 30, 'nostore')]
     for fl, name in cases:
-        f = lambda: L.mi_conv_gemm(P(x), P(wp), P(out), B, H, H, ci, H, H, co, 1, 1, 0, 1, 0, P(sc), P(sh), P(r), None, P(bits), fl, 0,
+        f = lambda: L.mi_conv_gemm(P(x), P(wp), P(out), B, H, H, ci, H, H, co, k, 1, d if k == 3 else 0, d, 0, P(sc), P(sh), P(r), None, P(bits), fl, 0,
                                    ctypes.c_float(0.0), st)
         t = timeit(f, 30)
-        print('%-16s %-8s MT=%s %7.1f us  %6.0f TF  %5.2f TB/s(min traffic)' % (label, name, os.environ.get("MI_IGEMM_MT", "auto"), t * 1e6,
-              2.0 * B * H * H * ci * co / t / 1e12, by_min / t / 1e12))
+        print('%-16s %-8s MT=%s %7.1f us  %6.0f TF  %5.2f TB/s(min traffic)' % (label, name, os.environ.get("MI_IGEMM_MT", "auto") + "/" + os.environ.get("MI_IGEMM_BN", "auto"), t * 1e6,
+              2.0 * B * H * H * ci * co * k * k / t / 1e12, by_min / t / 1e12))
 
 
 run(256, 1024, '1x1 256->1024')
 run(1024, 256, '1x1 1024->256', res=False)
+run(256, 256, '3x3 256 d2', res=False, k=3, d=2)
+run(512, 512, '3x3 512 d4', res=False, k=3, d=4)
+run(512, 2048, '1x1 512->2048')
