@@ -14,6 +14,9 @@ reduction.  Weight gradients are written by the wgrad reduce kernel straight int
 parameter's `.grad` (a view of one flat fp32 buffer per module -> fused SGD and bucketed RCCL
 all-reduce work on contiguous ranges).  No tensor of the schedule ever visits the CPU.
 """
+import contextlib
+import os
+
 import torch
 
 from .. import kernels as K
@@ -80,6 +83,52 @@ def grad_slot(p):
         p.grad = torch.empty_like(p, memory_format=torch.contiguous_format)
         return p.grad, False
     return p.grad, True
+
+
+# ------------------------------------------------------------------------------------------------ weight-gradient stream
+class _SideStream:
+    """Weight gradients are off the backward critical path (nothing consumes them before the optimizer / all-reduce), so they
+    run on a second HIP stream: their workgroups fill the CUs that the data-gradient kernels leave idle in their last partial
+    round (tile quantisation costs 10-25 % of a launch at M = 75 272), and the small slab reducers hide entirely.
+    MI_WGRAD_STREAM=0 puts everything back on one stream."""
+    _by_device = {}
+
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device)
+        self.dirty = False
+
+    @classmethod
+    def get(cls, device):
+        if os.environ.get("MI_WGRAD_STREAM", "1") == "0" or device.type != "cuda":
+            return None
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        if key not in cls._by_device:
+            cls._by_device[key] = cls(torch.device("cuda", key))
+        return cls._by_device[key]
+
+    def run(self, fn, *inputs):
+        """fn() on the side stream after everything enqueued so far on the current stream; `inputs` are the tensors it reads
+        (their memory must not be recycled by the allocator before the side stream is done with them)."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.stream.wait_event(ev)
+        with torch.cuda.stream(self.stream):
+            fn()
+        for t in inputs:
+            t.record_stream(self.stream)
+        self.dirty = True
+
+    def join(self):
+        if self.dirty:
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self.dirty = False
+
+
+def _off_path(side, fn, *inputs):
+    if side is None:
+        fn()
+    else:
+        side.run(fn, *inputs)
 
 
 # ------------------------------------------------------------------------------------------------ backbone stages
@@ -214,19 +263,20 @@ class StageEngine:
         """dfeat: d loss / d feat (bf16 NHWC); fbits: sign bits of feat.  Returns d loss / d x of the first block."""
         g = K.relu_mask(dfeat, fbits)                     # through the last block's ReLU
         store = getattr(self.convs[0].weight, "_mi_store", None)
+        side = _SideStream.get(dfeat.device)
         for bi in range(len(self.blocks) - 1, -1, -1):
             blk, rts = self.blocks[bi]
             x, a1, a2, xb, b1, b2 = saved[bi]
             first = bi == 0
             hw_in = (x.shape[1], x.shape[2])
             hw_mid = (a1.shape[1], a1.shape[2])
-            self._wgrad(g, a2, rts[2])
+            _off_path(side, lambda: self._wgrad(g, a2, rts[2]), g, a2)
             ga2 = self._dgrad(g, rts[2], (a2.shape[1], a2.shape[2]), bits=b2)
-            self._wgrad(ga2, a1, rts[1])
+            _off_path(side, lambda: self._wgrad(ga2, a1, rts[1]), ga2, a1)
             ga1 = self._dgrad(ga2, rts[1], hw_mid, bits=b1)
-            self._wgrad(ga1, x, rts[0])
+            _off_path(side, lambda: self._wgrad(ga1, x, rts[0]), ga1, x)
             if blk.down:
-                self._wgrad(g, x, rts[3])
+                _off_path(side, lambda: self._wgrad(g, x, rts[3]), g, x)
             if first and not need_dx:
                 g = None
             else:
@@ -235,8 +285,11 @@ class StageEngine:
             saved[bi] = None                              # release activations as we go
             if store is not None and store.grad_hooks:
                 lo, hi = store.span([rt.weight for rt in rts])
-                for hook in store.grad_hooks:
-                    hook(store, lo, hi)
+                with torch.cuda.stream(side.stream) if side is not None else contextlib.nullcontext():
+                    for hook in store.grad_hooks:         # the all-reduce of this range is ordered after its weight gradients
+                        hook(store, lo, hi)
+        if side is not None:
+            side.join()                                   # the optimizer / caller sees complete gradients on its own stream
         return g
 
 
@@ -331,34 +384,41 @@ class AsppEngine:
         g = K.aspp_im2col(dlow, self.rates)
         w4, ws = self._w4()
         b4, bs = self._b4()
-        slots = [grad_slot(p) for p in ws]
-        n = ws[0].numel()
-        base = slots[0][0].data_ptr()
-        stacked = all(s[0].data_ptr() == base + 4 * n * i for i, s in enumerate(slots)) and len({s[1] for s in slots}) == 1
-        if stacked:
-            dw4 = torch.as_strided(slots[0][0], (4,) + tuple(ws[0].shape), (n,) + tuple(ws[0].stride()))
-            K.conv_wgrad(g, x, dw4, out_map=1, accumulate=slots[0][1])
-        else:
-            dw4 = torch.empty((4,) + tuple(ws[0].shape), dtype=torch.float32, device=x.device)
-            K.conv_wgrad(g, x, dw4, out_map=1)
-            for i, (slot, acc) in enumerate(slots):
-                slot.add_(dw4[i]) if acc else slot.copy_(dw4[i])
-        bslots = [grad_slot(p) for p in bs]
-        bbase = bslots[0][0].data_ptr()
-        if all(s[0].data_ptr() == bbase + 4 * self.K * i for i, s in enumerate(bslots)) and len({s[1] for s in bslots}) == 1:
-            K.aspp_bias_grad(dlow, torch.as_strided(bslots[0][0], (4, self.K), (self.K, 1)), accumulate=bslots[0][1])
-        else:
-            db4 = torch.empty((4, self.K), dtype=torch.float32, device=x.device)
-            K.aspp_bias_grad(dlow, db4)
-            for i, (slot, acc) in enumerate(bslots):
-                slot.add_(db4[i]) if acc else slot.copy_(db4[i])
+        side = _SideStream.get(x.device)
+
+        def weight_and_bias_grads():
+            slots = [grad_slot(p) for p in ws]
+            n = ws[0].numel()
+            base = slots[0][0].data_ptr()
+            stacked = all(s[0].data_ptr() == base + 4 * n * i for i, s in enumerate(slots)) and len({s[1] for s in slots}) == 1
+            if stacked:
+                dw4 = torch.as_strided(slots[0][0], (4,) + tuple(ws[0].shape), (n,) + tuple(ws[0].stride()))
+                K.conv_wgrad(g, x, dw4, out_map=1, accumulate=slots[0][1])
+            else:
+                dw4 = torch.empty((4,) + tuple(ws[0].shape), dtype=torch.float32, device=x.device)
+                K.conv_wgrad(g, x, dw4, out_map=1)
+                for i, (slot, acc) in enumerate(slots):
+                    slot.add_(dw4[i]) if acc else slot.copy_(dw4[i])
+            bslots = [grad_slot(p) for p in bs]
+            bbase = bslots[0][0].data_ptr()
+            if all(s[0].data_ptr() == bbase + 4 * self.K * i for i, s in enumerate(bslots)) and len({s[1] for s in bslots}) == 1:
+                K.aspp_bias_grad(dlow, torch.as_strided(bslots[0][0], (4, self.K), (self.K, 1)), accumulate=bslots[0][1])
+            else:
+                db4 = torch.empty((4, self.K), dtype=torch.float32, device=x.device)
+                K.aspp_bias_grad(dlow, db4)
+                for i, (slot, acc) in enumerate(bslots):
+                    slot.add_(db4[i]) if acc else slot.copy_(db4[i])
+
+        # off the critical path: runs beside the data-gradient GEMM below; joined right after it is enqueued
+        _off_path(side, weight_and_bias_grads, g, x, dlow)
+        dx = K.conv_gemm(g, self.wallT, (h, w), msk=msk) if need_dx else None
+        if side is not None:
+            side.join()
         store = getattr(ws[0], "_mi_store", None)
         if store is not None and store.grad_hooks:
             for hook in store.grad_hooks:
                 hook(store, 0, store.total)
-        if not need_dx:
-            return None
-        return K.conv_gemm(g, self.wallT, (h, w), msk=msk)
+        return dx
 
 
 class AsppFn(torch.autograd.Function):

@@ -85,7 +85,9 @@ class _DiscEngine:
         hw = (x.shape[1], x.shape[2])
         g = ddlow.to(torch.bfloat16).contiguous()
         k = ps[4].shape[0]
-        if need_wgrad:
+        side = engine._SideStream.get(x.device) if need_wgrad else None      # weight gradients beside the data-gradient chain
+
+        def head_grads():
             dwc = torch.empty((NPAD,) + tuple(ps[4].shape[1:]), dtype=torch.float32, device=x.device)
             K.conv_wgrad(g, a2, dwc, 3, 1, 1, 1)
             dbc = torch.empty(NPAD, dtype=torch.float32, device=x.device)
@@ -93,19 +95,25 @@ class _DiscEngine:
             for p, val in ((ps[4], dwc[:k]), (ps[5], dbc[:k]), (ps[6], dwc[k:2 * k]), (ps[7], dbc[k:2 * k])):
                 slot, acc = engine.grad_slot(p)
                 slot.add_(val) if acc else slot.copy_(val)
+
+        def conv_grads(dy, xin, pw, pb):
+            slot, acc = engine.grad_slot(pw)
+            K.conv_wgrad(dy, xin, slot, 3, 1, 1, 1, accumulate=acc)
+            slot, acc = engine.grad_slot(pb)
+            K.bias_grad_bf16(dy, slot, accumulate=acc)
+
+        if need_wgrad:
+            engine._off_path(side, head_grads, g, a2)
         ga2 = K.conv_gemm(g, P["wct"], hw, 3, 1, 1, 1, K.GATHER_DGRAD, bits=m2, leaky=LEAK)
         if need_wgrad:
-            slot, acc = engine.grad_slot(ps[2])
-            K.conv_wgrad(ga2, a1, slot, 3, 1, 1, 1, accumulate=acc)
-            slot, acc = engine.grad_slot(ps[3])
-            K.bias_grad_bf16(ga2, slot, accumulate=acc)
+            engine._off_path(side, lambda: conv_grads(ga2, a1, ps[2], ps[3]), ga2, a1)
         ga1 = K.conv_gemm(ga2, P["w2t"], hw, 3, 1, 1, 1, K.GATHER_DGRAD, bits=m1, leaky=LEAK)
         if need_wgrad:
-            slot, acc = engine.grad_slot(ps[0])
-            K.conv_wgrad(ga1, x, slot, 3, 1, 1, 1, accumulate=acc)
-            slot, acc = engine.grad_slot(ps[1])
-            K.bias_grad_bf16(ga1, slot, accumulate=acc)
-        return K.conv_gemm(ga1, P["w1t"], hw, 3, 1, 1, 1, K.GATHER_DGRAD) if need_dx else None
+            engine._off_path(side, lambda: conv_grads(ga1, x, ps[0], ps[1]), ga1, x)
+        dx = K.conv_gemm(ga1, P["w1t"], hw, 3, 1, 1, 1, K.GATHER_DGRAD) if need_dx else None
+        if side is not None:
+            side.join()
+        return dx
 
 
 class _DiscFn(torch.autograd.Function):

@@ -139,7 +139,8 @@ _ws_cache = {}
 
 
 def _workspace(nbytes, device, tag="ws"):
-    key = (tag, str(device))
+    # one buffer per (purpose, device, stream): launches on one stream are ordered, so they can share it; two streams cannot
+    key = (tag, str(device), torch.cuda.current_stream().cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
