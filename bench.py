@@ -140,7 +140,8 @@ def main():
     events = [] if not args.no_kernel_events else None
     t0 = time.perf_counter()
     for i in range(args.steps):
-        # per-launch HIP events cost ~6 % of a step, so only every 4th timed step is instrumented
+        # per-launch HIP events cost ~6 % of a step, so only every 4th timed step is instrumented; an instrumented step also keeps the
+        # weight-gradient launches on the main stream (host/engine.py _SideStream) so that each event pair times one kernel alone
         kernels.PROFILE = events if (events is not None and i % 4 == 0) else None
         loss = step()
     kernels.PROFILE = None
@@ -193,7 +194,9 @@ def main():
                                "unit": "TFLOP/s", "frac": round(fl / tsec / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                                "launches_per_step": n // inst_steps, "avg_launch_us": round(1e6 * tsec / n, 2),
                                "alg_gflop_per_launch": round(fl / n / 1e9, 3), "ms_per_step_in_kernel": round(1e3 * tsec / inst_steps, 3),
-                               "instrumented_steps": inst_steps}
+                               "instrumented_steps": inst_steps,
+                               "note": "per-launch durations from the instrumented steps, which run single-stream; the other timed steps "
+                                       "overlap weight-gradient launches with the data-gradient chain on a second HIP stream"}
             out["kernels"] = {k: {"ms_per_step": round(1e3 * v[0] / inst_steps, 3), "tflops": round(v[1] / v[0] / 1e12, 2),
                                   "launches_per_step": v[2] // inst_steps} for k, v in by.items()}
         if events and os.environ.get("MI_BENCH_SHAPES"):

@@ -101,6 +101,8 @@ class _SideStream:
     def get(cls, device):
         if os.environ.get("MI_WGRAD_STREAM", "1") == "0" or device.type != "cuda":
             return None
+        if K.PROFILE is not None:      # per-launch timing requested (bench.py's instrumented steps): one stream, so that a
+            return None                # launch's event-to-event time is that kernel's alone
         key = device.index if device.index is not None else torch.cuda.current_device()
         if key not in cls._by_device:
             cls._by_device[key] = cls(torch.device("cuda", key))
