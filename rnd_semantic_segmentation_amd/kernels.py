@@ -124,6 +124,9 @@ def conv_gemm(a, wp, out_hw, ksize=1, stride=1, pad=0, dil=1, mode=GATHER_FWD, s
             out = torch.empty((B, Ho, Wo, N), dtype=torch.float32, device=a.device)
     elif out is None:
         out = torch.empty((B, Ho, Wo, N), dtype=torch.bfloat16, device=a.device)
+    _chk(out, torch.float32 if (zsplit or out_f32) else torch.bfloat16, "out")
+    if out.numel() != B * Ho * Wo * N:
+        raise _lib.MiError("out has %d elements, the conv writes %d" % (out.numel(), B * Ho * Wo * N))
     # algorithmic FLOPs (2 * pixels * C_out * C_in * k^2), padding columns of the ASPP operands excluded
     n_real = N * 19 // 20 if zsplit else N
     ca_real = 684 if Ca == ASPP_KPAD else Ca
