@@ -140,9 +140,9 @@ def main():
     events = [] if not args.no_kernel_events else None
     t0 = time.perf_counter()
     for i in range(args.steps):
-        # per-launch HIP events cost ~6 % of a step, so only every 4th timed step is instrumented; an instrumented step also keeps the
+        # per-launch HIP events cost ~6 % of a step, so only every 8th timed step is instrumented; an instrumented step also keeps the
         # weight-gradient launches on the main stream (host/engine.py _SideStream) so that each event pair times one kernel alone
-        kernels.PROFILE = events if (events is not None and i % 4 == 0) else None
+        kernels.PROFILE = events if (events is not None and i % 8 == 0) else None
         loss = step()
     kernels.PROFILE = None
     torch.cuda.synchronize()
@@ -171,7 +171,7 @@ def main():
             "whole_step_mfma_frac": round(ALG_GFLOP_PER_IMAGE * 1e9 * (args.size / 769.0) ** 2 * value / (PEAK_BF16_TFLOPS * 1e12 * world), 4),
         }
         if events:
-            inst_steps = (args.steps + 3) // 4
+            inst_steps = (args.steps + 7) // 8
             by = {}
             shapes = {}
             for name, e0, e1, flops, tag in events:

@@ -121,26 +121,57 @@ __global__ __launch_bounds__((Geo<MT, BKT, NWN>::NW * 64), (Geo<MT, BKT, NWN>::O
     const int a_first = wave * PA_BASE + (wave < PA_REM ? wave : PA_REM);      // first A piece of this wave
     const int a_count = PA_BASE + (wave < PA_REM ? 1 : 0);                     // wave-uniform
     const int sgn = (p.mode == MI_GATHER_FWD) ? 1 : -1;                // FWD: src = out + tap*dil - pad ; DGRAD: out + pad - tap*dil
+    // Pixel coordinates: a 1x1 conv needs none (the source row IS the output row); otherwise ONE pair of integer divisions per
+    // lane for its first row, the following rows (RPP pixels further each) are stepped incrementally.
+    const bool pointwise = UNIT && p.T == 1 && p.pad == 0;             // workgroup-uniform
+    int cb_ = 0, cho = 0, cwo = 0;
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
         const int m = m0 + (a_first + i) * RPP + prow;
         const bool ok = (m < p.M) & (i < a_count);
-        const int mm = ok ? m : 0;
-        const int b = mm / HoWo, rem = mm - b * HoWo;
-        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        if (pointwise) {
+            a_base[i] = reinterpret_cast<const char*>(p.A + (long)(ok ? m : 0) * p.Ca) + a_chunk;
+            a_mask[i] = ok ? 1u : 0u;
+            a_ho[i] = a_wo[i] = 0;
+            a_img[i] = -1;
+            continue;
+        }
+        if (!UNIT || i == 0) {
+            const int mm = ok ? m : 0;
+            cb_ = mm / HoWo;
+            const int rem = mm - cb_ * HoWo;
+            cho = rem / p.Wo;
+            cwo = rem - cho * p.Wo;
+        } else {
+            cwo += RPP;
+            while (cwo >= p.Wo) {
+                cwo -= p.Wo;
+                ++cho;
+            }
+            while (cho >= p.Ho) {
+                cho -= p.Ho;
+                ++cb_;
+            }
+        }
+        const int b = cb_, ho = cho, wo = cwo;
         a_ho[i] = ho;
         a_wo[i] = wo;
         a_img[i] = ok ? b * p.Ha * p.Wa : -1;
         if (UNIT) {
             const int h0 = ho - sgn * p.pad, w0 = wo - sgn * p.pad;   // tap (0,0) source; Ha == Ho, Wa == Wo here
             a_base[i] = reinterpret_cast<const char*>(p.A + ((long)b * p.Ha * p.Wa + (long)h0 * p.Wa + w0) * p.Ca) + a_chunk;
-            unsigned msk = 0;
-            for (int t = 0; t < p.T; ++t) {
-                const int ky = t / p.ksz, kx = t - ky * p.ksz;
-                const int hs = h0 + sgn * ky * p.dil, ws = w0 + sgn * kx * p.dil;
-                msk |= (unsigned)(ok & ((unsigned)hs < (unsigned)p.Ha) & ((unsigned)ws < (unsigned)p.Wa)) << t;
+            // validity of tap (ky, kx) is separable: 3 row bits x 3 column bits, no loop over taps (ksz is 1 or 3 here)
+            unsigned rb = 0, cb = 0;
+#pragma unroll
+            for (int kq = 0; kq < 3; ++kq) {
+                const bool live = kq < p.ksz;
+                rb |= (unsigned)(live & ((unsigned)(h0 + sgn * kq * p.dil) < (unsigned)p.Ha)) << kq;
+                cb |= (unsigned)(live & ((unsigned)(w0 + sgn * kq * p.dil) < (unsigned)p.Wa)) << kq;
             }
-            a_mask[i] = msk;
+            unsigned msk;
+            if (p.ksz == 1) msk = rb & cb & 1u;                                    // bit t = ky*ksz + kx
+            else msk = ((rb & 1u) ? cb : 0u) | ((rb & 2u) ? cb << 3 : 0u) | ((rb & 4u) ? cb << 6 : 0u);
+            a_mask[i] = ok ? msk : 0u;
         }
     }
     int w_row[NPW], w_chunk[NPW];
