@@ -183,15 +183,21 @@ __global__ void ce_bwd_kernel(const float* __restrict__ logits, const int64_t* _
 // their column support in ascending x:  tmp[b][y][j][k] = sum_x wx(x,j) d[x][k].
 constexpr int JT = 32;
 
+// KT > 0: the class count is a compile-time constant (19 for Cityscapes: exact-length register loops instead of 32 predicated
+// iterations); KT == 0: K is read from the arguments.
+template <int KT>
 __global__ __launch_bounds__(256) void upce_pass1_kernel(const float* __restrict__ low, const int64_t* __restrict__ labels,
-                                                         float* __restrict__ partial, float* __restrict__ tmp, int B, int K, Axis ay,
+                                                         float* __restrict__ partial, float* __restrict__ tmp, int B, int Krt, Axis ay,
                                                          Axis ax, int ignore_index, int npx_max) {
+    const int K = KT > 0 ? KT : Krt;
+    constexpr int KR = KT > 0 ? KT : KMAX;          // register array length
     extern __shared__ __attribute__((aligned(16))) float sh[];
     float* dbuf = sh;                               // [npx_max][K]
     float* lam = sh + (long)npx_max * K;            // [npx_max]  lambda_x
     int* x0s = reinterpret_cast<int*>(lam + npx_max);  // [npx_max]  x0
     float* red = reinterpret_cast<float*>(x0s + npx_max);  // [512]
-    float* vrow = red + 512;                        // [JT+2][K] low-res row already interpolated along y
+    int* pstart = reinterpret_cast<int*>(red + 512);   // [JT+3] first pixel (relative to xa) whose x0 >= j0 - 1 + q
+    float* vrow = red + 512 + JT + 4;                // [JT+2][K] low-res row already interpolated along y
     const int H = ay.n_out, W = ax.n_out, h = ay.n_in, w = ax.n_in;
     const int jt = blockIdx.x, y = blockIdx.y, b = blockIdx.z;
     const int j0 = jt * JT, j1 = min(w, j0 + JT);
@@ -203,6 +209,7 @@ __global__ __launch_bounds__(256) void upce_pass1_kernel(const float* __restrict
     const float* row0 = low + ((long)b * h + y0) * w * K;
     const float* row1 = low + ((long)b * h + y1) * w * K;
     const int cbase = max(j0 - 1, 0), ncol = min(j1, w - 1) - cbase + 1;          // source columns this tile touches
+    if (threadIdx.x < j1 - j0 + 2) pstart[threadIdx.x] = ax.first_with_i0_ge(j0 - 1 + (int)threadIdx.x) - xa;
     for (int e = threadIdx.x; e < ncol * K; e += 256) {
         const long o = (long)cbase * K + e;
         vrow[e] = (1.f - ly) * row0[o] + ly * row1[o];
@@ -215,7 +222,6 @@ __global__ __launch_bounds__(256) void upce_pass1_kernel(const float* __restrict
         float lx;
         ax.src(x, x0, x1, lx);
         lam[px] = lx;
-        x0s[px] = x0;
         const long lab = labels[((long)b * H + y) * W + x];
         float* d = dbuf + (long)px * K;
         if (lab == ignore_index || lab < 0 || lab >= K) {
@@ -224,10 +230,10 @@ __global__ __launch_bounds__(256) void upce_pass1_kernel(const float* __restrict
         }
         const float* c0 = vrow + (x0 - cbase) * K;
         const float* c1 = vrow + (x1 - cbase) * K;
-        float v[KMAX];
+        float v[KR];
         float mx = -3.0e38f;
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
+        for (int k = 0; k < KR; ++k) {
             if (k < K) {
                 v[k] = (1.f - lx) * c0[k] + lx * c1[k];
                 mx = fmaxf(mx, v[k]);
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(256) void upce_pass1_kernel(const float* __restrict
         }
         float se = 0.f;
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
+        for (int k = 0; k < KR; ++k) {
             if (k < K) {
                 v[k] = __expf(v[k] - mx);
                 se += v[k];
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(256) void upce_pass1_kernel(const float* __restrict
         const float rse = 1.f / se;
         float picked = 0.f;
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
+        for (int k = 0; k < KR; ++k) {
             if (k < K) {
                 if (k == lab) picked = v[k];
                 d[k] = v[k] * rse - (k == lab ? 1.f : 0.f);
@@ -262,14 +268,12 @@ __global__ __launch_bounds__(256) void upce_pass1_kernel(const float* __restrict
             const int jj = item / K, k = item - jj * K;
             const int j = j0 + jj;
             float s = 0.f;
-            // pixels with x0 == j-1 (contribute lam to j as x1) then x0 == j (contribute 1-lam; and lam too when x1 == x0 == j)
-            const int pa = ax.first_with_i0_ge(j - 1) - xa, pb = ax.first_with_i0_ge(j + 1) - xa;
-            for (int px = max(pa, 0); px < min(pb, npx); ++px) {
-                const int x0 = x0s[px];
-                const int x1 = (x0 < w - 1) ? x0 + 1 : x0;
-                const float wgt = (x0 == j ? 1.f - lam[px] : 0.f) + (x1 == j ? lam[px] : 0.f);
-                s += wgt * dbuf[(long)px * K + k];
-            }
+            // pixels with x0 == j-1 contribute lam to j (as x1), then pixels with x0 == j contribute 1-lam (and lam too when x1 is
+            // clamped onto j at the right edge); same weights and the same ascending-x order as a per-pixel test of x0 / x1
+            const int p0 = max(pstart[jj], 0), p1 = min(max(pstart[jj + 1], 0), npx), p2 = min(pstart[jj + 2], npx);
+            for (int px = p0; px < p1; ++px) s += (0.f + lam[px]) * dbuf[(long)px * K + k];
+            const bool edge = j == w - 1;
+            for (int px = p1; px < p2; ++px) s += ((1.f - lam[px]) + (edge ? lam[px] : 0.f)) * dbuf[(long)px * K + k];
             tmp[(((long)b * H + y) * w + j) * K + k] = s;
         }
     }
@@ -417,15 +421,20 @@ extern "C" int mi_upsample_ce(const float* low, const int64_t* labels, float* lo
     const size_t poff = (((size_t)B * H * tiles * 2 * sizeof(float)) + 255) & ~(size_t)255;
     float* tmp = dlow ? (float*)((char*)workspace + poff) : nullptr;
     const int npx_max = pass1_npx_max(ax);
-    const size_t lds = (size_t)npx_max * K * 4 + (size_t)npx_max * 8 + 512 * 4 + (size_t)(JT + 2) * K * 4;
+    const size_t lds = (size_t)npx_max * K * 4 + (size_t)npx_max * 8 + 512 * 4 + (JT + 4) * 4 + (size_t)(JT + 2) * K * 4;
     MI_REQUIRE(lds <= 160 * 1024, "mi_upsample_ce: upsample factor too large for one LDS tile (%zu B)", lds);
     static size_t lds_set = 0;
     if (lds > lds_set) {
-        (void)hipFuncSetAttribute((const void*)upce_pass1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)upce_pass1_kernel<19>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)upce_pass1_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_set = lds;
     }
-    hipLaunchKernelGGL(upce_pass1_kernel, dim3(tiles, H, B), dim3(256), lds, (hipStream_t)stream, low, labels, partial, tmp, B, K, ay, ax,
-                       ignore_index, npx_max);
+    if (K == 19)
+        hipLaunchKernelGGL(upce_pass1_kernel<19>, dim3(tiles, H, B), dim3(256), lds, (hipStream_t)stream, low, labels, partial, tmp, B, K, ay,
+                           ax, ignore_index, npx_max);
+    else
+        hipLaunchKernelGGL(upce_pass1_kernel<0>, dim3(tiles, H, B), dim3(256), lds, (hipStream_t)stream, low, labels, partial, tmp, B, K, ay,
+                           ax, ignore_index, npx_max);
     MI_CHECK_LAUNCH("mi_upsample_ce pass1");
     hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partial, B * H * tiles, loss_out);
     MI_CHECK_LAUNCH("mi_upsample_ce finalize");
