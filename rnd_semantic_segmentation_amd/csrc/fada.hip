@@ -83,16 +83,21 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const bf16x8* __restrict
 
 // pass 1: workgroup = (b, y, tile of JT low-res columns).  Per high-res pixel (once): soft labels from the segmentation logits,
 // log-softmax of the 2K discriminator logits, loss term, d = S*softmax(z) - placed(soft) into LDS; then gather along x.
+// KT > 0: compile-time class count (19: exact-length unrolled loops, soft labels indexed statically); KT == 0: runtime K.
+template <int KT>
 __global__ __launch_bounds__(256) void softce_pass1_kernel(const float* __restrict__ seg, float inv_t, float clip, const float* __restrict__ dl,
                                                            int ldD, int domain, float* __restrict__ partial, float* __restrict__ tmp, int B,
-                                                           int K, Axis ay, Axis ax, int npx_max) {
+                                                           int Krt, Axis ay, Axis ax, int npx_max) {
     extern __shared__ __attribute__((aligned(16))) float sh[];
+    const int K = KT > 0 ? KT : Krt;
+    constexpr int KR = KT > 0 ? KT : KMAX;
     const int K2 = 2 * K;
     float* dbuf = sh;                                   // [npx_max][K2]
     float* lam = dbuf + (long)npx_max * K2;             // [npx_max]
     int* x0s = reinterpret_cast<int*>(lam + npx_max);   // [npx_max]
     float* red = reinterpret_cast<float*>(x0s + npx_max);   // [256]
-    float* srow = red + 256;                            // [JT+2][K]   seg logits interpolated along y
+    int* pstart = reinterpret_cast<int*>(red + 256);    // [JT+3] first pixel (relative to xa) whose x0 >= j0 - 1 + q
+    float* srow = red + 256 + JT + 4;                   // [JT+2][K]   seg logits interpolated along y
     float* drow = srow + (JT + 2) * K;                  // [JT+2][K2]  discriminator logits interpolated along y
     const int H = ay.n_out, h = ay.n_in, w = ax.n_in;
     const int jt = blockIdx.x, y = blockIdx.y, b = blockIdx.z;
@@ -103,6 +108,7 @@ __global__ __launch_bounds__(256) void softce_pass1_kernel(const float* __restri
     float ly;
     ay.src(y, y0, y1, ly);
     const int cbase = max(j0 - 1, 0), ncol = min(j1, w - 1) - cbase + 1;
+    if (threadIdx.x < j1 - j0 + 2) pstart[threadIdx.x] = ax.first_with_i0_ge(j0 - 1 + (int)threadIdx.x) - xa;
     for (int e = threadIdx.x; e < ncol * K; e += 256) {
         const int c = e / K, k = e - c * K;
         const long o0 = (((long)b * h + y0) * w + cbase + c) * K + k, o1 = (((long)b * h + y1) * w + cbase + c) * K + k;
@@ -121,23 +127,22 @@ __global__ __launch_bounds__(256) void softce_pass1_kernel(const float* __restri
         float lx;
         ax.src(x, x0, x1, lx);
         lam[px] = lx;
-        x0s[px] = x0;
         const float* s0 = srow + (x0 - cbase) * K;
         const float* s1 = srow + (x1 - cbase) * K;
         const float* z0 = drow + (x0 - cbase) * K2;
         const float* z1 = drow + (x1 - cbase) * K2;
         // soft labels: softmax(seg / T), clipped (aspp_fada.py:91-103)
-        float soft[KMAX];
+        float soft[KR];
         float mx = -3.0e38f;
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k)
+        for (int k = 0; k < KR; ++k)
             if (k < K) {
                 soft[k] = ((1.f - lx) * s0[k] + lx * s1[k]) * inv_t;
                 mx = fmaxf(mx, soft[k]);
             }
         float se = 0.f;
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k)
+        for (int k = 0; k < KR; ++k)
             if (k < K) {
                 soft[k] = __expf(soft[k] - mx);
                 se += soft[k];
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(256) void softce_pass1_kernel(const float* __restri
         float S = 0.f;
         const float rse = 1.f / se;
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k)
+        for (int k = 0; k < KR; ++k)
             if (k < K) {
                 soft[k] = fminf(soft[k] * rse, clip);
                 S += soft[k];
@@ -158,15 +163,28 @@ __global__ __launch_bounds__(256) void softce_pass1_kernel(const float* __restri
         const float lse = zm + __logf(ze), rze = 1.f / ze;
         float* d = dbuf + (long)px * K2;
         float l = 0.f;
-        for (int k = 0; k < K2; ++k) {
-            const float z = (1.f - lx) * z0[k] + lx * z1[k];
-            float placed = 0.f;
-            const int c = k - domain * K;
+        if (KT > 0) {                     // channel k = half*K + q carries soft[q] when half == domain, else 0: static indices
 #pragma unroll
-            for (int q = 0; q < KMAX; ++q)
-                if (q == c) placed = soft[q];
-            l -= placed * (z - lse);
-            d[k] = S * __expf(z - zm) * rze - placed;
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int q = 0; q < KR; ++q) {
+                    const int k = half * KR + q;
+                    const float z = (1.f - lx) * z0[k] + lx * z1[k];
+                    const float placed = (half == domain) ? soft[q] : 0.f;
+                    l -= placed * (z - lse);
+                    d[k] = S * __expf(z - zm) * rze - placed;
+                }
+        } else {
+            for (int k = 0; k < K2; ++k) {
+                const float z = (1.f - lx) * z0[k] + lx * z1[k];
+                float placed = 0.f;
+                const int c = k - domain * K;
+#pragma unroll
+                for (int q = 0; q < KMAX; ++q)
+                    if (q == c) placed = soft[q];
+                l -= placed * (z - lse);
+                d[k] = S * __expf(z - zm) * rze - placed;
+            }
         }
         if (x0 >= j0) loss += l;          // the tile that owns x0 accounts for the pixel's loss
     }
@@ -177,13 +195,11 @@ __global__ __launch_bounds__(256) void softce_pass1_kernel(const float* __restri
             const int jj = item / K2, k = item - jj * K2;
             const int j = j0 + jj;
             float s = 0.f;
-            const int pa = ax.first_with_i0_ge(j - 1) - xa, pb = ax.first_with_i0_ge(j + 1) - xa;
-            for (int px = max(pa, 0); px < min(pb, npx); ++px) {
-                const int x0 = x0s[px];
-                const int x1 = (x0 < w - 1) ? x0 + 1 : x0;
-                const float wgt = (x0 == j ? 1.f - lam[px] : 0.f) + (x1 == j ? lam[px] : 0.f);
-                s += wgt * dbuf[(long)px * K2 + k];
-            }
+            // pixels with x0 == j-1 contribute lam (as x1), then pixels with x0 == j contribute 1-lam (+ lam at the clamped right edge)
+            const int p0 = max(pstart[jj], 0), p1 = min(max(pstart[jj + 1], 0), npx), p2 = min(pstart[jj + 2], npx);
+            for (int px = p0; px < p1; ++px) s += (0.f + lam[px]) * dbuf[(long)px * K2 + k];
+            const bool edge = j == w - 1;
+            for (int px = p1; px < p2; ++px) s += ((1.f - lam[px]) + (edge ? lam[px] : 0.f)) * dbuf[(long)px * K2 + k];
             tmp[(((long)b * H + y) * w + j) * K2 + k] = s;
         }
     }
@@ -275,15 +291,20 @@ extern "C" int mi_upsample_softce(const float* seg_low, float inv_temperature, f
     const size_t poff = (((size_t)B * H * tiles * sizeof(float)) + 255) & ~(size_t)255;
     float* tmp = dd_low ? (float*)((char*)workspace + poff) : nullptr;
     const int npx_max = npx_bound(ax);
-    const size_t lds = ((size_t)npx_max * K2 + (size_t)npx_max * 2 + 256 + (size_t)(JT + 2) * (K + K2)) * 4;
+    const size_t lds = ((size_t)npx_max * K2 + (size_t)npx_max * 2 + 256 + (JT + 4) + (size_t)(JT + 2) * (K + K2)) * 4;
     MI_REQUIRE(lds <= 160 * 1024, "mi_upsample_softce: upsample factor too large for one LDS tile (%zu B)", lds);
     static size_t lds_set = 0;
     if (lds > lds_set) {
-        (void)hipFuncSetAttribute((const void*)softce_pass1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)softce_pass1_kernel<19>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)softce_pass1_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_set = lds;
     }
-    hipLaunchKernelGGL(softce_pass1_kernel, dim3(tiles, H, B), dim3(256), lds, (hipStream_t)stream, seg_low, inv_temperature, clip, d_low, ldD,
-                       domain, partial, tmp, B, K, ay, ax, npx_max);
+    if (K == 19)
+        hipLaunchKernelGGL(softce_pass1_kernel<19>, dim3(tiles, H, B), dim3(256), lds, (hipStream_t)stream, seg_low, inv_temperature, clip, d_low,
+                           ldD, domain, partial, tmp, B, K, ay, ax, npx_max);
+    else
+        hipLaunchKernelGGL(softce_pass1_kernel<0>, dim3(tiles, H, B), dim3(256), lds, (hipStream_t)stream, seg_low, inv_temperature, clip, d_low,
+                           ldD, domain, partial, tmp, B, K, ay, ax, npx_max);
     MI_CHECK_LAUNCH("mi_upsample_softce pass1");
     const float count = (float)B * (float)H * (float)W;
     hipLaunchKernelGGL(softce_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partial, B * H * tiles, count, loss_out);
