@@ -111,7 +111,11 @@ int mi_aspp_col2im(const float* z /*[36][M][20]*/, const float* bias4 /*[4][K]*/
 /* g[m][k] bf16, k = (r*9+t)*K+n, columns >= 36*K zero */
 int mi_aspp_im2col(const float* dlow /*[B][H][W][K]*/, void* g_bf16 /*[M][704]*/,
                    int B, int H, int W, int K, const int* rates4 /*host*/, void* stream);
-int mi_aspp_bias_grad(const float* dlow, float* dbias4 /*[4][K]*/, int M, int K, int accumulate, void* stream);
+/* dbias4[r][n] (+)= sum_m dlow[m][n], r = 0..3 (every branch sees the same gradient); two-level fixed-order column sum,
+ * workspace >= mi_colsum_workspace(M, K) bytes (csrc/colsum.hip) */
+size_t mi_colsum_workspace(int M, int N);
+int mi_aspp_bias_grad(const float* dlow, float* dbias4 /*[4][K]*/, int M, int K, int accumulate,
+                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- bilinear upsample, align_corners=True (classifier.py:31, core/utils/utility.py:185) --------
  * low: [B][h][w][K] fp32 NHWC, up: [B][K][H][W] fp32 NCHW (the layout the reference returns). */
@@ -158,7 +162,8 @@ int mi_stem_pool_bwd(const void* dpool, const uint8_t* idx, const float* scale, 
 
 /* ---- FADA adversarial step (reference core/combos/aspp_fada.py:80-127) ---------------------------
  * db[n] (+)= sum_m dy[m][n]  (conv bias gradient; dy bf16 [M][N], N % 8 == 0; fixed summation order) */
-int mi_bias_grad_bf16(const void* dy_bf16, float* db, int M, int N, int accumulate, void* stream);
+int mi_bias_grad_bf16(const void* dy_bf16, float* db, int M, int N, int accumulate,
+                      void* workspace /* mi_colsum_workspace(M, N) */, size_t workspace_bytes, void* stream);
 /* Fused  soft = clip(softmax(upsample(seg_low) * inv_temperature), clip);  pred = upsample(d_low)[:, :2K];
  *        loss = mean_pixels( -sum_c soft_c * log_softmax(pred)[c + domain*K] )
  * = soft_label_cross_entropy(model_D(fea, size), cat(soft, 0) or cat(0, soft)) of aspp_fada.py:104-121 with the soft labels

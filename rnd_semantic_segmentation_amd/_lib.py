@@ -29,7 +29,8 @@ SIGNATURES = {
     "mi_aspp_pack_dgrad": (I, [P, P, I, I, P]),
     "mi_aspp_col2im": (I, [P, P, P, I, I, I, I, P, P]),
     "mi_aspp_im2col": (I, [P, P, I, I, I, I, P, P]),
-    "mi_aspp_bias_grad": (I, [P, P, I, I, I, P]),
+    "mi_colsum_workspace": (Z, [I, I]),
+    "mi_aspp_bias_grad": (I, [P, P, I, I, I, P, Z, P]),
     "mi_upsample_ac_fwd": (I, [P, P] + [I] * 6 + [P]),
     "mi_upsample_ac_bwd": (I, [P, P] + [I] * 6 + [P]),
     "mi_ce_workspace": (Z, [I, I, I]),
@@ -40,7 +41,7 @@ SIGNATURES = {
     "mi_upsample_softmax": (I, [P, P, P] + [I] * 6 + [P]),
     "mi_stem_pool_fwd": (I, [P, P, P, P, P] + [I] * 6 + [P]),
     "mi_stem_pool_bwd": (I, [P, P, P, P] + [I] * 6 + [P]),
-    "mi_bias_grad_bf16": (I, [P, P, I, I, I, P]),
+    "mi_bias_grad_bf16": (I, [P, P, I, I, I, P, Z, P]),
     "mi_upsample_softce_workspace": (Z, [I] * 6),
     "mi_upsample_softce": (I, [P, F, F, P, I, I, P, P] + [I] * 6 + [F, P, Z, P]),
     "mi_adam_step": (I, [P, P, P, P, Z, F, F, F, F, I, P]),

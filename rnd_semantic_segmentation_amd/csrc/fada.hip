@@ -56,31 +56,6 @@ __device__ __forceinline__ void block_sum(float& a, float* red) {
     __syncthreads();
 }
 
-// one workgroup per 8 channels; rows strided over 256 threads, then a fixed-order tree
-__global__ __launch_bounds__(256) void bias_grad_kernel(const bf16x8* __restrict__ dy, float* __restrict__ db, long M, int N8, int accumulate) {
-    __shared__ float red[8][256];
-    const int c8 = blockIdx.x;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (long m = threadIdx.x; m < M; m += 256) {
-        const bf16x8 v = dy[m * N8 + c8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) red[e][threadIdx.x] = acc[e];
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if (threadIdx.x < w)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) red[e][threadIdx.x] += red[e][threadIdx.x + w];
-        __syncthreads();
-    }
-    if (threadIdx.x < 8) {
-        const int n = c8 * 8 + threadIdx.x;
-        db[n] = accumulate ? db[n] + red[threadIdx.x][0] : red[threadIdx.x][0];
-    }
-}
-
 // pass 1: workgroup = (b, y, tile of JT low-res columns).  Per high-res pixel (once): soft labels from the segmentation logits,
 // log-softmax of the 2K discriminator logits, loss term, d = S*softmax(z) - placed(soft) into LDS; then gather along x.
 // KT > 0: compile-time class count (19: exact-length unrolled loops, soft labels indexed statically); KT == 0: runtime K.
@@ -263,13 +238,6 @@ inline int npx_bound(const Axis& ax) {
 }
 
 }  // namespace
-
-extern "C" int mi_bias_grad_bf16(const void* dy, float* db, int M, int N, int accumulate, void* stream) {
-    MI_REQUIRE(dy && db && M > 0 && N > 0 && N % 8 == 0 && mi_aligned16(dy), "mi_bias_grad_bf16: bad argument (N %% 8 == 0)");
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(N / 8), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)dy, db, (long)M, N / 8, accumulate);
-    MI_CHECK_LAUNCH("mi_bias_grad_bf16");
-    return MI_OK;
-}
 
 extern "C" size_t mi_upsample_softce_workspace(int B, int h, int w, int K, int H, int W) {
     const size_t tiles = (size_t)((w + JT - 1) / JT);

@@ -213,7 +213,9 @@ def aspp_bias_grad(dlow, dbias4, accumulate=False):
     _chk(dlow, torch.float32, "dlow")
     _chk(dbias4, torch.float32, "dbias4")
     B, H, W, K = dlow.shape
-    check(_lib.lib().mi_aspp_bias_grad(_p(dlow), _p(dbias4), B * H * W, K, int(accumulate), _stream()), "mi_aspp_bias_grad")
+    L = _lib.lib()
+    ws = _workspace(L.mi_colsum_workspace(B * H * W, K), dlow.device, "colsum")
+    check(L.mi_aspp_bias_grad(_p(dlow), _p(dbias4), B * H * W, K, int(accumulate), _p(ws), ws.numel(), _stream()), "mi_aspp_bias_grad")
     return dbias4
 
 
@@ -310,7 +312,9 @@ def bias_grad_bf16(dy, db, accumulate=False):
     _chk(dy, torch.bfloat16, "dy")
     _chk(db, torch.float32, "db")
     N = dy.shape[-1]
-    check(_lib.lib().mi_bias_grad_bf16(_p(dy), _p(db), dy.numel() // N, N, int(accumulate), _stream()), "mi_bias_grad_bf16")
+    L = _lib.lib()
+    ws = _workspace(L.mi_colsum_workspace(dy.numel() // N, N), dy.device, "colsum")
+    check(L.mi_bias_grad_bf16(_p(dy), _p(db), dy.numel() // N, N, int(accumulate), _p(ws), ws.numel(), _stream()), "mi_bias_grad_bf16")
     return db
 
 
