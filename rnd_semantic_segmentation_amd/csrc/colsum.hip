@@ -45,12 +45,23 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const void* __restr
     }
 }
 
-__global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblocks, int N, int rep, int accumulate) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+// 8 columns per workgroup, 32 lanes per column: lane q adds partials q, q+32, ... in ascending order, lane 0 then adds the 32 lane
+// sums in ascending order (fixed association, independent of timing)
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblocks, int N, int rep,
+                                                           int accumulate) {
+    __shared__ float red[32][8];
+    const int c = threadIdx.x & 7, q = threadIdx.x >> 3;
+    const int n = blockIdx.x * 8 + c;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partial[(long)b * N + n];
-    for (int r = 0; r < rep; ++r) out[r * N + n] = accumulate ? out[r * N + n] + s : s;
+    if (n < N)
+        for (int b = q; b < nblocks; b += 32) s += partial[(long)b * N + n];
+    red[q][c] = s;
+    __syncthreads();
+    if (q == 0 && n < N) {
+        float t = 0.f;
+        for (int i = 0; i < 32; ++i) t += red[i][c];
+        for (int r = 0; r < rep; ++r) out[r * N + n] = accumulate ? out[r * N + n] + t : t;
+    }
 }
 
 int launch(const void* src, float* out, long M, int N, int vec, int rep, int accumulate, void* workspace, size_t ws_bytes, void* stream,
@@ -69,7 +80,7 @@ int launch(const void* src, float* out, long M, int N, int vec, int rep, int acc
         hipLaunchKernelGGL(colsum_partial_kernel<1>, dim3(nb), dim3(256), 0, (hipStream_t)stream, src, partial, M, slots, cp, rows);
     else
         hipLaunchKernelGGL(colsum_partial_kernel<8>, dim3(nb), dim3(256), 0, (hipStream_t)stream, src, partial, M, slots, cp, rows);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)partial, out, nb, N, rep,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const float*)partial, out, nb, N, rep,
                        accumulate);
     return MI_OK;
 }

@@ -1,13 +1,13 @@
 #!/bin/bash
 # Round profile on the GPU box: rocprofv3 kernel stats of bench.py (default two-stream schedule, and single-stream), then the
-# three PMC passes (single-stream, so that counters are attributable per kernel).  Outputs under gpurun_out/<tag>_*.
+# three PMC passes (single stream: MI_WGRAD_STREAM=0 MI_BATCH_LANES=1, so that counters and durations are attributable per kernel).  Outputs under gpurun_out/<tag>_*.
 # usage: bash tools/profile_round.sh <tag>
 tag=${1:-r01}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 B="python3 $root/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-kernel-events"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/${tag}_stats -o bench -- $B > $root/gpurun_out/${tag}_stats.log 2>&1 || echo "stats failed"
-export MI_WGRAD_STREAM=0
+export MI_WGRAD_STREAM=0 MI_BATCH_LANES=1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/${tag}_stats_1s -o bench -- $B > $root/gpurun_out/${tag}_stats_1s.log 2>&1 || echo "stats 1s failed"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $root/gpurun_out/${tag}_pmcA -o bench -- $B > $root/gpurun_out/${tag}_pmcA.log 2>&1 || echo "pmcA failed"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $root/gpurun_out/${tag}_pmcB -o bench -- $B > $root/gpurun_out/${tag}_pmcB.log 2>&1 || echo "pmcB failed"
