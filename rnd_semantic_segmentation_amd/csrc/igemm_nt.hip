@@ -17,7 +17,7 @@
 // (pixel = lane&15, q = lane>>4) ends up with two groups of 8 CONTIGUOUS channels, 8q.. and 32+8q..: one 16-B store /
 // residual load / mask byte per group, and the 4 lanes of a pixel cover 64 CONTIGUOUS bytes per instruction (two full
 // 32-B sectors; two instructions fill the 128-B line).
-#include "mi_common.h"
+#include "igemm_common.h"
 #include <stdlib.h>
 
 namespace {
@@ -47,25 +47,6 @@ template <int MT, int BKT = 64, int NWN = 2> struct Geo {
     static constexpr int OCC = NWN == 4 ? 1 : (BKT == 64 ? 2 : (MT <= 4 ? 4 : 3));
 };
 
-__device__ __attribute__((aligned(256))) uint32_t g_zero_page[64];   // source of every padded / out-of-range chunk
-
-struct IgemmParams {
-    const __bf16* A;
-    const __bf16* Wp;
-    void* out;
-    const float* scale;
-    const float* bias;
-    const __bf16* res;
-    const __bf16* msk;            // bf16 tensor (MI_EPI_MASK) or packed sign bits, uint16 per 16 channels (MI_EPI_BITMASK)
-    uint16_t* mask_out;           // MI_EPI_WRITE_MASK: bit c%16 of word [m][c/16] = (out[m][c] > 0)
-    int M, N, Ca, T;
-    int Ho, Wo, Ha, Wa;
-    int ksz, stride, pad, dil, mode;
-    int flags, zgw;
-    float alpha;                  // LeakyReLU negative slope (MI_EPI_LEAKY)
-    int m_tiles, n_tiles;
-};
-
 __device__ __forceinline__ bool tap_src(const IgemmParams& p, int ho, int wo, int ky, int kx, int& ha, int& wa) {
     // general gather (any stride), branch-free
     const bool fwd = p.mode == MI_GATHER_FWD;
@@ -76,11 +57,6 @@ __device__ __forceinline__ bool tap_src(const IgemmParams& p, int ho, int wo, in
     ha = fwd ? fh : qh;
     wa = fwd ? fw : qw;
     return (fwd | dg_ok) & ((unsigned)ha < (unsigned)p.Ha) & ((unsigned)wa < (unsigned)p.Wa);
-}
-
-__device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
 // PREF: the epilogue's residual rows and mask bits are requested BEFORE the main loop (they are 150-300 MB of HBM traffic
@@ -252,30 +228,9 @@ __global__ __launch_bounds__((Geo<MT, BKT, NWN>::NW * 64), (Geo<MT, BKT, NWN>::O
     const int frow = lane & 15, fq = lane >> 4;
     const int wrow0 = wn * 64 + 8 * (frow >> 2) + (frow & 3);           // + 32*(i>>1) + 4*(i&1): permuted weight row of MFMA tile i
     const int flags = EPI >= 0 ? EPI : p.flags;
-    // The epilogue's residual rows and ReLU sign bits (150-300 MB of HBM traffic per launch on the 1024/2048-channel tensors) are
-    // fetched as ONE batch of independent loads per lane: before the main loop (PREF: they land behind the MFMA work) or right
-    // after it (registers of the operand fragments are free then).  Left inside the per-row loop they would be serialised
-    // behind the stores (out / res may alias as far as the compiler knows): one HBM round trip per 16 rows.
     bf16x8 pres[MT][2];
     unsigned pbits[MT];
-    auto fetch_epilogue_operands = [&]() __attribute__((always_inline)) {
-        const int nbp = n0 + wn * 64 + 8 * fq;
-#pragma unroll
-        for (int j = 0; j < MT; ++j) {
-            const int m = m0 + wm * (MT * 16) + j * 16 + frow;
-            const long o0 = (long)(m < p.M ? m : 0) * p.N + (nbp < p.N ? nbp : 0);
-            const long o1 = (long)(m < p.M ? m : 0) * p.N + (nbp + 32 < p.N ? nbp + 32 : 0);
-            if (flags & MI_EPI_RESIDUAL) {
-                pres[j][0] = *reinterpret_cast<const bf16x8*>(p.res + o0);
-                pres[j][1] = *reinterpret_cast<const bf16x8*>(p.res + o1);
-            }
-            if (flags & MI_EPI_BITMASK) {
-                const uint8_t* mb = reinterpret_cast<const uint8_t*>(p.msk);
-                pbits[j] = (unsigned)mb[o0 >> 3] | ((unsigned)mb[o1 >> 3] << 8);
-            }
-        }
-    };
-    if (PREF) fetch_epilogue_operands();
+    if (PREF) igemm_fetch_epilogue<MT, EPI>(p, m0, n0, wm, wn, frow, fq, pres, pbits);
     auto compute = [&](int buf) {
         const char* sa = smem + buf * STAGE_BYTES;
         const char* sb = sa + ATILE_BYTES;
@@ -313,131 +268,8 @@ __global__ __launch_bounds__((Geo<MT, BKT, NWN>::NW * 64), (Geo<MT, BKT, NWN>::O
             for (int j = 0; j < MT; ++j) asm volatile("" ::"v"(acc[i][j]));
         return;
     }
-    // ---- epilogue: lane owns pixel m (D col) and two groups of 8 contiguous channels: h = 0 -> nb .. nb+7 (MFMA tiles 0, 1),
-    //      h = 1 -> nb+32 .. nb+39 (tiles 2, 3); tile i holds channels nb + 32*(i>>1) + 4*(i&1) + (0..3) ------------------------
-    const int nb = n0 + wn * 64 + 8 * fq;
-    if (!PREF) fetch_epilogue_operands();
-    f32x4 esc[4], ebi[4];               // FrozenBN scale / shift of this lane's 16 channels: loaded once, not per pixel
-    if (flags & MI_EPI_SCALE_BIAS) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ni = nb + 32 * (i >> 1) + 4 * (i & 1);
-            const int n = (ni < p.N) ? ni : 0;
-            esc[i] = *reinterpret_cast<const f32x4*>(p.scale + n);
-            ebi[i] = *reinterpret_cast<const f32x4*>(p.bias + n);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < MT; ++j) {
-        const int m = m0 + wm * (MT * 16) + j * 16 + frow;
-        if (m >= p.M) continue;
-        const long o = (long)m * p.N + nb;       // group h starts at o + 32*h
-        f32x4 v[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = acc[i][j];
-        if (flags & MI_EPI_SCALE_BIAS) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = v[i] * esc[i] + ebi[i];
-        }
-        if (flags & MI_EPI_RESIDUAL) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (nb + 32 * h < p.N) {
-                    const bf16x8 r = pres[j][h];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[2 * h + (e >> 2)][e & 3] += (float)r[e];
-                }
-            }
-        }
-        if (flags & MI_EPI_RELU) {
-            if (flags & MI_EPI_LEAKY) {                                     // LeakyReLU(alpha)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[i][e] = v[i][e] > 0.f ? v[i][e] : p.alpha * v[i][e];
-            } else {                                                        // one v_max_f32 per value; the result is never -0
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) asm("v_max_f32 %0, 0, %1" : "=v"(v[i][e]) : "v"(v[i][e]));   // fmaxf() costs two (canonicalize)
-            }
-        }
-        if (flags & MI_EPI_MASK) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (nb + 32 * h < p.N) {
-                    const bf16x8 k = *reinterpret_cast<const bf16x8*>(p.msk + o + 32 * h);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        v[2 * h + (e >> 2)][e & 3] = ((float)k[e] > 0.f) ? v[2 * h + (e >> 2)][e & 3] : 0.f;
-                }
-            }
-        }
-        if (flags & MI_EPI_BITMASK) {
-            // the packed sign bits are addressed as bytes here: bit c%8 of byte c/8 == bit c%16 of the uint16 word c/16
-            const float neg = (flags & MI_EPI_LEAKY) ? p.alpha : 0.f;       // backward of LeakyReLU: gradient x alpha where the sign bit is 0
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (nb + 32 * h < p.N) {
-                    const unsigned bits = (pbits[j] >> (8 * h)) & 0xffu;
-                    if (flags & MI_EPI_LEAKY) {
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) v[2 * h + (c >> 2)][c & 3] = ((bits >> c) & 1u) ? v[2 * h + (c >> 2)][c & 3] : neg * v[2 * h + (c >> 2)][c & 3];
-                    } else {      // two ops per value: sign-extend bit c to a word mask (v_bfe_i32), AND it onto the float
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) {
-                            const unsigned keep = (unsigned)__builtin_amdgcn_sbfe((int)bits, c, 1);
-                            v[2 * h + (c >> 2)][c & 3] = __uint_as_float(__float_as_uint(v[2 * h + (c >> 2)][c & 3]) & keep);
-                        }
-                    }
-                }
-            }
-        }
-        if (flags & MI_EPI_WRITE_MASK) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (nb + 32 * h < p.N) {
-                    unsigned bits = 0;
-                    if ((flags & MI_EPI_RELU) && !(flags & MI_EPI_LEAKY)) {
-                        // after ReLU every value is >= +0, so (v > 0) == (bits of v != 0) == sign of (0 - bits): two ops per value,
-                        // v_sub_u32 and v_alignbit_b32 (shift the collected bits left by one and append that sign)
-#pragma unroll
-                        for (int c = 7; c >= 0; --c) bits = __builtin_amdgcn_alignbit(bits, 0u - __float_as_uint(v[2 * h + (c >> 2)][c & 3]), 31);
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) bits |= (v[2 * h + (c >> 2)][c & 3] > 0.f ? 1u : 0u) << c;
-                    }
-                    reinterpret_cast<uint8_t*>(p.mask_out)[(o + 32 * h) >> 3] = (uint8_t)bits;
-                }
-            }
-        }
-        if (flags & MI_EPI_ZSPLIT) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int n = nb + 32 * (i >> 1) + 4 * (i & 1);
-                if (n < p.N) {
-                    const int g = n / p.zgw, nn = n - g * p.zgw;
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + ((long)g * p.M + m) * p.zgw + nn) = v[i];
-                }
-            }
-        } else if (flags & MI_EPI_OUT_F32) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int n = nb + 32 * (i >> 1) + 4 * (i & 1);
-                if (n < p.N) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (long)m * p.N + n) = v[i];
-            }
-        } else {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (nb + 32 * h < p.N) {
-                    bf16x8 hv;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) hv[e] = (__bf16)v[2 * h + (e >> 2)][e & 3];
-                    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.out) + o + 32 * h) = hv;
-                }
-            }
-        }
-    }
+    if (!PREF) igemm_fetch_epilogue<MT, EPI>(p, m0, n0, wm, wn, frow, fq, pres, pbits);
+    igemm_epilogue<MT, EPI>(p, acc, m0, n0, wm, wn, frow, fq, pres, pbits);
 }
 
 template <int MT, bool UNIT, bool PREF, int BKT, int EPI, int NWN>

@@ -121,6 +121,47 @@ def test_conv_fused_epilogue_bn_residual_relu_mask():
     assert relmax(dw.cpu().numpy(), ref_ops.conv2d_wgrad(dy, x, 3, 1, d, d) * scale.reshape(-1, 1, 1, 1)) < 2e-5
 
 
+@pytest.mark.parametrize("ci,co,B,H,W", [(256, 1024, 2, 13, 11), (128, 528, 1, 17, 9), (64, 256, 3, 21, 20), (256, 1024, 8, 97, 97)])
+def test_pointwise_wide_conv_all_hot_epilogues_vs_torch(ci, co, B, H, W):
+    """The short-K / wide-N 1x1 convs (conv3 forward, conv1 data gradient: K in {64,128,256}, N = 4K) run on the A-stationary
+    kernel (igemm_astat.hip) for the four epilogue flag sets of the bottlenecks; ragged M, an N tail (528 = 4 tiles + 16) and
+    the BASELINE shape.  Reference: fp32 torch on the same bf16 operands; bf16 outputs within one ulp of the max, bits exact."""
+    g = torch.Generator().manual_seed(ci + co + H)
+    x = (torch.randn(B, H, W, ci, generator=g)).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(co, ci, 1, 1, generator=g) * 0.06).to(DEV)
+    wb = w.to(torch.bfloat16).float().view(co, ci)
+    res = torch.randn(B, H, W, co, generator=g).to(torch.bfloat16).to(DEV)
+    sc, sh = (torch.rand(co, generator=g) + 0.5).to(DEV), torch.randn(co, generator=g).to(DEV)
+    wp = K.pack_weight_fwd(w)
+    lin = x.float().view(-1, ci) @ wb.t()                                   # [M, co] fp32
+    M = B * H * W
+
+    def bits_of(t):
+        return ((t.view(B, H, W, co // 16, 1).int() >> torch.arange(16, device=DEV).int()) & 1).bool().reshape(M, co)
+
+    # 69: FrozenBN + ReLU + sign bits;  71: + residual
+    for use_res in (False, True):
+        bits = torch.zeros((B, H, W, co // 16), dtype=torch.int16, device=DEV)
+        y = K.conv_gemm(x, wp, (H, W), scale=sc, bias=sh, res=res if use_res else None, relu=True, mask_out=bits)
+        pre = lin * sc + sh + (res.float().view(M, co) if use_res else 0)
+        want = torch.relu(pre)
+        assert relmax(y.float().view(M, co).cpu().numpy(), want.cpu().numpy()) < 2.0 ** -8
+        sure = pre.abs() > 1e-3
+        assert torch.equal(bits_of(bits)[sure], (pre > 0)[sure])
+        assert torch.equal(bits_of(bits), y.view(M, co) > 0) or (~sure).any()
+    # 128: ReLU backward from sign bits;  130: + residual-gradient add
+    keep = torch.rand(B, H, W, co, generator=g).to(DEV) > 0.4
+    packed = (keep.view(B, H, W, co // 16, 16).int() << torch.arange(16, device=DEV).int()).sum(-1).to(torch.int16)
+    for use_res in (False, True):
+        y = K.conv_gemm(x, wp, (H, W), res=res if use_res else None, bits=packed)
+        want = (lin + (res.float().view(M, co) if use_res else 0)) * keep.view(M, co)
+        assert relmax(y.float().view(M, co).cpu().numpy(), want.cpu().numpy()) < 2.0 ** -8
+        assert bool((y.view(M, co)[~keep.view(M, co)] == 0).all())
+    # run-to-run reproducibility
+    y2 = K.conv_gemm(x, wp, (H, W), res=res, bits=packed)
+    assert torch.equal(y, y2)
+
+
 def test_conv_identity_weight_is_exact_shift_full_size():
     """Size-independent property at the BASELINE shape (B=8, 97x97, C=256, d=2): a one-hot tap weight makes the
     conv an exact spatial shift with zero fill - bit exact in bf16."""

@@ -23,7 +23,8 @@ def run(ci, co, label, res=True, k=1, d=1):
     cases += [(1 | 4 | 64, 'no-res')] if res else []
     cases += [(1 << 30, 'nostore')]
     for fl, name in cases:
-        f = lambda: L.mi_conv_gemm(P(x), P(wp), P(out), B, H, H, ci, H, H, co, k, 1, d if k == 3 else 0, d, 0, P(sc), P(sh), P(r), None, P(bits), fl, 0,
+        zg = 0
+        f = lambda: L.mi_conv_gemm(P(x), P(wp), P(out), B, H, H, ci, H, H, co, k, 1, d if k == 3 else 0, d, 0, P(sc), P(sh), P(r), None, P(bits), fl, zg,
                                    ctypes.c_float(0.0), st)
         t = timeit(f, 30)
         print('%-16s %-8s MT=%s %7.1f us  %6.0f TF  %5.2f TB/s(min traffic)' % (label, name, os.environ.get("MI_IGEMM_MT", "auto") + "/" + os.environ.get("MI_IGEMM_BN", "auto"), t * 1e6,
