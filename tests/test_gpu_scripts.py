@@ -71,3 +71,14 @@ def test_bench_under_torchrun_nccl_single_rank_exercises_the_reducer():
     r2 = run(["bench.py", "--steps", "3", "--warmup", "1", "--size", "161", "--batch", "2", "--no-cpu-baseline"], {})
     out2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
     assert abs(out2["config"]["final_loss"] - out["config"]["final_loss"]) < 1e-4
+
+
+def test_opt_in_kernel_variants_and_single_stream_schedule_stay_correct():
+    """Selections that are not the default still have to be right: the 8-wave 256-wide conv tile (MI_IGEMM_BN=256), and the
+    single-stream schedule (no forward lanes, weight gradients on the main stream) that bench.py's instrumented steps use.
+    Environment switches are read once per process, so each runs the relevant parity tests in a child pytest."""
+    for env, sel in (({"MI_IGEMM_BN": "256"}, ["tests/test_gpu_ops.py", "-k", "golden or fused_epilogue or pointwise or identity"]),
+                     ({"MI_WGRAD_STREAM": "0", "MI_BATCH_LANES": "1"}, ["tests/test_gpu_model.py", "-k", "tinynet"])):
+        r = run(["-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider"] + sel, env)
+        assert r.returncode == 0, (env, r.stdout[-3000:])
+        assert " passed" in r.stdout and " failed" not in r.stdout
