@@ -195,8 +195,9 @@ def main():
                                "launches_per_step": n // inst_steps, "avg_launch_us": round(1e6 * tsec / n, 2),
                                "alg_gflop_per_launch": round(fl / n / 1e9, 3), "ms_per_step_in_kernel": round(1e3 * tsec / inst_steps, 3),
                                "instrumented_steps": inst_steps,
-                               "note": "per-launch durations from the instrumented steps, which run single-stream; the other timed steps "
-                                       "overlap weight-gradient launches with the data-gradient chain on a second HIP stream"}
+                               "note": "per-launch durations from the instrumented steps, which run single-stream; the other timed steps run "
+                                       "the forward as two half-batch lanes and the weight gradients beside the data-gradient chain "
+                                       "on extra HIP streams"}
             out["kernels"] = {k: {"ms_per_step": round(1e3 * v[0] / inst_steps, 3), "tflops": round(v[1] / v[0] / 1e12, 2),
                                   "launches_per_step": v[2] // inst_steps} for k, v in by.items()}
         if events and os.environ.get("MI_BENCH_SHAPES"):
