@@ -63,8 +63,11 @@ __device__ __forceinline__ bool tap_src(const IgemmParams& p, int ho, int wo, in
 // per launch on the 1024/2048-channel tensors) so that they land behind the MFMA work instead of after it.
 // EPI >= 0: the epilogue flag set is a compile-time constant (the four sets the ResNet bottlenecks launch 200x per step get a
 // straight-line epilogue: no per-flag branches, no dead ZSPLIT / fp32 paths); EPI < 0: flags are read from the parameters.
-template <int MT, bool UNIT, bool PREF, int BKT, int EPI, int NWN>
+// STG: residual in / bf16 tile out through an LDS image with row-contiguous lanes (igemm_common.h); 128-column tiles with a
+// compile-time epilogue flag set only.
+template <int MT, bool UNIT, bool PREF, int BKT, int EPI, int NWN, bool STG = false>
 __global__ __launch_bounds__((Geo<MT, BKT, NWN>::NW * 64), (Geo<MT, BKT, NWN>::OCC)) void igemm_nt_kernel(IgemmParams p) {
+    static_assert(!STG || (EPI >= 0 && !PREF && NWN == 2 && BKT == 64 && !(EPI & (MI_EPI_OUT_F32 | MI_EPI_ZSPLIT))), "staged epilogue: hot bf16 sets only");
     using G = Geo<MT, BKT, NWN>;
     constexpr int BM = G::BM, BN = G::BNT, ATILE_BYTES = G::ATILE_BYTES, STAGE_BYTES = G::STAGE_BYTES;
     constexpr int ROWB = G::ROWB, RPP = G::RPP, CPR = G::CPR, NPA = G::NPA, NPW = G::NPW, NW = G::NW;
@@ -268,14 +271,37 @@ __global__ __launch_bounds__((Geo<MT, BKT, NWN>::NW * 64), (Geo<MT, BKT, NWN>::O
             for (int j = 0; j < MT; ++j) asm volatile("" ::"v"(acc[i][j]));
         return;
     }
+    if constexpr (STG) {
+        constexpr bool RES = (EPI & MI_EPI_RESIDUAL) != 0;
+        if (RES) igemm_residual_to_lds<MT>(p, m0, n0, wave, lane, zero, smem);
+        igemm_fetch_epilogue<MT, EPI, false>(p, m0, n0, wm, wn, frow, fq, pres, pbits);      // mask bytes only (registers)
+        if (RES) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            igemm_residual_from_lds<MT>(smem, wm, wn, frow, fq, pres);
+        }
+        igemm_epilogue<MT, EPI, true>(p, acc, m0, n0, wm, wn, frow, fq, pres, pbits, smem);
+        __syncthreads();
+        igemm_store_staged<MT>(p, m0, n0, tid, smem);
+        return;
+    }
     if (!PREF) igemm_fetch_epilogue<MT, EPI>(p, m0, n0, wm, wn, frow, fq, pres, pbits);
     igemm_epilogue<MT, EPI>(p, acc, m0, n0, wm, wn, frow, fq, pres, pbits);
 }
 
-template <int MT, bool UNIT, bool PREF, int BKT, int EPI, int NWN>
+inline bool staged_on() {        // MI_IGEMM_STAGED=0: MFMA-layout loads / stores straight from registers
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MI_IGEMM_STAGED");
+        v = e ? atoi(e) : 1;
+    }
+    return v != 0;
+}
+
+template <int MT, bool UNIT, bool PREF, int BKT, int EPI, int NWN, bool STG = false>
 void launch_one(dim3 grid, hipStream_t stream, const IgemmParams& p) {
     static bool attr_done = false;
-    auto kern = igemm_nt_kernel<MT, UNIT, PREF, BKT, EPI, NWN>;
+    auto kern = igemm_nt_kernel<MT, UNIT, PREF, BKT, EPI, NWN, STG>;
     constexpr int lds = Geo<MT, BKT, NWN>::LDS_BYTES;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -289,7 +315,14 @@ void launch_one(dim3 grid, hipStream_t stream, const IgemmParams& p) {
 template <int MT, bool UNIT, bool PREF, int BKT, int NWN>
 void launch_variant(dim3 grid, hipStream_t stream, const IgemmParams& p) {
     const int fl = p.flags;
+    const bool staged = staged_on();
     if constexpr (UNIT) {
+        if constexpr (!PREF && NWN == 2 && BKT == 64) {
+            if (staged) {     // the residual sets only: 5-7 % faster staged; without a residual tile to read it is a wash
+                if (fl == 71) return launch_one<MT, UNIT, PREF, BKT, 71, NWN, true>(grid, stream, p);
+                if (fl == 130) return launch_one<MT, UNIT, PREF, BKT, 130, NWN, true>(grid, stream, p);
+            }
+        }
         if constexpr (!PREF) {
             if (fl == 69) return launch_one<MT, UNIT, PREF, BKT, 69, NWN>(grid, stream, p);
             if (fl == 128) return launch_one<MT, UNIT, PREF, BKT, 128, NWN>(grid, stream, p);
@@ -386,7 +419,8 @@ extern "C" int mi_conv_gemm(const void* a, const void* wp, void* out, int B, int
             if ((force_mt == 0 || force_mt == mt) && cost(32 * mt, 256) < wbest * 0.999) wbest = cost(32 * mt, 256), wmt = mt;
         if (wmt) mt_sel = wmt, bn = 256;
     }
-    const bool pref = bn == 128 && pref_on && unit && (flags & MI_EPI_RESIDUAL) && N % 16 == 0;
+    const bool hot_set = flags == 71 || flags == 130;
+    const bool pref = bn == 128 && pref_on && unit && (flags & MI_EPI_RESIDUAL) && N % 16 == 0 && !(staged_on() && hot_set);
     if (!unit) mt_sel = 4;                               // the general (strided) gather exists in the 128-row shape only
     if (pref && mt_sel == 6) mt_sel = 5;                 // the prefetched rows cost 8 VGPRs per 16-row MFMA tile
     const int bm = mt_sel * 32;
