@@ -327,6 +327,49 @@ def test_errors_are_reported_not_thrown_across_the_abi():
         K.relu_mask(torch.zeros(8, dtype=torch.bfloat16), torch.zeros(8, dtype=torch.bfloat16))
 
 
+@pytest.mark.parametrize("B,H,W,ci,co,k,d", [(1, 1, 1, 64, 64, 1, 1), (1, 2, 3, 64, 72, 3, 1), (1, 5, 4, 128, 64, 3, 6), (3, 1, 7, 64, 8, 3, 2)])
+def test_tiny_and_ragged_conv_shapes(B, H, W, ci, co, k, d):
+    """Degenerate geometry: a single pixel, images smaller than the dilation (every off-centre tap is padding), N = 8 and
+    N = 72 (below / not a multiple of the 128-column tile), M far below one tile.  Forward, data and weight gradients
+    against fp32 torch on the same bf16 operands."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(B * 7 + H * 5 + W + co)
+    x = torch.randn(B, ci, H, W, generator=g).to(torch.bfloat16).float()
+    w = (torch.randn(co, ci, k, k, generator=g) * 0.1).to(torch.bfloat16).float()
+    dy = torch.randn(B, co, H, W, generator=g).to(torch.bfloat16).float()
+    pad = d if k == 3 else 0
+    xq = x.clone().requires_grad_(True)
+    wq = w.clone().requires_grad_(True)
+    y = F.conv2d(xq, wq, None, 1, pad, d)
+    y.backward(dy)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+    got = K.conv_gemm(xd, K.pack_weight_fwd(w.to(DEV)), (H, W), k, 1, pad, d, out_f32=True)
+    assert relmax(to_nchw(got), y.detach().numpy()) < 2e-5
+    if ci % 8 == 0 and co % 64 == 0:       # the data gradient contracts over co
+        dx = K.conv_gemm(dyd, K.pack_weight_dgrad(w.to(DEV)), (H, W), k, 1, pad, d, K.GATHER_DGRAD, out_f32=True)
+        assert relmax(to_nchw(dx), xq.grad.numpy()) < 2e-5
+    dw = torch.full((co, ci, k, k), float("nan"), device=DEV)
+    K.conv_wgrad(dyd, xd, dw, k, 1, pad, d)
+    assert relmax(dw.cpu().numpy(), wq.grad.numpy()) < 2e-5
+
+
+def test_tiny_upsample_ce_shapes():
+    """1x1 -> 1x1, 1x1 -> 5x3, 2x2 -> 2x2 (identity), one class: the fused upsample + CE against the unfused kernels."""
+    for (B, h, w, Kc, H, W) in ((1, 1, 1, 3, 1, 1), (2, 1, 1, 19, 5, 3), (1, 2, 2, 19, 2, 2), (1, 3, 2, 1, 7, 5)):
+        g = torch.Generator().manual_seed(h * 10 + W)
+        low = torch.randn(B, h, w, Kc, generator=g).to(DEV)
+        lab = torch.randint(0, Kc, (B, H, W), generator=g).to(DEV)
+        if H * W > 2:
+            lab[0, 0, 0] = 255
+        out, dlow = K.upsample_ce(low, lab)
+        up = K.upsample_ac_fwd(low, (H, W))
+        ref = K.softmax_ce_fwd(up, lab)
+        assert abs(out[0].item() - ref[0].item()) <= 1e-5 * max(1.0, abs(ref[0].item())) and out[1].item() == ref[1].item()
+        dref = K.upsample_ac_bwd(K.softmax_ce_bwd(up, lab, ref), (h, w))
+        assert relmax(dlow.cpu().numpy(), dref.cpu().numpy()) < 1e-4 or float(dref.abs().max()) < 1e-6
+
+
 def test_stem_bn_relu_maxpool_fused_vs_torch_ops():
     """Fused FrozenBN + ReLU + 3x3/2/1 max-pool (reference resnet.py:138-141) against the same chain of PyTorch ops on
     the GPU: forward bit-exact (bf16), backward within one bf16 ulp (up to 4 window contributions are summed)."""
