@@ -62,7 +62,7 @@ __device__ __forceinline__ void igemm_fetch_epilogue(const IgemmParams& p, int m
 // global memory; igemm_store_staged() then writes the tile out with row-contiguous lanes.
 template <int MT, int EPI, bool STAGED = false>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[4][MT], int m0, int n0, int wm, int wn, int frow, int fq,
-                                               bf16x8 (&pres)[MT][2], unsigned (&pbits)[MT], char* stage = nullptr) {
+                                               bf16x8 (&pres)[MT][2], unsigned (&pbits)[MT], char* stage = nullptr, bool mask_lds = false) {
     const int flags = EPI >= 0 ? EPI : p.flags;
     // ---- epilogue: lane owns pixel m (D col) and two groups of 8 contiguous channels: h = 0 -> nb .. nb+7 (MFMA tiles 0, 1),
     //      h = 1 -> nb+32 .. nb+39 (tiles 2, 3); tile i holds channels nb + 32*(i>>1) + 4*(i&1) + (0..3) ------------------------
@@ -157,7 +157,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
 #pragma unroll
                         for (int c = 0; c < 8; ++c) bits |= (v[2 * h + (c >> 2)][c & 3] > 0.f ? 1u : 0u) << c;
                     }
-                    reinterpret_cast<uint8_t*>(p.mask_out)[(o + 32 * h) >> 3] = (uint8_t)bits;
+                    if (STAGED && mask_lds)     // byte wn*8 + h*4 + fq of the row's 16 mask bytes, behind the bf16 image
+                        reinterpret_cast<uint8_t*>(stage)[MT * 32 * 256 + (wm * (MT * 16) + j * 16 + frow) * 16 + wn * 8 + h * 4 + fq] = (uint8_t)bits;
+                    else
+                        reinterpret_cast<uint8_t*>(p.mask_out)[(o + 32 * h) >> 3] = (uint8_t)bits;
                 }
             }
         }
@@ -222,6 +225,39 @@ __device__ __forceinline__ void igemm_residual_from_lds(const char* stage, int w
         const int row = wm * (MT * 16) + j * 16 + frow;
 #pragma unroll
         for (int h = 0; h < 2; ++h) pres[j][h] = *reinterpret_cast<const bf16x8*>(stage + row * 256 + (((wn * 8 + h * 4 + fq) ^ (row & 15)) << 4));
+    }
+}
+
+// The packed sign bits of a 128-column tile are 16 bytes per row.  From the MFMA layout they are touched 4 bytes per row per
+// instruction; through the LDS image behind the bf16 tile ([BM][16 B]) one lane moves a whole row's 16 bytes.  Only for
+// N % 128 == 0 (16-B aligned rows, no partial tile); otherwise the byte path stays.
+template <int MT>
+__device__ __forceinline__ void igemm_mask_to_lds(const IgemmParams& p, int m0, int n0, int tid, char* stage) {
+    if (tid < MT * 32) {
+        const int m = m0 + tid;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (m < p.M) v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(p.msk) + (((long)m * p.N + n0) >> 3));
+        *reinterpret_cast<u32x4*>(stage + MT * 32 * 256 + tid * 16) = v;
+    }
+}
+
+template <int MT>
+__device__ __forceinline__ void igemm_mask_from_lds(const char* stage, int wm, int wn, int frow, int fq, unsigned (&pbits)[MT]) {
+    const uint8_t* img = reinterpret_cast<const uint8_t*>(stage) + MT * 32 * 256;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int base = (wm * (MT * 16) + j * 16 + frow) * 16 + wn * 8 + fq;
+        pbits[j] = (unsigned)img[base] | ((unsigned)img[base + 4] << 8);
+    }
+}
+
+template <int MT>
+__device__ __forceinline__ void igemm_store_mask_staged(const IgemmParams& p, int m0, int n0, int tid, const char* stage) {
+    if (tid < MT * 32) {
+        const int m = m0 + tid;
+        if (m < p.M)
+            *reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(p.mask_out) + (((long)m * p.N + n0) >> 3)) =
+                *reinterpret_cast<const u32x4*>(stage + MT * 32 * 256 + tid * 16);
     }
 }
 

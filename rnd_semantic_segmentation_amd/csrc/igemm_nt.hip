@@ -272,17 +272,23 @@ __global__ __launch_bounds__((Geo<MT, BKT, NWN>::NW * 64), (Geo<MT, BKT, NWN>::O
         return;
     }
     if constexpr (STG) {
-        constexpr bool RES = (EPI & MI_EPI_RESIDUAL) != 0;
+        constexpr bool RES = (EPI & MI_EPI_RESIDUAL) != 0, BITS_IN = (EPI & MI_EPI_BITMASK) != 0, BITS_OUT = (EPI & MI_EPI_WRITE_MASK) != 0;
+        const bool mask_lds = (p.N & 127) == 0;          // uniform: 16-B aligned mask rows, no partial tile
         if (RES) igemm_residual_to_lds<MT>(p, m0, n0, wave, lane, zero, smem);
-        igemm_fetch_epilogue<MT, EPI, false>(p, m0, n0, wm, wn, frow, fq, pres, pbits);      // mask bytes only (registers)
-        if (RES) {
+        if (BITS_IN) {
+            if (mask_lds) igemm_mask_to_lds<MT>(p, m0, n0, tid, smem);
+            else igemm_fetch_epilogue<MT, EPI, false>(p, m0, n0, wm, wn, frow, fq, pres, pbits);      // mask bytes straight to registers
+        }
+        if (RES || BITS_IN) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            igemm_residual_from_lds<MT>(smem, wm, wn, frow, fq, pres);
+            if (RES) igemm_residual_from_lds<MT>(smem, wm, wn, frow, fq, pres);
+            if (BITS_IN && mask_lds) igemm_mask_from_lds<MT>(smem, wm, wn, frow, fq, pbits);
         }
-        igemm_epilogue<MT, EPI, true>(p, acc, m0, n0, wm, wn, frow, fq, pres, pbits, smem);
+        igemm_epilogue<MT, EPI, true>(p, acc, m0, n0, wm, wn, frow, fq, pres, pbits, smem, mask_lds);
         __syncthreads();
         igemm_store_staged<MT>(p, m0, n0, tid, smem);
+        if (BITS_OUT && mask_lds) igemm_store_mask_staged<MT>(p, m0, n0, tid, smem);
         return;
     }
     if (!PREF) igemm_fetch_epilogue<MT, EPI>(p, m0, n0, wm, wn, frow, fq, pres, pbits);
