@@ -21,10 +21,10 @@ def run(ci, co, label, res=True, k=1, d=1):
     by_min = (x.numel() + out.numel() * (2 if res else 1)) * 2
     cases = [(1 | 4 | (2 if res else 0) | 64, 'full')]
     cases += [(1 | 4 | 64, 'no-res')] if res else []
-    cases += [(1 << 30, 'nostore')]
+    cases += [(1 << 30, 'nostore'), (128 | (2 if res else 0), 'dgrad-bits')]
     for fl, name in cases:
         zg = 0
-        f = lambda: L.mi_conv_gemm(P(x), P(wp), P(out), B, H, H, ci, H, H, co, k, 1, d if k == 3 else 0, d, 0, P(sc), P(sh), P(r), None, P(bits), fl, zg,
+        f = lambda: L.mi_conv_gemm(P(x), P(wp), P(out), B, H, H, ci, H, H, co, k, 1, d if k == 3 else 0, d, 0, P(sc), P(sh), P(r), P(bits) if fl & 128 else None, P(bits), fl, zg,
                                    ctypes.c_float(0.0), st)
         t = timeit(f, 30)
         print('%-16s %-8s MT=%s %7.1f us  %6.0f TF  %5.2f TB/s(min traffic)' % (label, name, os.environ.get("MI_IGEMM_MT", "auto") + "/" + os.environ.get("MI_IGEMM_BN", "auto"), t * 1e6,
