@@ -119,3 +119,108 @@ def test_two_rank_gloo_gradient_average_and_trainer_step(tmp_path):
     oc.step()
     want = torch.cat([p.detach().reshape(-1) for p in list(fe.parameters()) + list(cls.parameters())]).numpy()
     assert np.abs(p0 - want).max() <= 2e-6 * np.abs(want).max()
+
+
+# ------------------------------------------------------------------------------------------------ FADA, two ranks
+def _fada_models():
+    fe, cls = _models()
+    D = ref_model.RefPixelDiscriminator(2048, 256, 19)
+    synth.load_formula_weights(D)
+    return fe, cls, D
+
+
+def _fada_batch(rank):
+    xs = torch.from_numpy(synth.synth_image(1, 33, 33, seed=300 + rank))
+    ys = torch.from_numpy(synth.synth_label(1, 33, 33, 19, seed=300 + rank))
+    xt = torch.from_numpy(synth.synth_image(1, 33, 33, seed=400 + rank))
+    return xs, ys, xt
+
+
+def _fada_worker(rank, world, port, tmpdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    try:
+        import logging
+        from rnd_semantic_segmentation_amd.host import fada
+        from rnd_semantic_segmentation_amd.host import trainer as tr
+        cfg = hc.CfgNode(hc.default_tree())
+        cfg.merge_from_list(["MODEL.NUM_CLASSES", 19, "MODEL.FREEZE_BN", True, "SOLVER.BASE_LR", 5e-4, "SOLVER.BASE_LR_D", 1e-4,
+                             "OUTPUT_DIR", tmpdir])
+        cfg.freeze()
+        tr.ASPPTrainer.build_feature_extractor = staticmethod(lambda cfg: _fada_models()[0])
+        tr.ASPPTrainer.build_classifier = staticmethod(lambda cfg: _fada_models()[1])
+        fada.FADAAdapter.build_adversarial_discriminator = staticmethod(lambda cfg: _fada_models()[2])
+        fada.setup_logger = lambda *a, **k: logging.getLogger("fada_ddp%d" % rank)
+        combo = fada.AsppFada("aspp_fada", cfg, [None] * 4, [None] * 4, rank)
+        assert combo.aspp.reducer is not None and combo.fada.reducer is not None and combo.fada.distributed
+        xs, ys, xt = _fada_batch(rank)
+        r = combo.train_step(xs, ys, xt, 40)
+        flat = torch.cat([p.detach().reshape(-1) for m in (combo.aspp.feature_extractor, combo.aspp.classifier, combo.fada.model_D)
+                          for p in m.parameters()])
+        np.save(os.path.join(tmpdir, "fada_params_%d.npy" % rank), flat.numpy())
+        np.save(os.path.join(tmpdir, "fada_losses_%d.npy" % rank), np.array([float(r[k]) for k in ("loss_seg", "loss_adv_tgt", "loss_D_src", "loss_D_tgt")]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_fada_iteration(tmp_path):
+    """AsppFada in a 2-rank job: generator-side gradients (two backward passes accumulate before ONE all-reduce) and the
+    discriminator's gradients are averaged over ranks, every rank ends with identical parameters, equal to a single process
+    applying the averaged gradients of the oracle's literal iteration."""
+    port = _free_port()
+    mp.spawn(_fada_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = np.load(tmp_path / "fada_params_0.npy"), np.load(tmp_path / "fada_params_1.npy")
+    assert np.array_equal(p0, p1)
+    # single-process expectation: run the literal iteration per rank WITHOUT optimizer steps to collect gradients at the two
+    # points of the iteration (generator step, discriminator step), average them, and apply the reference's updates.
+    import torch.nn.functional as F
+    T = 1.8
+    gen_grads, d_grads, losses = [], [], []
+    for r in range(2):
+        fe, cls, D = _fada_models()
+        xs, ys, xt = _fada_batch(r)
+        src_fea = fe(xs)
+        src_pred = cls(src_fea, xs.shape[-2:]).div(T)
+        loss_seg = F.cross_entropy(src_pred, ys.long(), ignore_index=255)
+        loss_seg.backward()
+        src_soft = F.softmax(src_pred, 1).detach()
+        src_soft[src_soft > 0.9] = 0.9
+        tgt_fea = fe(xt)
+        tgt_soft = F.softmax(cls(tgt_fea, xt.shape[-2:]).div(T), 1).detach()
+        tgt_soft[tgt_soft > 0.9] = 0.9
+        loss_adv = 0.001 * ref_model.ref_soft_label_cross_entropy(D(tgt_fea, xt.shape[-2:]), torch.cat((tgt_soft, torch.zeros_like(tgt_soft)), 1))
+        loss_adv.backward()
+        gen_grads.append({k: p.grad.clone() for m in (fe, cls) for k, p in m.named_parameters()})
+        for p in D.parameters():
+            p.grad = None
+        l_src = 0.5 * ref_model.ref_soft_label_cross_entropy(D(src_fea.detach(), xs.shape[-2:]), torch.cat((src_soft, torch.zeros_like(src_soft)), 1))
+        l_src.backward()
+        l_tgt = 0.5 * ref_model.ref_soft_label_cross_entropy(D(tgt_fea.detach(), xt.shape[-2:]), torch.cat((torch.zeros_like(tgt_soft), tgt_soft), 1))
+        l_tgt.backward()
+        d_grads.append({k: p.grad.clone() for k, p in D.named_parameters()})
+        losses.append([loss_seg.item(), loss_adv.item(), l_src.item(), l_tgt.item()])
+    # NOTE: the discriminator losses above are evaluated before the generator's SGD step, as in the reference (features are
+    # detached copies of the pre-update forward), so per-rank losses must match the workers' exactly
+    for r in range(2):
+        got = np.load(tmp_path / ("fada_losses_%d.npy" % r))
+        assert np.allclose(got, losses[r], rtol=1e-5), (r, got, losses[r])
+    fe, cls, D = _fada_models()
+    lr = 5e-4 * ((1 - 1 / 40) ** 0.9)
+    lr_d = 1e-4 * ((1 - 1 / 40) ** 0.9)
+    of, oc = ref_model.make_optimizers(fe, cls, 5e-4)
+    for g in of.param_groups:
+        g["lr"] = lr
+    for g in oc.param_groups:
+        g["lr"] = lr * 10
+    od = torch.optim.Adam(D.parameters(), lr=lr_d, betas=(0.9, 0.99))
+    for m in (fe, cls):
+        for k, p in m.named_parameters():
+            p.grad = (gen_grads[0][k] + gen_grads[1][k]) / 2
+    for k, p in D.named_parameters():
+        p.grad = (d_grads[0][k] + d_grads[1][k]) / 2
+    of.step()
+    oc.step()
+    od.step()
+    want = torch.cat([p.detach().reshape(-1) for m in (fe, cls, D) for p in m.parameters()]).numpy()
+    assert np.abs(p0 - want).max() <= 5e-6 * np.abs(want).max()
