@@ -357,6 +357,9 @@ extern "C" int mi_conv_gemm(const void* a, const void* wp, void* out, int B, int
     MI_REQUIRE(!(flags & MI_EPI_MASK) || (msk && mi_aligned16(msk)), "mi_conv_gemm: mask");
     MI_REQUIRE(!(flags & MI_EPI_BITMASK) || (msk && N % 16 == 0 && !(flags & MI_EPI_MASK)), "mi_conv_gemm: bit mask needs N %% 16 == 0");
     MI_REQUIRE(!(flags & MI_EPI_WRITE_MASK) || (mask_out && N % 16 == 0), "mi_conv_gemm: mask_out needs N %% 16 == 0");
+    // N % 128 == 0: the staged epilogue moves a tile row's 16 mask bytes at once (otherwise masks are touched bytewise)
+    MI_REQUIRE(!(flags & MI_EPI_BITMASK) || N % 128 != 0 || mi_aligned16(msk), "mi_conv_gemm: the packed sign bits must be 16-byte aligned");
+    MI_REQUIRE(!(flags & MI_EPI_WRITE_MASK) || N % 128 != 0 || mi_aligned16(mask_out), "mi_conv_gemm: mask_out must be 16-byte aligned");
     MI_REQUIRE(!(flags & MI_EPI_ZSPLIT) || (zgw > 0 && zgw % 4 == 0 && N % zgw == 0), "mi_conv_gemm: zgw");
     const long M = (long)B * Ho * Wo;
     MI_REQUIRE(M < (1L << 31) && (long)B * Ha * Wa < (1L << 31), "mi_conv_gemm: pixel count overflows int32");
