@@ -72,7 +72,9 @@ int mi_pack_weights_multi(const float* wflat, const float* sflat, void* wp_bf16,
  * the fused epilogue, the FrozenBN / ReLU / residual that follow it (resnet.py:93-113).
  *   out[b][ho][wo][n] = epi( sum_{t,c} a[b][src_h(ho,t)][src_w(wo,t)][c] * wp[t][n][c] )
  * a: [B][Ha][Wa][Ca] bf16, wp: [k*k][N][Ca] bf16, out: [B][Ho][Wo][N] bf16 (or fp32).
- * Requirements: Ca % 64 == 0, N % 4 == 0, 16-byte aligned pointers. */
+ * Requirements: Ca % 64 == 0, N % 8 == 0, 16-byte aligned pointers; N % 16 == 0 with MI_EPI_BITMASK / MI_EPI_WRITE_MASK
+ * (one uint16 of sign bits per 16 channels), and when N % 128 == 0 those packed-bit tensors must be 16-byte aligned too
+ * (a tile row's 16 mask bytes move as one access).  Violations return MI_EINVAL. */
 int mi_conv_gemm(const void* a, const void* wp, void* out,
                  int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N,
                  int ksize, int stride, int pad, int dil, int gather_mode,
@@ -83,13 +85,15 @@ int mi_conv_gemm(const void* a, const void* wp, void* out,
  * Replaces the weight-gradient half of convolution_backward.
  *   dw[o][i][t] (+)= scale[o] * sum_m dy[m][o] * x[src(m,t)][i]
  * dy: [B][Ho][Wo][O] bf16, x: [B][Ha][Wa][I] bf16, dw: fp32 OIHW.  O % 8 == 0, I % 8 == 0.
- * out_map 0: OIHW as above.  out_map 1 (ASPP): ksize must be 1 and o = (br*9+tap)*19+cls is scattered to
- * dw[br][cls][i][tap] of the 4 stacked [19][I][3][3] tensors. */
+ * out_map 0: OIHW as above (ncls ignored).  out_map 1 (ASPP): ksize must be 1 and row o = (br*9+tap)*ncls+cls of the
+ * [O][I] product (O >= 36*ncls, 36*ncls <= MI_ASPP_KPAD: the column layout mi_aspp_im2col writes) is scattered to
+ * dw[br][cls][i][tap] of the 4 stacked [ncls][I][3][3] tensors.  dw_elems = number of floats dw points at; the call
+ * fails with MI_EINVAL instead of writing past it. */
 size_t mi_conv_wgrad_workspace(int B, int Ho, int Wo, int O, int I, int ksize);
 int mi_conv_wgrad(const void* dy, const void* x, float* dw,
                   int B, int Ha, int Wa, int I, int Ho, int Wo, int O,
                   int ksize, int stride, int pad, int dil,
-                  const float* scale_o, int accumulate, int out_map,
+                  const float* scale_o, int accumulate, int out_map, int ncls, size_t dw_elems,
                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- ASPP head (reference core/models/classifiers/aspp/classifier.py:6-32) ---------------------
@@ -123,10 +127,12 @@ int mi_upsample_ac_fwd(const float* low, float* up, int B, int h, int w, int K, 
 int mi_upsample_ac_bwd(const float* dup, float* dlow, int B, int h, int w, int K, int H, int W, void* stream);
 
 /* ---- per-pixel softmax cross-entropy, ignore_index (core/trainers/aspp_trainer.py:61,91) --------
- * logits [B][K][H][W] fp32 NCHW, labels [B][H][W] int64.  loss_out[0] = mean over valid pixels
- * (nan if none), loss_out[1] = number of valid pixels.  workspace: mi_ce_workspace bytes. */
+ * logits [B][K][H][W] fp32 NCHW, labels [B][H][W] int64.  loss_out is FOUR floats: [0] = mean over valid pixels
+ * (nan if none), [1] = number of valid pixels, [2] = number of labels outside [0,K) that are not ignore_index (torch
+ * raises a device assert for those; here they are left out of the loss and reported - a non-zero count means the
+ * label map is wrong), [3] = scratch.  workspace: mi_ce_workspace bytes. */
 size_t mi_ce_workspace(int B, int H, int W);
-int mi_softmax_ce_fwd(const float* logits, const int64_t* labels, float* loss_out /*[2]*/,
+int mi_softmax_ce_fwd(const float* logits, const int64_t* labels, float* loss_out /*[4]*/,
                       int B, int K, int H, int W, int ignore_index, void* workspace, size_t workspace_bytes, void* stream);
 /* dlogits = (softmax - onehot) * valid / n_valid * grad_scale, n_valid read from loss_out[1] on device */
 int mi_softmax_ce_bwd(const float* logits, const int64_t* labels, const float* loss_out, float* dlogits,
@@ -135,11 +141,11 @@ int mi_softmax_ce_bwd(const float* logits, const int64_t* labels, const float* l
 /* ---- fused upsample + cross-entropy: never materialises the [B][K][H][W] tensor (training path) --
  * classifier(feat, size) + CrossEntropyLoss of reference aspp_trainer.py:89-91 in one call.
  * low [B][h][w][K] fp32 NHWC, labels [B][H][W] int64 (H >= h, W >= w, K <= 32).
- * loss_out[0] = mean loss over valid pixels, loss_out[1] = n_valid.
+ * loss_out (four floats, as mi_softmax_ce_fwd): [0] = mean loss over valid pixels, [1] = n_valid, [2] = out-of-range labels.
  * dlow (may be NULL: loss only) [B][h][w][K] = d loss / d low * grad_scale, already divided by n_valid.
  * Deterministic (fixed summation order, no atomics). */
 size_t mi_upsample_ce_workspace(int B, int h, int w, int K, int H, int W);
-int mi_upsample_ce(const float* low, const int64_t* labels, float* loss_out /*[2]*/, float* dlow,
+int mi_upsample_ce(const float* low, const int64_t* labels, float* loss_out /*[4]*/, float* dlow,
                    int B, int h, int w, int K, int H, int W, int ignore_index, float grad_scale,
                    void* workspace, size_t workspace_bytes, void* stream);
 

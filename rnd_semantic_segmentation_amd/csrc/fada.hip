@@ -261,12 +261,9 @@ extern "C" int mi_upsample_softce(const float* seg_low, float inv_temperature, f
     const int npx_max = npx_bound(ax);
     const size_t lds = ((size_t)npx_max * K2 + (size_t)npx_max * 2 + 256 + (JT + 4) + (size_t)(JT + 2) * (K + K2)) * 4;
     MI_REQUIRE(lds <= 160 * 1024, "mi_upsample_softce: upsample factor too large for one LDS tile (%zu B)", lds);
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        (void)hipFuncSetAttribute((const void*)softce_pass1_kernel<19>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)softce_pass1_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_set = lds;
-    }
+    static std::atomic<uint64_t> lds_set[2];
+    mi_allow_dynamic_lds((const void*)softce_pass1_kernel<19>, MI_LDS_MAX, lds_set[0]);
+    mi_allow_dynamic_lds((const void*)softce_pass1_kernel<0>, MI_LDS_MAX, lds_set[1]);
     if (K == 19)
         hipLaunchKernelGGL(softce_pass1_kernel<19>, dim3(tiles, H, B), dim3(256), lds, (hipStream_t)stream, seg_low, inv_temperature, clip, d_low,
                            ldD, domain, partial, tmp, B, K, ay, ax, npx_max);

@@ -306,13 +306,10 @@ inline bool staged_on() {        // MI_IGEMM_STAGED=0: MFMA-layout loads / store
 
 template <int MT, bool UNIT, bool PREF, int BKT, int EPI, int NWN, bool STG = false>
 void launch_one(dim3 grid, hipStream_t stream, const IgemmParams& p) {
-    static bool attr_done = false;
+    static std::atomic<uint64_t> attr_done{0};        // per instantiation, one bit per device
     auto kern = igemm_nt_kernel<MT, UNIT, PREF, BKT, EPI, NWN, STG>;
     constexpr int lds = Geo<MT, BKT, NWN>::LDS_BYTES;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_done = true;
-    }
+    mi_allow_dynamic_lds((const void*)kern, lds, attr_done);
     hipLaunchKernelGGL(kern, grid, dim3(Geo<MT, BKT, NWN>::NW * 64), lds, stream, p);
 }
 

@@ -275,13 +275,20 @@ extern "C" size_t mi_conv_wgrad_workspace(int B, int Ho, int Wo, int O, int I, i
 }
 
 extern "C" int mi_conv_wgrad(const void* dy, const void* x, float* dw, int B, int Ha, int Wa, int I, int Ho, int Wo, int O,
-                             int ksize, int stride, int pad, int dil, const float* scale_o, int accumulate, int out_map,
-                             void* workspace, size_t workspace_bytes, void* stream) {
+                             int ksize, int stride, int pad, int dil, const float* scale_o, int accumulate, int out_map, int ncls,
+                             size_t dw_elems, void* workspace, size_t workspace_bytes, void* stream) {
     MI_REQUIRE(dy && x && dw && workspace, "mi_conv_wgrad: null operand");
     MI_REQUIRE(B > 0 && Ha > 0 && Wa > 0 && Ho > 0 && Wo > 0, "mi_conv_wgrad: non-positive dimension");
     MI_REQUIRE(O % 8 == 0 && I % 8 == 0, "mi_conv_wgrad: O=%d, I=%d must be multiples of 8", O, I);
     MI_REQUIRE(ksize == 1 || ksize == 3, "mi_conv_wgrad: ksize");
     MI_REQUIRE(out_map == 0 || (out_map == 1 && ksize == 1), "mi_conv_wgrad: out_map 1 needs ksize 1");
+    // the reducer scatters into dw: bound it here (out_map 1 writes 4 stacked [ncls][I][3][3] tensors)
+    if (out_map == 1) {
+        MI_REQUIRE(ncls > 0 && 36 * ncls <= MI_ASPP_KPAD && O >= 36 * ncls, "mi_conv_wgrad: out_map 1 needs 0 < 36*ncls=%d <= min(O=%d, %d)", 36 * ncls, O, MI_ASPP_KPAD);
+        MI_REQUIRE(dw_elems >= (size_t)36 * ncls * I, "mi_conv_wgrad: dw holds %zu floats, the ASPP gradient needs %zu", dw_elems, (size_t)36 * ncls * I);
+    } else {
+        MI_REQUIRE(dw_elems >= (size_t)O * I * ksize * ksize, "mi_conv_wgrad: dw holds %zu floats, the gradient needs %zu", dw_elems, (size_t)O * I * ksize * ksize);
+    }
     MI_REQUIRE(mi_aligned16(dy) && mi_aligned16(x) && mi_aligned16(workspace), "mi_conv_wgrad: alignment");
     const long M = (long)B * Ho * Wo;
     MI_REQUIRE(M < (1L << 31) && (long)B * Ha * Wa < (1L << 31), "mi_conv_wgrad: pixel count overflows int32");
@@ -308,13 +315,10 @@ extern "C" int mi_conv_wgrad(const void* dy, const void* x, float* dw, int B, in
     p.S = pick_splits(M, p.o_tiles * p.i_tiles * p.T);
     const long steps = (M + KP - 1) / KP;
     p.rows_per_split = (int)(((steps + p.S - 1) / p.S) * KP);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)wgrad_tn_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)wgrad_tn_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)wgrad_tn_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_set[3];
+    mi_allow_dynamic_lds((const void*)wgrad_tn_kernel<0>, LDS_BYTES, attr_set[0]);
+    mi_allow_dynamic_lds((const void*)wgrad_tn_kernel<1>, LDS_BYTES, attr_set[1]);
+    mi_allow_dynamic_lds((const void*)wgrad_tn_kernel<2>, LDS_BYTES, attr_set[2]);
     const unsigned nblocks = (unsigned)(p.o_tiles * p.i_tiles * p.T * p.S);
     const bool unit = stride == 1 && Ha == Ho && Wa == Wo;
     if (unit && ksize == 1 && pad == 0)
@@ -324,12 +328,9 @@ extern "C" int mi_conv_wgrad(const void* dy, const void* x, float* dw, int B, in
     else
         hipLaunchKernelGGL(wgrad_tn_kernel<0>, dim3(nblocks), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
     MI_CHECK_LAUNCH("mi_conv_wgrad");
-    int o_real = O, ncls = 1;
-    if (out_map == 1) {
-        ncls = 19;
-        o_real = 36 * ncls;
-        MI_REQUIRE(O >= o_real, "mi_conv_wgrad: out_map 1 needs O >= 684");
-    }
+    int o_real = O;
+    if (out_map == 1) o_real = 36 * ncls;
+    else ncls = 1;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((I + (p.T == 1 ? 255 : 63)) / (p.T == 1 ? 256 : 64)), (unsigned)o_real), dim3(256), 0, (hipStream_t)stream, p.slab, dw,
                        scale_o, p.S, p.T, O, I, accumulate, out_map, ncls);
     MI_CHECK_LAUNCH("mi_conv_wgrad reduce");

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 #include "../../include/mi355seg.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -26,6 +27,19 @@ int mi_set_error(int code, const char* fmt, ...);
         hipError_t e_ = hipGetLastError();                                         \
         if (e_ != hipSuccess) return mi_set_error(MI_EHIP, "%s: %s", name, hipGetErrorString(e_)); \
     } while (0)
+
+// Kernels that need more than 64 KiB of dynamic LDS must be allowed to, once per (kernel, device): the attribute is
+// per device, so a process-wide "done" flag would leave the second device of a process launching without it.  One bit
+// per device ordinal; two racing threads both set the attribute (idempotent).
+static inline void mi_allow_dynamic_lds(const void* kern, int bytes, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done.fetch_or(bit, std::memory_order_release);
+}
+constexpr int MI_LDS_MAX = 160 * 1024;
 
 static inline bool mi_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 

@@ -117,14 +117,21 @@ __device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {
     __syncthreads();
 }
 
+// Labels outside [0, K) that are not ignore_index: torch.nn.CrossEntropyLoss raises a device assert; here they are excluded
+// from the loss AND counted (integer atomic: order-independent) so that the host can refuse the batch (loss_out[2]).
+__device__ __forceinline__ void count_bad_label(long lab, int K, int ignore_index, unsigned* bad) {
+    if (lab != ignore_index && (lab < 0 || lab >= K)) atomicAdd(bad, 1u);
+}
+
 __global__ void ce_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, float* __restrict__ partial,
-                              int B, int K, long HW, int ignore_index) {
+                              int B, int K, long HW, int ignore_index, unsigned* __restrict__ bad) {
     __shared__ float red[512];
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     float loss = 0.f, cnt = 0.f;
     if (idx < (long)B * HW) {
         const long b = idx / HW, pix = idx - b * HW;
         const long lab = labels[idx];
+        count_bad_label(lab, K, ignore_index, bad);
         if (lab != ignore_index && lab >= 0 && lab < K) {
             const float* p = logits + b * K * HW + pix;
             float mx = p[0];
@@ -153,6 +160,7 @@ __global__ void ce_finalize_kernel(const float* __restrict__ partial, int n, flo
     if (threadIdx.x == 0) {
         loss_out[0] = s / c;   // 0/0 = nan when every pixel is ignored, like torch
         loss_out[1] = c;
+        loss_out[2] = (float)*reinterpret_cast<const unsigned*>(loss_out + 3);      // out-of-range labels seen by pass 1
     }
 }
 
@@ -188,7 +196,7 @@ constexpr int JT = 32;
 template <int KT>
 __global__ __launch_bounds__(256) void upce_pass1_kernel(const float* __restrict__ low, const int64_t* __restrict__ labels,
                                                          float* __restrict__ partial, float* __restrict__ tmp, int B, int Krt, Axis ay,
-                                                         Axis ax, int ignore_index, int npx_max) {
+                                                         Axis ax, int ignore_index, int npx_max, unsigned* __restrict__ bad) {
     const int K = KT > 0 ? KT : Krt;
     constexpr int KR = KT > 0 ? KT : KMAX;          // register array length
     extern __shared__ __attribute__((aligned(16))) float sh[];
@@ -224,6 +232,7 @@ __global__ __launch_bounds__(256) void upce_pass1_kernel(const float* __restrict
         lam[px] = lx;
         const long lab = labels[((long)b * H + y) * W + x];
         float* d = dbuf + (long)px * K;
+        if (x0 >= j0) count_bad_label(lab, K, ignore_index, bad);       // once per pixel: by the tile that owns it
         if (lab == ignore_index || lab < 0 || lab >= K) {
             for (int k = 0; k < K; ++k) d[k] = 0.f;
             continue;
@@ -385,7 +394,9 @@ extern "C" int mi_softmax_ce_fwd(const float* logits, const int64_t* labels, flo
     MI_REQUIRE(logits && labels && loss_out && workspace && B > 0 && K > 0 && H > 0 && W > 0, "mi_softmax_ce_fwd: bad argument");
     if (workspace_bytes < mi_ce_workspace(B, H, W)) return mi_set_error(MI_ENOMEM, "mi_softmax_ce_fwd: workspace too small");
     const unsigned nb = nblk((long)B * H * W, 256);
-    hipLaunchKernelGGL(ce_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, logits, labels, (float*)workspace, B, K, (long)H * W, ignore_index);
+    unsigned* bad = reinterpret_cast<unsigned*>(loss_out + 3);
+    if (hipMemsetAsync(bad, 0, sizeof(unsigned), (hipStream_t)stream) != hipSuccess) return mi_set_error(MI_EHIP, "mi_softmax_ce_fwd: memset");
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, logits, labels, (float*)workspace, B, K, (long)H * W, ignore_index, bad);
     MI_CHECK_LAUNCH("mi_softmax_ce_fwd");
     hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (int)nb, loss_out);
     MI_CHECK_LAUNCH("mi_softmax_ce_fwd finalize");
@@ -423,18 +434,17 @@ extern "C" int mi_upsample_ce(const float* low, const int64_t* labels, float* lo
     const int npx_max = pass1_npx_max(ax);
     const size_t lds = (size_t)npx_max * K * 4 + (size_t)npx_max * 8 + 512 * 4 + (JT + 4) * 4 + (size_t)(JT + 2) * K * 4;
     MI_REQUIRE(lds <= 160 * 1024, "mi_upsample_ce: upsample factor too large for one LDS tile (%zu B)", lds);
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        (void)hipFuncSetAttribute((const void*)upce_pass1_kernel<19>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)upce_pass1_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_set = lds;
-    }
+    static std::atomic<uint64_t> lds_set[2];           // the launch size varies with the upsample factor: allow the maximum once per device
+    mi_allow_dynamic_lds((const void*)upce_pass1_kernel<19>, MI_LDS_MAX, lds_set[0]);
+    mi_allow_dynamic_lds((const void*)upce_pass1_kernel<0>, MI_LDS_MAX, lds_set[1]);
+    unsigned* bad = reinterpret_cast<unsigned*>(loss_out + 3);
+    if (hipMemsetAsync(bad, 0, sizeof(unsigned), (hipStream_t)stream) != hipSuccess) return mi_set_error(MI_EHIP, "mi_upsample_ce: memset");
     if (K == 19)
         hipLaunchKernelGGL(upce_pass1_kernel<19>, dim3(tiles, H, B), dim3(256), lds, (hipStream_t)stream, low, labels, partial, tmp, B, K, ay,
-                           ax, ignore_index, npx_max);
+                           ax, ignore_index, npx_max, bad);
     else
         hipLaunchKernelGGL(upce_pass1_kernel<0>, dim3(tiles, H, B), dim3(256), lds, (hipStream_t)stream, low, labels, partial, tmp, B, K, ay,
-                           ax, ignore_index, npx_max);
+                           ax, ignore_index, npx_max, bad);
     MI_CHECK_LAUNCH("mi_upsample_ce pass1");
     hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partial, B * H * tiles, loss_out);
     MI_CHECK_LAUNCH("mi_upsample_ce finalize");

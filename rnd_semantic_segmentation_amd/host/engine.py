@@ -449,7 +449,7 @@ class AsppEngine:
     def forward(self, x):
         """x [B,h,w,C] bf16 -> low [B,h,w,K] fp32 (1/8-resolution logits, classifier.py:27-29)."""
         B, h, w, _ = x.shape
-        z = K.conv_gemm(x, self.wall, (h, w), zsplit=K.ASPP_ZGW)
+        z = K.conv_gemm(x, self.wall, (h, w), zsplit=K.ASPP_ZGW, flop_cols=self.K)
         b4, _ = self._b4()
         return K.aspp_col2im(z, b4, B, h, w, self.K, self.rates)
 
@@ -468,10 +468,10 @@ class AsppEngine:
             stacked = all(s[0].data_ptr() == base + 4 * n * i for i, s in enumerate(slots)) and len({s[1] for s in slots}) == 1
             if stacked:
                 dw4 = torch.as_strided(slots[0][0], (4,) + tuple(ws[0].shape), (n,) + tuple(ws[0].stride()))
-                K.conv_wgrad(g, x, dw4, out_map=1, accumulate=slots[0][1])
+                K.conv_wgrad(g, x, dw4, out_map=1, ncls=self.K, accumulate=slots[0][1])
             else:
                 dw4 = torch.empty((4,) + tuple(ws[0].shape), dtype=torch.float32, device=x.device)
-                K.conv_wgrad(g, x, dw4, out_map=1)
+                K.conv_wgrad(g, x, dw4, out_map=1, ncls=self.K)
                 for i, (slot, acc) in enumerate(slots):
                     slot.add_(dw4[i]) if acc else slot.copy_(dw4[i])
             bslots = [grad_slot(p) for p in bs]
@@ -486,7 +486,7 @@ class AsppEngine:
 
         # off the critical path: runs beside the data-gradient GEMM below; joined right after it is enqueued
         _off_path(side, weight_and_bias_grads, g, x, dlow)
-        dx = K.conv_gemm(g, self.wallT, (h, w), msk=msk) if need_dx else None
+        dx = K.conv_gemm(g, self.wallT, (h, w), msk=msk, flop_cols=36 * self.K) if need_dx else None
         if side is not None:
             side.join()
         store = getattr(ws[0], "_mi_store", None)
@@ -530,7 +530,7 @@ class AsppLossFn(torch.autograd.Function):
         else:
             loss_out, dlow = K.upsample_ce(low, labels, want_grad=train, ignore_index=ignore_index)
         ctx.eng, ctx.x, ctx.dlow = eng, (x if train else None), dlow
-        ctx.loss_out = loss_out
+        ctx.loss_out = eng.last_loss_out = loss_out          # [loss, n_valid, out-of-range labels, -]: see K.check_labels
         return loss_out[0].clone()
 
     @staticmethod
@@ -561,6 +561,7 @@ class SoftmaxCEFn(torch.autograd.Function):
     def forward(ctx, logits, labels, ignore_index):
         logits = logits.contiguous()
         out = K.softmax_ce_fwd(logits, labels, ignore_index)
+        K.check_labels(out, logits.shape[1], "CrossEntropyLoss target")      # torch raises for these; this (unfused, API-parity) path syncs
         ctx.save_for_backward(logits, labels, out)
         ctx.ignore_index = ignore_index
         return out[0].clone()

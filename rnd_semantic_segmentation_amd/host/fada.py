@@ -401,6 +401,10 @@ class AsppFada:
         self.fada.model_D.train()
         start, end = time.time(), time.time()
         for epoch in range(self.fada.start_adv_epoch, self.cfg.SOLVER.EPOCHS + 1):
+            for loader in (self.aspp.train_loader, self.fada.tgt_train_loader):      # DistributedSampler: new order per epoch
+                sampler = getattr(loader, "sampler", None)
+                if hasattr(sampler, "set_epoch"):
+                    sampler.set_epoch(epoch)
             for (src_input, src_label, _), (tgt_input, _, _) in zip(self.aspp.train_loader, self.fada.tgt_train_loader):
                 data_time = time.time() - end
                 r = self.train_step(src_input, src_label, tgt_input, max_iter)

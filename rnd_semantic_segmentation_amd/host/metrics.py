@@ -171,7 +171,12 @@ def inference(feature_extractor, classifier, image, label, flip=True):
     if flip:
         image = torch.cat([image, torch.flip(image, [3])], 0)
     with torch.no_grad():
-        probs = classifier.predict_probs(feature_extractor(image), size)
+        feat = feature_extractor(image)
+        if hasattr(classifier, "predict_probs"):            # fused upsample + softmax kernel
+            probs = classifier.predict_probs(feat, size)
+        else:                                               # a substituted / foreign classifier: the reference's literal tail
+            probs = torch.nn.functional.softmax(
+                torch.nn.functional.interpolate(classifier(feat), size=size, mode="bilinear", align_corners=True), dim=1)
     if flip:
         out = (probs[0] + probs[1].flip(2)) / 2
     else:

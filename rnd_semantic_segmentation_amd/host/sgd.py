@@ -60,7 +60,9 @@ class FusedSGD(torch.optim.SGD):
             if not params[0].is_cuda:
                 raise RuntimeError("FusedSGD updates parameters on the MI355X; got %s" % params[0].device)
             st = getattr(params[0], "_mi_store", None)
-            whole = (st is not None and len(params) == len(st.params) and all(a is b for a, b in zip(params, st.params))
+            # the group covers a whole flat store (in any order: the optimizer keeps module.parameters() order for
+            # state_dict interchange with the reference, the store keeps the engine's layout)
+            whole = (st is not None and len(params) == len(st.params) and {id(p) for p in params} == {id(q) for q in st.params}
                      and st.intact() and all(p.grad.data_ptr() == st.grad.data_ptr() + 4 * p._mi_off for p in params))
             if whole:
                 for p in params:

@@ -59,8 +59,9 @@ class ASPPTrainer(BaseTrainer):
 
     @staticmethod
     def _ordered_params(module):
-        if hasattr(module, "engine_parameters") and getattr(module, "_store", None) is not None:
-            return [p for _, p in module.engine_parameters()]
+        """module.parameters() order, exactly what the reference hands torch.optim.SGD (aspp_trainer.py:25-26): the optimizer
+        state_dict is positional, so `optimizer_fea` / `optimizer_cls` of a checkpoint interchange only in this order
+        (the flat store may lay the tensors out differently; FusedSGD matches a store by membership, not by order)."""
         return list(module.parameters())
 
     def _load_checkpoint(self):
@@ -131,6 +132,10 @@ class ASPPTrainer(BaseTrainer):
         images = 0
 
         def flush():
+            lo = getattr(getattr(self.classifier, "_engine", None), "last_loss_out", None)
+            if lo is not None and pending:                  # the loss is fetched here anyway: one more float
+                from .. import kernels
+                kernels.check_labels(lo, self.cfg.MODEL.NUM_CLASSES, "train labels")
             for l, lr in pending:
                 v = float(l)
                 meters.update(loss_seg=v)
@@ -139,6 +144,9 @@ class ASPPTrainer(BaseTrainer):
             pending.clear()
 
         for epoch in range(self.start_epoch, self.cfg.SOLVER.EPOCHS + 1):
+            sampler = getattr(self.train_loader, "sampler", None)
+            if hasattr(sampler, "set_epoch"):                 # DistributedSampler: reshuffle per epoch like a single-process loader
+                sampler.set_epoch(epoch)
             for i, (src_input, src_label, _) in enumerate(self.train_loader):
                 data_time = time.time() - end
                 loss, lr = self.train_step(src_input, src_label, max_iter)

@@ -77,10 +77,11 @@ def pack_weights_multi(wflat, sflat, wp, wpt, table_dev, n_desc, total_blocks):
 
 
 def conv_gemm(a, wp, out_hw, ksize=1, stride=1, pad=0, dil=1, mode=GATHER_FWD, scale=None, bias=None, res=None,
-              msk=None, relu=False, out_f32=False, zsplit=0, out=None, bits=None, mask_out=None, leaky=0.0):
+              msk=None, relu=False, out_f32=False, zsplit=0, out=None, bits=None, mask_out=None, leaky=0.0, flop_cols=0):
     """out[b,ho,wo,n] = epi(sum_{t,c} a[b,src(ho,wo,t),c] * wp[t,n,c]);  a [B,Ha,Wa,Ca] bf16, wp [k*k,N,Ca] bf16.
     msk: bf16 [B,Ho,Wo,N] ReLU mask source; bits: the same mask as packed sign bits (int16 [B,Ho,Wo,N/16]);
-    mask_out: int16 [B,Ho,Wo,N/16] receiving the sign bits of the result."""
+    mask_out: int16 [B,Ho,Wo,N/16] receiving the sign bits of the result.
+    flop_cols: live columns of a padded ASPP operand (per zsplit plane, or of Ca == 704), for the FLOP accounting only."""
     _chk(a, torch.bfloat16, "a")
     _chk(wp, torch.bfloat16, "wp")
     B, Ha, Wa, Ca = a.shape
@@ -128,8 +129,8 @@ def conv_gemm(a, wp, out_hw, ksize=1, stride=1, pad=0, dil=1, mode=GATHER_FWD, s
     if out.numel() != B * Ho * Wo * N:
         raise _lib.MiError("out has %d elements, the conv writes %d" % (out.numel(), B * Ho * Wo * N))
     # algorithmic FLOPs (2 * pixels * C_out * C_in * k^2), padding columns of the ASPP operands excluded
-    n_real = N * 19 // 20 if zsplit else N
-    ca_real = 684 if Ca == ASPP_KPAD else Ca
+    n_real = N * flop_cols // zsplit if (zsplit and flop_cols) else N
+    ca_real = flop_cols if (Ca == ASPP_KPAD and flop_cols) else Ca
     flops = 2.0 * B * Ho * Wo * n_real * ca_real * ksize * ksize
     check(_timed("igemm_nt_kernel", flops, lambda: _lib.lib().mi_conv_gemm(
         _p(a), _p(wp), _p(out), B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, pad, dil, mode,
@@ -151,8 +152,9 @@ def _workspace(nbytes, device, tag="ws"):
     return buf
 
 
-def conv_wgrad(dy, x, dw, ksize=1, stride=1, pad=0, dil=1, scale=None, accumulate=False, out_map=0):
-    """dw[o,i,ky,kx] (+)= scale[o] * sum_m dy[m,o] x[src(m,t),i];  dy [B,Ho,Wo,O], x [B,Ha,Wa,I] bf16; dw fp32."""
+def conv_wgrad(dy, x, dw, ksize=1, stride=1, pad=0, dil=1, scale=None, accumulate=False, out_map=0, ncls=0):
+    """dw[o,i,ky,kx] (+)= scale[o] * sum_m dy[m,o] x[src(m,t),i];  dy [B,Ho,Wo,O], x [B,Ha,Wa,I] bf16; dw fp32.
+    out_map=1 (ASPP): dy is the im2col matrix with 36*ncls live columns, dw the 4 stacked [ncls,I,3,3] gradients."""
     _chk(dy, torch.bfloat16, "dy")
     _chk(x, torch.bfloat16, "x")
     _chk(dw, torch.float32, "dw")
@@ -161,11 +163,13 @@ def conv_wgrad(dy, x, dw, ksize=1, stride=1, pad=0, dil=1, scale=None, accumulat
     L = _lib.lib()
     need = L.mi_conv_wgrad_workspace(B, Ho, Wo, O, I, ksize)
     ws = _workspace(need, dy.device, "wgrad")
-    o_real = 684 if out_map == 1 else O
+    if out_map == 1 and not 0 < 36 * ncls <= O:
+        raise _lib.MiError("conv_wgrad(out_map=1) needs ncls with 36*ncls <= %d, got %r" % (O, ncls))
+    o_real = 36 * ncls if out_map == 1 else O
     flops = 2.0 * B * Ho * Wo * o_real * I * ksize * ksize
     check(_timed("wgrad_tn_kernel+reduce", flops, lambda: L.mi_conv_wgrad(
         _p(dy), _p(x), _p(dw), B, Ha, Wa, I, Ho, Wo, O, ksize, stride, pad, dil, _p(scale),
-        int(accumulate), out_map, _p(ws), ws.numel(), _stream()), tag=("wgrad", ksize, I, O, B * Ho * Wo, 0)), "mi_conv_wgrad")
+        int(accumulate), out_map, int(ncls), dw.numel(), _p(ws), ws.numel(), _stream()), tag=("wgrad", ksize, I, O, B * Ho * Wo, 0)), "mi_conv_wgrad")
     return dw
 
 
@@ -239,13 +243,13 @@ def upsample_ac_bwd(dup, low_hw):
 
 
 def softmax_ce_fwd(logits, labels, ignore_index=255):
-    """logits [B,K,H,W] fp32, labels [B,H,W] int64 -> loss_out fp32[2] = (mean loss, n_valid) on device"""
+    """logits [B,K,H,W] fp32, labels [B,H,W] int64 -> loss_out fp32[4] = (mean loss, n_valid, out-of-range labels, scratch)"""
     _chk(logits, torch.float32, "logits")
     _chk(labels, torch.int64, "labels")
     B, K, H, W = logits.shape
     L = _lib.lib()
     ws = _workspace(L.mi_ce_workspace(B, H, W), logits.device, "ce")
-    out = torch.empty(2, dtype=torch.float32, device=logits.device)
+    out = torch.empty(4, dtype=torch.float32, device=logits.device)
     check(L.mi_softmax_ce_fwd(_p(logits), _p(labels), _p(out), B, K, H, W, ignore_index, _p(ws), ws.numel(), _stream()),
           "mi_softmax_ce_fwd")
     return out
@@ -262,18 +266,27 @@ def softmax_ce_bwd(logits, labels, loss_out, grad_scale=1.0, ignore_index=255):
 
 
 def upsample_ce(low, labels, want_grad=True, grad_scale=1.0, ignore_index=255):
-    """Fused classifier-upsample + CrossEntropyLoss.  Returns (loss_out[2], dlow or None)."""
+    """Fused classifier-upsample + CrossEntropyLoss.  Returns (loss_out[4], dlow or None)."""
     _chk(low, torch.float32, "low")
     _chk(labels, torch.int64, "labels")
     B, h, w, K = low.shape
     _, H, W = labels.shape
     L = _lib.lib()
     ws = _workspace(L.mi_upsample_ce_workspace(B, h, w, K, H, W), low.device, "upce")
-    out = torch.empty(2, dtype=torch.float32, device=low.device)
+    out = torch.empty(4, dtype=torch.float32, device=low.device)
     dlow = torch.empty_like(low) if want_grad else None
     check(L.mi_upsample_ce(_p(low), _p(labels), _p(out), _p(dlow), B, h, w, K, H, W, ignore_index, float(grad_scale),
                            _p(ws), ws.numel(), _stream()), "mi_upsample_ce")
     return out, dlow
+
+
+def check_labels(loss_out, num_classes, what="labels"):
+    """Raise if the CE kernels saw labels outside [0, num_classes) that are not ignore_index (torch's device assert).
+    Synchronises (reads one float): call it where the loss value is fetched anyway."""
+    bad = int(loss_out[2].item())
+    if bad:
+        raise ValueError("%s: %d label values lie outside [0, %d) and are not ignore_index - torch.nn.CrossEntropyLoss would "
+                         "raise a device assert; map the label ids to train ids first" % (what, bad, num_classes))
 
 
 def upsample_softmax(low, size, want_pred=True):

@@ -47,6 +47,25 @@ def test_argument_validation_needs_no_gpu(built):
     assert built.mi_upsample_ce_workspace(8, 97, 97, 19, 769, 769) >= 8 * 769 * 97 * 19 * 4
 
 
+def test_documented_divisibility_rules_are_enforced(built):
+    """include/mi355seg.h: mi_conv_gemm needs Ca % 64 == 0, N % 8 == 0 (N % 16 with sign-bit masks); checked before any launch."""
+    one = ctypes.c_void_p(16)          # non-null, 16-byte aligned dummy: validation fails before it is dereferenced
+
+    def gemm(N, Ca=64, flags=0, mask_out=None):
+        return built.mi_conv_gemm(one, one, one, 1, 1, 1, Ca, 1, 1, N, 1, 1, 0, 1, 0, None, None, None, None, mask_out, flags, 0, 0.0, None)
+
+    assert gemm(4) == -22 and b"multiple of 8" in built.mi_last_error()
+    assert gemm(12) == -22 and b"multiple of 8" in built.mi_last_error()
+    assert gemm(8, Ca=32) == -22 and b"multiple of 64" in built.mi_last_error()
+    assert gemm(8, flags=64, mask_out=one) == -22 and b"N % 16" in built.mi_last_error()
+    # mi_conv_wgrad: out_map 1 is bounded by ncls and by the size of dw
+    ws = ctypes.c_void_p(4096)
+    rc = built.mi_conv_wgrad(one, one, one, 1, 4, 4, 64, 4, 4, 704, 1, 1, 0, 1, None, 0, 1, 2, 10, ws, 1 << 40, None)
+    assert rc == -22 and b"dw holds" in built.mi_last_error()
+    rc = built.mi_conv_wgrad(one, one, one, 1, 4, 4, 64, 4, 4, 704, 1, 1, 0, 1, None, 0, 1, 20, 1 << 30, ws, 1 << 40, None)
+    assert rc == -22 and b"36*ncls" in built.mi_last_error()
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))

@@ -202,7 +202,41 @@ def _aspp_forward(xd, w4, b4, rates=(6, 12, 18, 24)):
     B, H, W, C = xd.shape
     wall = K.aspp_pack_fwd(w4)
     z = K.conv_gemm(xd, wall, (H, W), zsplit=K.ASPP_ZGW)
-    return K.aspp_col2im(z, b4, B, H, W, 19, rates)
+    return K.aspp_col2im(z, b4, B, H, W, w4.shape[1], rates)
+
+
+@pytest.mark.parametrize("ncls", [2, 7])
+def test_aspp_head_other_class_counts_vs_oracle(ncls):
+    """MODEL.NUM_CLASSES != 19 (the reference ships deeplabv2_r101_src_kvasir.yaml with 2): every ASPP kernel takes K, the
+    weight-gradient scatter included (it used to assume 19 and wrote out of bounds)."""
+    B, C, H, W = 2, 64, 21, 19
+    x = synth.bf16_round(np.maximum(synth.uniform("aspp_k.x", (B, C, H, W)) * 4, 0))
+    ws = np.stack([synth.bf16_round(synth.formula_tensor("conv2d_list.%d.weight" % i, (ncls, C, 3, 3)) * 4) for i in range(4)])
+    bs = np.stack([synth.formula_tensor("conv2d_list.%d.bias" % i, (ncls,)) for i in range(4)])
+    dlow = synth.bf16_round(synth.uniform("aspp_k.dlow", (B, ncls, H, W)))
+    xd, w4, b4 = nhwc_bf16(x), dev(ws), dev(bs)
+    low = _aspp_forward(xd, w4, b4)
+    assert low.shape == (B, H, W, ncls)
+    assert relmax(to_nchw(low), ref_ops.aspp_head(x, ws, bs)) < 2e-5
+    dl = dev(dlow).permute(0, 2, 3, 1).contiguous()
+    gm = K.aspp_im2col(dl, (6, 12, 18, 24))
+    dx = K.conv_gemm(gm, K.aspp_pack_dgrad(w4), (H, W), out_f32=True)
+    dx_ref, dw_ref, db_ref = ref_ops.aspp_head_backward(dlow, x, ws)
+    assert relmax(to_nchw(dx), dx_ref) < 2e-5
+    guard = torch.full((4 * ncls * C * 9 + 4096,), 7.0, device=DEV)            # canary behind the gradient
+    dw4 = guard[:4 * ncls * C * 9].view(4, ncls, C, 3, 3)
+    K.conv_wgrad(gm, xd, dw4, out_map=1, ncls=ncls)
+    assert relmax(dw4.cpu().numpy(), np.stack(dw_ref)) < 2e-5
+    assert bool((guard[4 * ncls * C * 9:] == 7.0).all()), "weight-gradient scatter wrote past dw"
+    db4 = torch.empty_like(b4)
+    K.aspp_bias_grad(dl, db4)
+    assert relmax(db4.cpu().numpy(), np.stack(db_ref)) < 2e-5
+    # the C side refuses a dw that is too small or a class count that does not fit, instead of scattering out of bounds
+    from rnd_semantic_segmentation_amd._lib import MiError
+    with pytest.raises(MiError, match="dw holds"):
+        K.conv_wgrad(gm, xd, dw4[:3], out_map=1, ncls=ncls)
+    with pytest.raises(MiError):
+        K.conv_wgrad(gm, xd, dw4, out_map=1, ncls=20)
 
 
 def test_aspp_head_upsample_ce_vs_reference_golden():
@@ -240,7 +274,7 @@ def test_aspp_head_upsample_ce_vs_reference_golden():
     dx_ref, dw_ref, db_ref = ref_ops.aspp_head_backward(dlow_r, x, ws)
     assert relmax(to_nchw(dx), dx_ref) < 2e-5
     dw4 = torch.empty_like(w4)
-    K.conv_wgrad(gm, xd, dw4, out_map=1)
+    K.conv_wgrad(gm, xd, dw4, out_map=1, ncls=19)
     assert relmax(dw4.cpu().numpy(), np.stack(dw_ref)) < 2e-5
     db4 = torch.empty_like(b4)
     K.aspp_bias_grad(dlow, db4)

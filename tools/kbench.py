@@ -73,7 +73,7 @@ def main():
         fl = 2.0 * B * H * H * 684 * C
         t1 = timeit(lambda: K.conv_gemm(x, wall, (H, H), zsplit=K.ASPP_ZGW), args.iters)
         t2 = timeit(lambda: K.conv_gemm(g, wallT, (H, H), msk=x), args.iters)
-        t3 = timeit(lambda: K.conv_wgrad(g, x, dw4, out_map=1), args.iters)
+        t3 = timeit(lambda: K.conv_wgrad(g, x, dw4, out_map=1, ncls=19), args.iters)
         print("%-22s %6.0f %5.2f %6.0f %5.2f %6.0f %5.2f" % ("aspp Z / dX / dW", fl / t1 / 1e12, t1 * 1e3, fl / t2 / 1e12, t2 * 1e3, fl / t3 / 1e12, t3 * 1e3))
         for kk, t in (("fwd", t1), ("dgrad", t2), ("wgrad", t3)):
             tot[kk][0] += t
