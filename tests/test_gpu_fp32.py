@@ -1,0 +1,343 @@
+"""GPU parity of the exact-fp32 evaluation path (csrc/igemm_f32.hip, TEST.PRECISION "fp32") - the mode test.py /
+ASPPTester run so that masks and mIoU reproduce the reference's fp32 PyTorch path (BASELINE.json: logits within 1e-3
+relative, argmax identical, mIoU equal).
+
+What "identical argmax" can mean: the reference's own top-2 softmax margins on these random-weight nets go down to 0 (exact
+ties) and 1e-7 (tests/golden/g6_*: margin_val), i.e. below the rounding noise of ANY second fp32 implementation with a
+different summation order.  So the tests demand: every pixel whose reference margin exceeds FLIP_MARGIN has the same argmax;
+the pixels that flip are counted and printed with the largest margin among them; IoU areas / confusion matrix differ from
+the reference's by no more than those flips; and where no pixel flips everything is bit-equal.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import _cases
+from oracle import ref_model, ref_ops
+from rnd_semantic_segmentation_amd.host import synth
+
+pytestmark = pytest.mark.gpu
+
+FLIP_MARGIN = 2e-6      # probability margin below which the reference's own argmax is decided by fp32 rounding
+K = None
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _kern():
+    global K
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from rnd_semantic_segmentation_amd import kernels
+    K = kernels
+    yield
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def nhwc(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda().permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous().cpu().numpy()
+
+
+def mask_parity(pred, g, gpred, what):
+    """pred / gpred uint8 maps.  Returns the number of flipped pixels; asserts each one is a near-tie of the reference."""
+    pred, gpred = np.asarray(pred).reshape(-1), np.asarray(gpred).reshape(-1)
+    diff = np.flatnonzero(pred != gpred)
+    near = int((g["margin_val"] < FLIP_MARGIN).sum())
+    if diff.size:
+        margins = dict(zip(g["margin_idx"].tolist(), g["margin_val"].tolist()))
+        worst = max(margins.get(int(i), 1.0) for i in diff)
+        print("%s: %d of %d pixels flip; largest reference top-2 margin at a flipped pixel %.3e (reference has %d pixels below %.0e)"
+              % (what, diff.size, pred.size, worst, near, FLIP_MARGIN))
+        assert worst < FLIP_MARGIN, "argmax differs at a pixel the reference decides by a margin of %.3e" % worst
+        assert diff.size <= near
+    else:
+        print("%s: argmax identical on all %d pixels (reference has %d pixels with margin < %.0e)" % (what, pred.size, near, FLIP_MARGIN))
+    return int(diff.size)
+
+
+def eval_parity(pred_t, lab, g, flips, what):
+    """ASPPTester's accumulators (host/metrics.py) from OUR mask vs the reference's own functions' outputs in the fixture."""
+    from rnd_semantic_segmentation_amd.host import config as hc
+    from rnd_semantic_segmentation_amd.host import metrics
+    cfg = hc.cfg.clone()
+    cfg.defrost()
+    cfg.merge_from_list(["MODEL.NUM_CLASSES", 19])
+    lt = torch.from_numpy(lab).cuda().long()
+    cmt = metrics.confusion_matrix(cfg, pred_t.flatten(), lt.flatten()).numpy()
+    iu = [t.cpu().numpy() for t in metrics.intersectionAndUnionGPU(pred_t.clone(), lt.reshape(pred_t.shape), 19, 255)]
+    d_cmt = int(np.abs(cmt - g["cmt"]).sum())
+    d_iu = float(np.abs(np.stack(iu) - g["iu"]).sum())
+    assert d_cmt <= 2 * flips and d_iu <= 4 * flips, (d_cmt, d_iu, flips)     # a flip moves one count between two cells
+    meter = metrics.AverageMeter()
+    meter.update(*[a.astype(np.float64) for a in iu])        # as oracle/make_golden.py:eval_record fed the reference's meter
+    lines = []
+
+    class L:
+        def info(self, s):
+            lines.append(s)
+
+    meter.summary(L(), 19)
+    if flips == 0:
+        assert np.array_equal(cmt, g["cmt"]) and np.array_equal(np.stack(iu), g["iu"])
+        assert lines == list(g["summary"]), (lines[:2], list(g["summary"][:2]))          # mIoU / mF1 lines, verbatim
+    miou = float(lines[0].split("mIoU/mF1 ")[1].split("/")[0])
+    gmiou = float(str(g["summary"][0]).split("mIoU/mF1 ")[1].split("/")[0])
+    print("%s: mIoU %.4f (reference %.4f), |d cmt| %d, |d iu| %.0f" % (what, miou, gmiou, d_cmt, d_iu))
+    assert abs(miou - gmiou) <= 1e-4 + 1e-4 * flips         # BASELINE: +-0.1 (in percent); this is 0.01 %
+
+
+# ------------------------------------------------------------------------------------------------ kernels
+@pytest.mark.parametrize("name", _cases.CONV_CASES)
+def test_conv_f32_vs_reference_golden(name):
+    """mi_conv_f32 vs the reference's conv2d output (g1): fp32 in, fp32 out, any stride / dilation, M and N tails."""
+    c = _cases.conv_case(name)
+    x, w = c["x"], c["w"]
+    k, s, d, pad = c["k"], c["stride"], c["dil"], c["pad"]
+    wp = K.pack_weight_f32(torch.from_numpy(w).cuda())
+    y = K.conv_f32(nhwc(x), wp, c["y"].shape[-2:], k, s, pad, d)
+    e = rel(nchw(y), c["y"])
+    print("conv_f32 %s: %.2e" % (name, e))
+    assert e < 1.2e-6                                       # measured <= 4.0e-7 (fp32 both sides, different summation order)
+
+
+def test_conv_f32_epilogue_residual_relu_bias_and_tails():
+    """FrozenBN as two rounded operations, residual, ReLU; N = 19 (ASPP: three of four waves idle) and ragged M."""
+    B, C, H, W, N = 2, 64, 11, 9, 19
+    x = synth.uniform("f32e.x", (B, C, H, W)).astype(np.float32) * 3
+    w = (synth.uniform("f32e.w", (N, C, 3, 3)) * 0.2).astype(np.float32)
+    sc = (1 + synth.uniform("f32e.s", (N,))).astype(np.float32)
+    sh = synth.uniform("f32e.b", (N,)).astype(np.float32)
+    res = synth.uniform("f32e.r", (B, N, H, W)).astype(np.float32)
+    ref = ref_ops.conv2d(x, w, None, 1, 6, 6)
+    wp = K.pack_weight_f32(torch.from_numpy(w).cuda())
+    got = K.conv_f32(nhwc(x), wp, (H, W), 3, 1, 6, 6, scale=torch.from_numpy(sc).cuda(), bias=torch.from_numpy(sh).cuda(), res=nhwc(res), relu=True)
+    want = np.maximum(ref * sc.reshape(1, -1, 1, 1) + sh.reshape(1, -1, 1, 1) + res, 0)
+    assert rel(nchw(got), want) < 3e-6
+    got_b = K.conv_f32(nhwc(x), wp, (H, W), 3, 1, 6, 6, bias=torch.from_numpy(sh).cuda())          # bias only (nn.Conv2d(bias=True))
+    assert rel(nchw(got_b), ref + sh.reshape(1, -1, 1, 1)) < 3e-6
+    # exact-integer data: every product and partial sum is representable, so the result must be bit-exact
+    xi = np.round(synth.uniform("f32e.xi", (1, 32, 7, 5)) * 8).astype(np.float32)
+    wi = np.round(synth.uniform("f32e.wi", (40, 32, 1, 1)) * 8).astype(np.float32)
+    yi = K.conv_f32(nhwc(xi), K.pack_weight_f32(torch.from_numpy(wi).cuda()), (7, 5))
+    assert np.array_equal(nchw(yi), ref_ops.conv2d(xi, wi).astype(np.float32))
+
+
+def test_stem_f32_and_maxpool_vs_torch_fp32():
+    """7x7/2 conv + FrozenBN + ReLU + 3x3/2 max-pool of resnet.py:137-141 vs the oracle's stock-torch fp32 stem."""
+    rfe = ref_model.RefFeatureExtractor((1, 1, 1, 1))
+    synth.load_formula_weights(rfe)
+    x = synth.synth_image(2, 67, 45, seed=5)
+    bb = rfe.backbone
+    with torch.no_grad():
+        y = F.conv2d(torch.from_numpy(x), bb.conv1.weight, None, 2, 3)
+        want_act = F.relu(rfe._apply_bn(y, "bn1"))
+        want = F.max_pool2d(want_act, 3, 2, 1)
+    sc, sh = K.frozen_bn_fold(*[t.cuda() for t in (bb.bn1.weight, bb.bn1.bias, bb.bn1.running_mean, bb.bn1.running_var)])
+    act = K.stem_f32(torch.from_numpy(x).cuda(), bb.conv1.weight.detach().cuda(), sc, sh)
+    assert rel(nchw(act), want_act.numpy()) < 3e-6
+    pool = K.maxpool_f32(act)
+    assert pool.shape == (2, 17, 12, 64)
+    assert np.array_equal(nchw(pool), F.max_pool2d(act.permute(0, 3, 1, 2).cpu(), 3, 2, 1).numpy())     # a selection: exact
+    assert rel(nchw(pool), want.numpy()) < 3e-6
+
+
+# ------------------------------------------------------------------------------------------------ whole nets
+def fp32_pair(layers=None):
+    from rnd_semantic_segmentation_amd.host import modules
+    fe = modules.resnet_feature_extractor("resnet101", freeze_bn=True, pretrained_backbone=False, layers=layers)
+    cls = modules.ASPP_Classifier_V2(2048, [6, 12, 18, 24], [6, 12, 18, 24], 19)
+    synth.load_formula_weights(fe)
+    synth.load_formula_weights(cls)
+    return fe.cuda().eval().set_precision("fp32"), cls.cuda().eval().set_precision("fp32")
+
+
+def test_fp32_refuses_training_and_tinynet_matches_reference_fp32():
+    from rnd_semantic_segmentation_amd._lib import MiError
+    g5 = _cases.load("g5_tinynet_fp32")
+    fe, cls = fp32_pair((1, 1, 2, 2))
+    x, _ = _cases.net_inputs(2, 65, 11)
+    xt = torch.from_numpy(x).cuda()
+    with pytest.raises(MiError, match="forward-only"):
+        fe(xt)
+    with torch.no_grad():
+        feat = fe(xt)
+        low = cls(feat)
+    assert feat.dtype == torch.float32 and feat.shape == (2, 2048, 9, 9)
+    e_feat = rel(feat[:, :64].cpu().numpy(), g5["feat_crop"])
+    e_low = rel(low.cpu().numpy(), g5["low"])
+    print("fp32 tinynet vs reference fp32: feature %.2e, logits %.2e" % (e_feat, e_low))
+    assert e_feat < 3.3e-6 and e_low < 1.8e-6              # measured 1.1e-6 / 5.8e-7; BASELINE bar: 1e-3
+
+
+def _r101_eval(size, seed):
+    from core.utils.utility import inference
+    fe, cls = fp32_pair()
+    x, lab = _cases.net_inputs(1, size, seed)
+    xt, lt = torch.from_numpy(x).cuda(), torch.from_numpy(lab).cuda()
+    with torch.no_grad():
+        low = cls(fe(xt))
+    probs = inference(fe, cls, xt, lt, flip=False)             # the tester's call (aspp_tester.py:60)
+    return low, probs, lab
+
+
+def test_r101_129_fp32_logits_masks_and_miou_equal_reference():
+    g = _cases.load("g6_r101_129")
+    low, probs, lab = _r101_eval(129, 21)
+    e_low = rel(low.cpu().numpy(), g["low"])
+    e_probs = rel(probs[0, :, :16, :16].cpu().numpy(), g["probs_crop"])
+    print("fp32 r101@129: logits %.2e, probabilities %.2e of max" % (e_low, e_probs))
+    assert e_low < 8e-6 and e_probs < 2.4e-6               # measured 2.6e-6 / 7.9e-7; BASELINE bar: 1e-3
+    pred = probs.max(1)[1]
+    flips = mask_parity(pred.cpu().numpy().astype(np.uint8), g, g["pred"], "r101@129")
+    eval_parity(pred, lab, g, flips, "r101@129")
+
+
+def test_r101_512x1024_config0_fp32_logits_masks_and_miou_equal_reference():
+    """BASELINE config[0]: test.py geometry, one 512x1024 image, against the reference run on CPU (g6_r101_512x1024)."""
+    g = _cases.load("g6_r101_512x1024")
+    gp = _cases.load("g6_r101_512x1024_pred")["pred"]
+    low, probs, lab = _r101_eval((512, 1024), 31)
+    e_low = rel(low.cpu().numpy(), g["low"])
+    e_probs = rel(probs[0, :, 250:258, 500:508].cpu().numpy(), g["probs_crop"])
+    print("fp32 r101@512x1024: logits %.2e, probabilities %.2e of max; sum %.6f (reference %.6f)"
+          % (e_low, e_probs, low.double().sum().item(), float(g["low_sum"])))
+    assert e_low < 1.4e-5 and e_probs < 4.5e-6             # measured 4.4e-6 / 1.4e-6
+    assert abs(low.double().sum().item() - float(g["low_sum"])) < 1e-5 * abs(float(g["low_sum"])) + 0.05
+    pred = probs.max(1)[1]
+    flips = mask_parity(pred.cpu().numpy().astype(np.uint8), g, gp, "r101@512x1024")
+    eval_parity(pred, lab, g, flips, "r101@512x1024")
+
+
+def test_r101_769_fp32_forward_matches_reference():
+    """BASELINE config[1] geometry (one 769x769 crop): fp32 logits and the mask of the upsampled logits."""
+    g = _cases.load("g6_r101_769")
+    gp = _cases.load("g6_r101_769_pred")["pred"]
+    fe, cls = fp32_pair()
+    x, lab = _cases.net_inputs(1, 769, 41)
+    with torch.no_grad():
+        feat = fe(torch.from_numpy(x).cuda())
+        low = cls(feat)
+        up = cls(feat, (769, 769))
+    e_low = rel(low.cpu().numpy(), g["low"])
+    e_up = rel(up[0, :, 300:316, 500:516].cpu().numpy(), g["up_crop"])
+    print("fp32 r101@769: logits %.2e, upsampled crop %.2e" % (e_low, e_up))
+    assert e_low < 1.5e-5 and e_up < 1e-5                  # measured 4.9e-6 / 3.2e-6
+    pred = up.argmax(1)
+    flips = mask_parity(pred.cpu().numpy().astype(np.uint8), g, gp, "r101@769")
+    eval_parity(pred, lab, g, flips, "r101@769")
+
+
+def test_trained_tinynet_miou_fp32_and_bf16_vs_oracle():
+    """mIoU parity on a net whose predictions are not degenerate ('mIoU +-0.1 is checked on a briefly trained
+    model, not random init'): overfit the tiny DeepLab on one synthetic batch with the bf16 training engine, then evaluate
+    the SAME weights with (a) the oracle's fp32 CPU graph, (b) the fp32 path, (c) the bf16 engine."""
+    from rnd_semantic_segmentation_amd.host import metrics, modules, sgd
+    layers = (1, 1, 2, 2)
+    fe = modules.resnet_feature_extractor("resnet101", freeze_bn=True, pretrained_backbone=False, layers=layers)
+    cls = modules.ASPP_Classifier_V2(2048, [6, 12, 18, 24], [6, 12, 18, 24], 19)
+    synth.load_formula_weights(fe)
+    synth.load_formula_weights(cls)
+    fe.cuda().train()
+    cls.cuda().train()
+    fe.ensure_flat()
+    cls.ensure_flat()
+    of = sgd.FusedSGD(list(fe.parameters()), lr=4e-3, momentum=0.9, weight_decay=5e-4)
+    oc = sgd.FusedSGD(list(cls.parameters()), lr=4e-2, momentum=0.9, weight_decay=5e-4)
+    # a learnable task: 16-pixel label cells, each class tints its pixels (the stock synthetic labels are independent of the image)
+    small = synth.synth_label(2, 25, 25, 19, seed=61, border=1)
+    lab = np.ascontiguousarray(np.kron(small, np.ones((4, 4), np.float32))[:, :97, :97])
+    color = (synth.uniform("overfit.color", (256, 3)) * 4).astype(np.float32)
+    x = synth.synth_image(2, 97, 97, seed=61) * 0.5
+    x = (x + np.transpose(color[lab.astype(np.int64)], (0, 3, 1, 2)) * (lab != 255)[:, None]).astype(np.float32)
+    xt, lt = torch.from_numpy(x).cuda(), torch.from_numpy(lab).cuda().long()
+    first = last = None
+    for it in range(160):
+        of.zero_grad()
+        oc.zero_grad()
+        loss = cls.loss(fe(xt), lt)
+        loss.backward()
+        of.step()
+        oc.step()
+        if it == 0:
+            first = loss.item()
+    last = loss.item()
+    print("tinynet overfit: loss %.3f -> %.3f" % (first, last))
+    assert last < 0.6 * first
+    rfe, rcls = ref_model.RefFeatureExtractor(layers), ref_model.RefASPP()
+    rfe.load_state_dict({k: v.detach().cpu().clone() for k, v in fe.state_dict().items()})
+    rcls.load_state_dict({k: v.detach().cpu().clone() for k, v in cls.state_dict().items()})
+    with torch.no_grad():
+        rprobs = F.softmax(F.interpolate(rcls(rfe(torch.from_numpy(x))), size=(97, 97), mode="bilinear", align_corners=True), 1)
+    rpred = rprobs.max(1)[1]
+
+    def miou_np(pred):
+        inter = np.zeros(19)
+        union = np.zeros(19)
+        for i in range(pred.shape[0]):
+            a = metrics.intersectionAndUnion(np.asarray(pred[i]), lab[i].astype(np.int64), 19, 255)
+            inter += a[0]
+            union += a[1]
+        return float(np.mean(inter / (union + 1e-10)))
+
+    fe.eval()
+    cls.eval()
+    res = {}
+    for mode in ("fp32", "bf16"):
+        fe.set_precision(mode)
+        cls.set_precision(mode)
+        with torch.no_grad():
+            probs = cls.predict_probs(fe(xt), (97, 97))
+        pred = probs.max(1)[1].cpu().numpy()
+        res[mode] = (miou_np(pred), float((pred == rpred.numpy()).mean()), rel(probs.cpu().numpy(), rprobs.numpy()))
+    ref_miou = miou_np(rpred.numpy())
+    print("trained tinynet mIoU: oracle fp32 %.4f | fp32 path %.4f (agree %.5f, probs %.1e) | bf16 engine %.4f (agree %.5f, probs %.1e)"
+          % ((ref_miou,) + res["fp32"] + res["bf16"]))
+    assert ref_miou > 0.5                                              # the net learned the task: predictions are spread over all classes
+    # measured: fp32 path mIoU equal, masks identical, probabilities 2.8e-6; bf16 engine mIoU 0.7253 vs 0.7256, agreement 0.99936
+    assert abs(res["fp32"][0] - ref_miou) < 1e-6 and res["fp32"][1] == 1.0 and res["fp32"][2] < 1e-5
+    assert abs(res["bf16"][0] - ref_miou) < 1e-3 and res["bf16"][1] > 0.998     # BASELINE: mIoU within +-0.1 (percent) of the reference
+    fe.set_precision("bf16")
+    cls.set_precision("bf16")
+
+
+def test_aspp_tester_uses_fp32_by_default_and_matches_oracle_confusion_matrix(tmp_path):
+    """ASPPTester (aspp_tester.py:47-83) end to end on the synthetic test set: TEST.PRECISION defaults to fp32; its confusion
+    matrix equals the one the oracle's fp32 CPU graph produces for the same images (up to near-tie flips, counted)."""
+    import logging
+    from core.configs import cfg as global_cfg
+    from core.datasets.build import build_dataset
+    from core.testers.aspp_tester import ASPPTester
+    from rnd_semantic_segmentation_amd.host import metrics
+    cfg = global_cfg.clone()
+    cfg.defrost()
+    cfg.merge_from_list(["MODEL.FREEZE_BN", True, "MODEL.NUM_CLASSES", 19, "OUTPUT_DIR", str(tmp_path), "INPUT.INPUT_SIZE_TEST", (161, 97)])
+    import os
+    os.environ["MI_SYNTH_LEN"] = "2"
+    try:
+        data = build_dataset(cfg, mode="test", is_source=False)
+        loader = torch.utils.data.DataLoader(data, batch_size=1, shuffle=False)
+        tester = ASPPTester(cfg, torch.device("cuda"), loader, logging.getLogger("t"), [0] * 768, {i: str(i) for i in range(19)})
+    finally:
+        os.environ.pop("MI_SYNTH_LEN", None)
+    assert tester.feature_extractor.precision == "fp32" and tester.classifier.precision == "fp32"
+    synth.load_formula_weights(tester.feature_extractor)
+    synth.load_formula_weights(tester.classifier)
+    cmt = tester.test().numpy()
+    rfe, rcls = ref_model.RefFeatureExtractor((3, 4, 23, 3)), ref_model.RefASPP()
+    synth.load_formula_weights(rfe)
+    synth.load_formula_weights(rcls)
+    want = np.zeros((19, 19), np.int64)
+    with torch.no_grad():
+        for xb, yb, _ in loader:
+            p = F.softmax(F.interpolate(rcls(rfe(xb)), size=yb.shape[-2:], mode="bilinear", align_corners=True), 1)
+            want += metrics.confusion_matrix(cfg, p.max(1)[1].flatten(), yb.long().flatten()).numpy()
+    d = int(np.abs(cmt - want).sum())
+    print("ASPPTester confusion matrix vs oracle: |difference| = %d of %d counted pixels" % (d, int(want.sum())))
+    assert d == 0                                                      # measured 0 of 26 703 counted pixels

@@ -86,25 +86,26 @@ def test_tinynet_forward_backward_vs_rounding_emulating_oracle():
     r_low = rel(low.detach().float().cpu().numpy(), elow.detach().numpy())
     # bf16 storage of every activation: a different fp32 summation order flips roundings (1 ulp = 2^-8 of an element),
     # which propagates through 6 blocks; max error stays ~1e-2 of the logit range, the MEAN error must be far smaller
-    assert r_low < 2e-2, r_low
+    assert r_low < 9e-3, r_low                     # measured 3.0e-3
     mean_err = np.abs(low.detach().float().cpu().numpy() - elow.detach().numpy()).mean() / np.abs(elow.detach().numpy()).max()
+    print("tinynet: mean |low - emulated| / max = %.2e" % mean_err)
     assert mean_err < 2e-3, mean_err
     assert abs(loss.item() - eloss.item()) < 2e-3 * abs(eloss.item())
     # every parameter gradient: direction and size (bf16 gradient storage -> percent-level)
     ref_grads = {k: p.grad for m in (rfe, rcls) for k, p in m.named_parameters()}
     got = {k: p.grad for m in (fe, cls) for k, p in m.named_parameters()}
-    worst = 0.0
+    worst = worst_cos = 0.0
     for k, g in ref_grads.items():
         a = got[k].float().cpu().double().flatten()
         b = g.double().flatten()
         cos = torch.dot(a, b) / (a.norm() * b.norm() + 1e-300)
         ratio = a.norm() / (b.norm() + 1e-300)
-        worst = max(worst, 1 - cos.item(), abs(ratio.item() - 1))
+        worst, worst_cos = max(worst, abs(ratio.item() - 1)), max(worst_cos, 1 - cos.item())
         # gradients are stored bf16 between kernels and this net has only 2x9x9 pixels at layers 3-4, so each weight
-        # gradient is a short noisy sum: direction within cos 0.98, norm within 5 % (the 3-step loss test below pins
-        # the update itself to the reference to 1e-5)
-        assert cos > 0.98 and abs(ratio - 1) < 0.05, (k, cos.item(), ratio.item())
-    print("tinynet: rel(low)=%.2e worst grad deviation=%.3e" % (r_low, worst))
+        # gradient is a short noisy sum (the 3-step loss test below pins the update itself to the reference to 1e-5);
+        # bars = 3x the measured worst case (1 - cos 1.6e-2 at most, norm ratio within 1.6 %)
+        assert 1 - cos < 0.045 and abs(ratio - 1) < 0.045, (k, cos.item(), ratio.item())
+    print("tinynet: rel(low)=%.2e worst gradient deviation: 1-cos %.3e, |norm ratio - 1| %.3e" % (r_low, worst_cos, worst))
 
 
 def test_tinynet_vs_reference_golden_fp32_and_bf16_regime():
@@ -145,7 +146,7 @@ def test_tinynet_three_sgd_steps_track_reference_losses():
         oc.step()
         losses.append(loss.item())
     print("losses", losses, "reference", g5["loss"])
-    assert np.allclose(losses, g5["loss"], rtol=3e-2)
+    assert np.allclose(losses, g5["loss"], rtol=3e-5)              # measured 8e-6 (bf16 engine vs the fp32 reference)
     assert losses[2] < losses[0]
     # momentum buffers keep torch's state_dict format
     sd = oc.state_dict()
@@ -176,15 +177,99 @@ def test_r101_129_vs_reference_golden_and_dropin_api():
         up = cls(feat, (129, 129))
     e_low = rel(low.float().cpu().numpy(), g["low"])
     print("r101@129 low vs reference fp32: %.3e (|low|max %.2f)" % (e_low, np.abs(g["low"]).max()))
-    assert e_low < 5e-2                                                   # bf16 regime through 33 blocks
+    assert e_low < 3e-2                                                   # bf16 regime through 33 blocks; measured 9.9e-3
     probs = inference(fe, cls, xt, lt, flip=False)
     assert probs.shape == (1, 19, 129, 129)
     pred = probs.max(1)[1]
     agree = (pred.cpu().numpy().astype(np.uint8) == g["pred"]).mean()
     print("argmax agreement with the fp32 reference: %.4f" % agree)
-    assert agree > 0.85            # random-weight nets have near-tied logits (88.6 % measured for bf16 autocast)
+    assert agree > 0.99            # measured 0.9969 (the reference's own bf16-autocast run agrees 0.9968: g9_r101_129_bf16)
     assert torch.equal(pred, up.argmax(1))                               # same tensor through both API routes
     inter, union, target, res = intersectionAndUnionGPU(pred.clone(), lt.long(), 19, 255)
     assert float(target.sum()) == float((lab != 255).sum())
     # flip=True path runs
     assert inference(fe, cls, xt, lt, flip=True).shape == (1, 19, 129, 129)
+
+
+def _product_r101():
+    from rnd_semantic_segmentation_amd.host import modules
+    fe = modules.resnet_feature_extractor("resnet101", freeze_bn=True, pretrained_backbone=False)
+    cls = modules.ASPP_Classifier_V2(2048, [6, 12, 18, 24], [6, 12, 18, 24], 19)
+    synth.load_formula_weights(fe)
+    synth.load_formula_weights(cls)
+    return fe.cuda(), cls.cuda()
+
+
+def test_config0_512x1024_bf16_engine_vs_reference_golden():
+    """BASELINE config[0] geometry (test.py, one 512x1024 image) on the bf16 training engine against the reference's fp32 CPU run
+    (g6_r101_512x1024).  bf16 regime: the exact-fp32 evaluation path is pinned to the same fixture in test_gpu_fp32.py."""
+    g = _cases.load("g6_r101_512x1024")
+    gp = _cases.load("g6_r101_512x1024_pred")["pred"]
+    fe, cls = _product_r101()
+    fe.eval()
+    cls.eval()
+    x, lab = _cases.net_inputs(1, (512, 1024), 31)
+    xt = torch.from_numpy(x).cuda()
+    with torch.no_grad():
+        feat = fe(xt)
+        low = cls(feat)
+        probs = cls.predict_probs(feat, (512, 1024))
+    assert low.shape == (1, 19, 64, 128)
+    e_low = rel(low.float().cpu().numpy(), g["low"])
+    e_sum = abs(low.double().sum().item() - float(g["low_sum"])) / abs(float(g["low_sum"]))
+    pred = probs.max(1)[1].cpu().numpy().astype(np.uint8)
+    agree = float((pred == gp).mean())
+    e_probs = rel(probs[0, :, 250:258, 500:508].cpu().numpy(), g["probs_crop"])
+    print("bf16 r101@512x1024 vs reference fp32: logits %.3e of max, sum %.3e, probs crop %.3e, argmax agreement %.5f" % (e_low, e_sum, e_probs, agree))
+    # measured 1.1e-2 / 2.1e-2 / 0.99783 / 4.0e-3; bars = 3x
+    assert e_low < 3.4e-2 and e_sum < 6.4e-2 and agree > 0.9935 and e_probs < 1.2e-2
+
+
+def test_r101_769_bf16_training_step_vs_reference_golden():
+    """BASELINE config[1] geometry, one 769x769 crop: fused ASPP + upsample + CE loss and the full hand-written backward of the
+    bf16 engine against the reference's fp32 autograd (g6_r101_769: loss, per-stage gradient norms, bias gradient)."""
+    g = _cases.load("g6_r101_769")
+    fe, cls = _product_r101()
+    fe.train()
+    cls.train()
+    fe.ensure_flat()
+    cls.ensure_flat()
+    x, lab = _cases.net_inputs(1, 769, 41)
+    feat = fe(torch.from_numpy(x).cuda())
+    assert feat.shape == (1, 2048, 97, 97)
+    loss = cls.loss(feat, torch.from_numpy(lab).cuda().long())
+    loss.backward()
+    e_loss = abs(loss.item() - float(g["loss"])) / abs(float(g["loss"]))
+    e_low = rel(cls.last_low.float().cpu().numpy(), g["low"])
+    stage = {}
+    for m in (fe, cls):
+        for k, p in m.named_parameters():
+            s = k.split(".")[1] if k.startswith("backbone.") else "aspp"
+            stage[s] = float(np.sqrt(stage.get(s, 0.0) ** 2 + float(p.grad.double().norm()) ** 2))
+    names = [str(n) for n in g["stage_names"]]
+    ratios = np.array([stage[n] for n in names]) / g["stage_grad_norm"]
+    bg = dict(cls.named_parameters())["conv2d_list.0.bias"].grad.cpu().numpy()
+    e_bias = rel(bg, g["aspp0_bias_grad"])
+    print("bf16 r101@769 train step vs reference fp32: loss %.3e, logits %.3e, stage grad-norm ratios %s, aspp bias grad %.3e"
+          % (e_loss, e_low, np.round(ratios, 4).tolist(), e_bias))
+    # measured: loss 2.0e-4, logits 1.1e-2, norms within 0.9 %, bias gradient 3.6e-3; bars = 3x
+    assert e_loss < 6e-4 and e_low < 3.4e-2
+    assert np.all(np.abs(ratios - 1) < 0.027) and e_bias < 1.1e-2
+
+
+def test_r101_129_bf16_engine_vs_reference_under_cpu_autocast():
+    """SURVEY 8c G9 for the full net: the engine's logits sit as close to the fp32 reference as the reference's own bf16 autocast
+    run does (same regime), and its mask agrees with the fp32 reference at least as often."""
+    g32, g16 = _cases.load("g6_r101_129"), _cases.load("g9_r101_129_bf16")
+    fe, cls = _product_r101()
+    fe.eval()
+    cls.eval()
+    x, lab = _cases.net_inputs(1, 129, 21)
+    with torch.no_grad():
+        feat = fe(torch.from_numpy(x).cuda())
+        low = cls(feat).float().cpu().numpy()
+        pred = cls.predict_probs(feat, (129, 129)).max(1)[1].cpu().numpy().astype(np.uint8)
+    e_ours, e_ref16 = rel(low, g32["low"]), rel(g16["low"], g32["low"])
+    a_ours, a_ref16 = float((pred == g32["pred"]).mean()), float((g16["pred"] == g32["pred"]).mean())
+    print("r101@129 vs fp32 reference: engine %.3e (agree %.4f) | reference under CPU bf16 autocast %.3e (agree %.4f)" % (e_ours, a_ours, e_ref16, a_ref16))
+    assert e_ours < 1.5 * e_ref16 + 1e-3 and a_ours > a_ref16 - 0.01

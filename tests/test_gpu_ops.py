@@ -284,6 +284,116 @@ def test_aspp_head_upsample_ce_vs_reference_golden():
     assert relmax(dw4.cpu().numpy(), g["dw"]) < 4e-3
 
 
+def test_aspp_head_2048_channels_17x17_vs_reference_golden():
+    """SURVEY 8c G2: the head at its real width (2048 input channels) on a 17x17 map, where every rate reaches the padding;
+    forward, data gradient, weight gradient (out_map 1) and bias gradient against the reference's autograd (g2_aspp_2048)."""
+    g = _cases.load("g2_aspp_2048")
+    C, H, Kc = 2048, 17, 19
+    ws = np.stack([synth.bf16_round(synth.formula_tensor("conv2d_list.%d.weight" % i, (Kc, C, 3, 3)) * 4) for i in range(4)])
+    bs = np.stack([synth.formula_tensor("conv2d_list.%d.bias" % i, (Kc,)) for i in range(4)])
+    x = synth.bf16_round(np.maximum(synth.uniform("g2b.x", (1, C, H, H)) * 2, 0))
+    dl = synth.bf16_round(synth.uniform("g2b.dlow", (1, Kc, H, H)))
+    assert _cases.sha(x) + _cases.sha(ws) + _cases.sha(dl) == str(g["in_sha"]), "input formulas drifted from the fixture"
+    xd, w4, b4 = nhwc_bf16(x), dev(ws), dev(bs)
+    low = _aspp_forward(xd, w4, b4)
+    e_low = relmax(to_nchw(low), g["low"])
+    dld = dev(dl).permute(0, 2, 3, 1).contiguous()
+    gm = K.aspp_im2col(dld, (6, 12, 18, 24))
+    dx = K.conv_gemm(gm, K.aspp_pack_dgrad(w4), (H, H), out_f32=True)
+    e_dx = relmax(to_nchw(dx)[0, :96], g["dx_crop"])
+    dw4 = torch.empty_like(w4)
+    K.conv_wgrad(gm, xd, dw4, out_map=1, ncls=Kc)
+    e_dw = relmax(dw4.cpu().numpy()[:, :, :48], g["dw_crop"])
+    db4 = torch.empty_like(b4)
+    K.aspp_bias_grad(dld, db4)
+    print("aspp 2048x17x17: low %.2e dx %.2e dw %.2e |dx| %.6f (ref %.6f)" % (e_low, e_dx, e_dw, dx.double().norm().item(), float(g["dx_norm"])))
+    assert e_low < 2e-5 and e_dx < 2e-5 and e_dw < 2e-5                    # operands are bf16-exact on both sides
+    assert abs(dx.double().norm().item() - float(g["dx_norm"])) < 1e-5 * float(g["dx_norm"])
+    assert abs(dw4.double().norm().item() - float(g["dw_norm"])) < 1e-5 * float(g["dw_norm"])
+    assert relmax(db4.cpu().numpy(), g["db"]) < 2e-5
+
+
+def test_upsample_13x21_to_97x161_and_large_logits_vs_reference_golden():
+    """non-square, non-integer scale; and |logit| up to 60 with near-one-hot rows (the fused kernel uses the
+    hardware exp / log: VERDICT r1 weak 11)."""
+    g = _cases.load("g3_upsample_13x21")
+    low = synth.uniform("g3b.low", (2, 19, 13, 21)).astype(np.float32) * 6
+    lab = synth.synth_label(2, 97, 161, 19, seed=13)
+    assert _cases.sha(low) + _cases.sha(lab) == str(g["in_sha"])
+    lowd, labd = dev(low).permute(0, 2, 3, 1).contiguous(), dev(lab, torch.int64)
+    up = K.upsample_ac_fwd(lowd, (97, 161))
+    assert relmax(up.cpu().numpy()[:, :, ::4, ::5], g["up_sub"]) < 2e-6
+    lo, dlow = K.upsample_ce(lowd, labd)
+    assert abs(lo[0].item() - float(g["loss"])) < 2e-6 * abs(float(g["loss"]))
+    assert lo[2].item() == 0
+    assert relmax(to_nchw(dlow), g["dlow"]) < 2e-5
+    lo_u = K.softmax_ce_fwd(up, labd)
+    dup = K.softmax_ce_bwd(up, labd, lo_u)
+    assert relmax(dup.cpu().numpy()[:, :, ::4, ::5], g["dup_sub"]) < 2e-5
+    assert relmax(to_nchw(K.upsample_ac_bwd(dup, (13, 21))), g["dlow"]) < 2e-5
+    # large logits
+    g = _cases.load("g3_upsample_large_logits")
+    low = (synth.uniform("g3c.low", (1, 19, 9, 11)).astype(np.float32) * 120).astype(np.float32)
+    lab = synth.synth_label(1, 65, 81, 19, seed=17)
+    assert _cases.sha(low) + _cases.sha(lab) == str(g["in_sha"])
+    lowd, labd = dev(low).permute(0, 2, 3, 1).contiguous(), dev(lab, torch.int64)
+    lo, dlow = K.upsample_ce(lowd, labd)
+    e_loss = abs(lo[0].item() - float(g["loss"])) / abs(float(g["loss"]))
+    e_d = relmax(to_nchw(dlow), g["dlow"])
+    probs, _ = K.upsample_softmax(lowd, (65, 81))
+    e_p = relmax(probs.cpu().numpy()[:, :, ::3, ::4], g["probs_sub"])
+    print("large logits: loss %.2e dlow %.2e probs %.2e" % (e_loss, e_d, e_p))
+    assert e_loss < 2e-6 and e_d < 2e-5 and e_p < 2e-6
+
+
+def test_out_of_range_labels_are_counted_not_silently_ignored():
+    """torch.nn.CrossEntropyLoss raises a device assert for a label outside [0,K) that is not ignore_index; the kernels
+    count such pixels (loss_out[2]) and the host refuses them."""
+    low = dev(synth.uniform("oor.low", (1, 9, 7, 19)).astype(np.float32))
+    lab = synth.synth_label(1, 33, 25, 19, seed=4)
+    lab[0, 10, 5:9] = 33            # raw Cityscapes id, not a train id
+    lab[0, 20, 3] = -1
+    labd = dev(lab, torch.int64)
+    lo, _ = K.upsample_ce(low, labd)
+    assert lo[2].item() == 5
+    with pytest.raises(ValueError, match="5 label values"):
+        K.check_labels(lo, 19)
+    up = K.upsample_ac_fwd(low, (33, 25))
+    assert K.softmax_ce_fwd(up, labd)[2].item() == 5
+    from rnd_semantic_segmentation_amd.host import modules
+    with pytest.raises(ValueError, match="outside"):
+        modules.CrossEntropyLoss(255)(up, labd)
+
+
+def test_metrics_on_device_bit_exact_vs_reference_golden():
+    """A9 on the device path: intersectionAndUnionGPU / confusion_matrix on CUDA tensors, exact integers vs g7 (the reference's
+    utility.py:133-161,347-359 outputs)."""
+    from rnd_semantic_segmentation_amd.host import config as hc
+    from rnd_semantic_segmentation_amd.host import metrics
+    g = _cases.load("g7_metrics")
+    pred, target, t2 = (torch.from_numpy(g[k]).cuda() for k in ("pred", "target", "target2"))
+    for tgt, want in ((target, g["iu"]), (t2, g["iu2"])):
+        out = metrics.intersectionAndUnionGPU(pred.clone(), tgt, 19, 255)
+        assert all(o.is_cuda for o in out)
+        assert np.array_equal(np.stack([o.cpu().numpy() for o in out]), want.astype(np.float32))
+    cfg = hc.cfg.clone()
+    cfg.defrost()
+    cfg.merge_from_list(["MODEL.NUM_CLASSES", 19])
+    cmt = metrics.confusion_matrix(cfg, torch.from_numpy(g["small_p"]).cuda(), torch.from_numpy(g["small_t"]).cuda())
+    assert cmt.dtype == torch.int64 and np.array_equal(cmt.numpy(), g["cmt"])
+    meter = metrics.AverageMeter()
+    for tgt in (target, t2):
+        meter.update(*[o.cpu().numpy().astype(np.float64) for o in metrics.intersectionAndUnionGPU(pred.clone(), tgt, 19, 255)])
+    lines = []
+
+    class L:
+        def info(self, s):
+            lines.append(s)
+
+    meter.summary(L(), 19)
+    assert lines == [str(s) for s in g["summary"]]
+
+
 def test_upsample_integer_scale_all_ignored_and_inference_tail():
     c = _cases.upsample_case()
     g = c["g"]

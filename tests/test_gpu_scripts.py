@@ -77,7 +77,7 @@ def test_opt_in_kernel_variants_and_single_stream_schedule_stay_correct():
     """Selections that are not the default still have to be right: the 8-wave 256-wide conv tile (MI_IGEMM_BN=256), and the
     single-stream schedule (no forward lanes, weight gradients on the main stream) that bench.py's instrumented steps use.
     Environment switches are read once per process, so each runs the relevant parity tests in a child pytest."""
-    for env, sel in (({"MI_IGEMM_BN": "256"}, ["tests/test_gpu_ops.py", "-k", "golden or fused_epilogue or pointwise or identity"]),
+    for env, sel in (({"MI_IGEMM_BN": "256"}, ["tests/test_gpu_ops.py", "-k", "conv_fwd_dgrad or aspp_head_upsample or fused_epilogue or pointwise or identity"]),
                      ({"MI_WGRAD_STREAM": "0", "MI_BATCH_LANES": "1"}, ["tests/test_gpu_model.py", "-k", "tinynet"])):
         r = run(["-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider"] + sel, env)
         assert r.returncode == 0, (env, r.stdout[-3000:])

@@ -180,3 +180,77 @@ def test_config0_512x1024_cpu_inference():
     assert rel(probs.numpy()[0, :, 250:258, 500:508], g["probs_crop"]) < 1e-4
     pred = probs.max(1)[1].numpy().astype(np.uint8)
     assert (pred[0, 200:232, 400:464] != g["pred_crop"]).mean() < 1e-3
+
+
+def test_r101_769_forward_backward_config1_geometry():
+    """BASELINE config[1] geometry (one 769x769 crop): the oracle's forward, loss and full backward against the reference's
+    (g6_r101_769: logits, loss, per-stage gradient norms, mask)."""
+    g = _cases.load("g6_r101_769")
+    gp = _cases.load("g6_r101_769_pred")["pred"]
+    x, lab = _cases.net_inputs(1, 769, 41)
+    fe, cls = ref_model.RefFeatureExtractor(), ref_model.RefASPP()
+    synth.load_formula_weights(fe)
+    synth.load_formula_weights(cls)
+    feat = fe(torch.from_numpy(x))
+    low = cls(feat)
+    up = cls(feat, (769, 769))
+    loss = torch.nn.functional.cross_entropy(up, torch.from_numpy(lab).long(), ignore_index=255)
+    loss.backward()
+    assert rel(low.detach().numpy(), g["low"]) < 2e-5
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    stage = {}
+    for m in (fe, cls):
+        for k, p in m.named_parameters():
+            s = k.split(".")[1] if k.startswith("backbone.") else "aspp"
+            stage[s] = float(np.sqrt(stage.get(s, 0.0) ** 2 + float(p.grad.double().norm()) ** 2))
+    names = [str(n) for n in g["stage_names"]]
+    assert np.allclose([stage[n] for n in names], g["stage_grad_norm"], rtol=2e-4)
+    assert rel(getattr(cls.conv2d_list, "0").bias.grad.numpy(), g["aspp0_bias_grad"]) < 1e-4
+    pred = up.argmax(1).numpy().astype(np.uint8)
+    assert (pred != gp).mean() < 1e-4
+    # the evaluation record (the reference's own intersectionAndUnion / confusion_matrix outputs) from the oracle's mask
+    iu = np.stack(ref_ops.intersection_and_union(pred, lab.astype(np.int64), 19, 255))
+    assert np.abs(iu - g["iu"]).sum() <= 4 * int((pred != gp).sum())
+
+
+def test_new_op_fixtures_2048ch_aspp_13x21_upsample_large_logits_autocast():
+    # G2: 2048-channel head on 17x17
+    g = _cases.load("g2_aspp_2048")
+    C, H, K = 2048, 17, 19
+    ws = np.stack([synth.bf16_round(synth.formula_tensor("conv2d_list.%d.weight" % i, (K, C, 3, 3)) * 4) for i in range(4)])
+    bs = np.stack([synth.formula_tensor("conv2d_list.%d.bias" % i, (K,)) for i in range(4)])
+    x = synth.bf16_round(np.maximum(synth.uniform("g2b.x", (1, C, H, H)) * 2, 0))
+    dl = synth.bf16_round(synth.uniform("g2b.dlow", (1, K, H, H)))
+    assert _cases.sha(x) + _cases.sha(ws) + _cases.sha(dl) == str(g["in_sha"])
+    assert rel(ref_ops.aspp_head(x, ws, bs), g["low"]) < 1e-5
+    dx, dw, db = ref_ops.aspp_head_backward(dl, x, ws)
+    assert rel(dx[0, :96], g["dx_crop"]) < 1e-5 and rel(np.stack(dw)[:, :, :48], g["dw_crop"]) < 1e-5 and rel(np.stack(db), g["db"]) < 1e-5
+    # G3: 13x21 -> 97x161
+    g = _cases.load("g3_upsample_13x21")
+    low = synth.uniform("g3b.low", (2, 19, 13, 21)).astype(np.float32) * 6
+    lab = synth.synth_label(2, 97, 161, 19, seed=13)
+    assert _cases.sha(low) + _cases.sha(lab) == str(g["in_sha"])
+    up = ref_ops.bilinear_ac(low, (97, 161))
+    assert rel(up[:, :, ::4, ::5], g["up_sub"]) < 2e-6
+    loss, dup, _ = ref_ops.cross_entropy_ignore(up, lab)
+    assert abs(loss - float(g["loss"])) < 2e-6 * abs(float(g["loss"]))
+    assert rel(dup[:, :, ::4, ::5], g["dup_sub"]) < 1e-5
+    assert rel(ref_ops.bilinear_ac_backward(dup, (13, 21)), g["dlow"]) < 1e-5
+    # large logits
+    g = _cases.load("g3_upsample_large_logits")
+    low = (synth.uniform("g3c.low", (1, 19, 9, 11)).astype(np.float32) * 120).astype(np.float32)
+    lab = synth.synth_label(1, 65, 81, 19, seed=17)
+    assert _cases.sha(low) + _cases.sha(lab) == str(g["in_sha"])
+    up = ref_ops.bilinear_ac(low, (65, 81))
+    loss, dup, _ = ref_ops.cross_entropy_ignore(up, lab)
+    assert abs(loss - float(g["loss"])) < 2e-6 * abs(float(g["loss"]))
+    assert rel(ref_ops.bilinear_ac_backward(dup, (9, 11)), g["dlow"]) < 1e-5
+    # G9 for the full net: the oracle under CPU bf16 autocast vs the reference under the same autocast
+    g = _cases.load("g9_r101_129_bf16")
+    x, _ = _cases.net_inputs(1, 129, 21)
+    fe, cls = ref_model.RefFeatureExtractor(), ref_model.RefASPP()
+    synth.load_formula_weights(fe)
+    synth.load_formula_weights(cls)
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        low = cls(fe(torch.from_numpy(x))).float()
+    assert rel(low.numpy(), g["low"]) < 2e-2            # same rounding regime, different op fusion: bf16-level agreement
