@@ -81,6 +81,17 @@ int mi_conv_gemm(const void* a, const void* wp, void* out,
                  const float* scale, const float* bias, const void* res, const void* msk, void* mask_out,
                  int flags, int zgw, float alpha, void* stream);
 
+/* The wide-tile main loop of mi_conv_gemm (csrc/igemm_pp.hip: 320|256 x 256 tile, 8 waves in two groups that alternate
+ * between MFMA and LDS/DMA phases, 4-slot LDS ring) called explicitly.  Same contract and epilogue flags, restricted to
+ * stride 1, Ha == Ho, Wa == Wo, Ca % 32 == 0.  mi_conv_gemm picks it by its own cost model; this entry point exists so that
+ * the two main loops can be compared on one shape in one process.  mtg: 16-row MFMA tiles per wave (8 or 10 -> 256 or 320
+ * tile rows), 0 = choose. */
+int mi_conv_gemm_pp(const void* a, const void* wp, void* out,
+                    int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N,
+                    int ksize, int stride, int pad, int dil, int gather_mode,
+                    const float* scale, const float* bias, const void* res, const void* msk, void* mask_out,
+                    int flags, int zgw, float alpha, int mtg, void* stream);
+
 /* ---- weight gradient (contraction over pixels), split-K with deterministic reduction ------------
  * Replaces the weight-gradient half of convolution_backward.
  *   dw[o][i][t] (+)= scale[o] * sum_m dy[m][o] * x[src(m,t)][i]

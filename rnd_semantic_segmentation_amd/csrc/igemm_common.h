@@ -77,6 +77,23 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
             ebi[i] = *reinterpret_cast<const f32x4*>(p.bias + n);
         }
     }
+    // Everything the row loop below consumes must have LANDED before the loop: the loop body sits behind per-row exec-mask
+    // branches (m < M, n < N), and hipcc places the s_waitcnt for a pending load inside the first conditional block that uses
+    // it - a path that skips that block still has the load pending, so EVERY later block gets its own s_waitcnt vmcnt(0),
+    // which also waits for the previous block's stores: ten dependent HBM round trips per tile.  A no-op asm that reads the
+    // registers puts the one wait here, in straight-line code.
+    if (flags & MI_EPI_SCALE_BIAS) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(esc[i]), "v"(ebi[i]));
+    }
+    if (flags & MI_EPI_RESIDUAL) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) asm volatile("" ::"v"(pres[j][0]), "v"(pres[j][1]));
+    }
+    if (flags & MI_EPI_BITMASK) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) asm volatile("" ::"v"(pbits[j]));
+    }
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
         const int m = m0 + wm * (MT * 16) + j * 16 + frow;

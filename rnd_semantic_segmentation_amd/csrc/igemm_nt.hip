@@ -338,6 +338,10 @@ void launch_variant(dim3 grid, hipStream_t stream, const IgemmParams& p) {
 
 }  // namespace
 
+extern "C" int mi_conv_gemm_pp(const void* a, const void* wp, void* out, int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N, int ksize,
+                               int stride, int pad, int dil, int gather_mode, const float* scale, const float* bias, const void* res,
+                               const void* msk, void* mask_out, int flags, int zgw, float alpha, int mtg, void* stream);
+
 extern "C" int mi_conv_gemm(const void* a, const void* wp, void* out, int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N,
                             int ksize, int stride, int pad, int dil, int gather_mode, const float* scale, const float* bias,
                             const void* res, const void* msk, void* mask_out, int flags, int zgw, float alpha, void* stream) {
@@ -363,6 +367,19 @@ extern "C" int mi_conv_gemm(const void* a, const void* wp, void* out, int B, int
     if (gather_mode == MI_GATHER_FWD) {
         MI_REQUIRE((Ho - 1) * stride - pad < Ha && (Wo - 1) * stride - pad < Wa, "mi_conv_gemm: output larger than the input supports");
     }
+    // Long contractions without a residual tile go to the wide-tile ping-pong main loop (igemm_pp.hip): 7.0 instead of 13-14
+    // L2 bytes per kFLOP.  Measured per shape against this kernel in one process (tools/ppexp.py, B = 8, 97 x 97): 3x3 256 +16 %,
+    // 3x3 512 +13 %, 1x1 2048->512 +18 %, 1x1 1024->256 / 1024->2048 / ASPP forward +6 %; the short contractions (K <= 704)
+    // are epilogue-bound and stay here.  MI_IGEMM_PP=0 switches the dispatch off.
+    static int pp_on = -1;
+    if (pp_on < 0) {
+        const char* e = getenv("MI_IGEMM_PP");
+        pp_on = e ? atoi(e) : 1;
+    }
+    if (pp_on && stride == 1 && Ha == Ho && Wa == Wo && !(flags & (MI_EPI_RESIDUAL | MI_EPI_MASK | MI_EPI_LEAKY)) && (long)ksize * ksize * Ca >= 1024 &&
+        M >= 320 * 64 && N >= 256)
+        return mi_conv_gemm_pp(a, wp, out, B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, pad, dil, gather_mode, scale, bias, res, msk, mask_out, flags, zgw,
+                               alpha, 0, stream);
     IgemmParams p;
     p.A = (const __bf16*)a;
     p.Wp = (const __bf16*)wp;

@@ -1,0 +1,283 @@
+// Implicit-GEMM convolution, wide-tile "ping-pong" main loop for gfx950 (bf16 operands, fp32 MFMA accumulate).
+//
+//   out[m][n] = epi( sum_t sum_c A[src(m,t)][c] * Wp[t][n][c] )      same contract and epilogue as igemm_nt.hip, for the
+// stride-1 convs / plain GEMMs with a long contraction (K = taps * Ca >= 1024): the dilated 3x3 family of layer3 / layer4
+// (reference core/components/resnet.py:22-25, 100) and the ASPP head's GEMMs (classifiers/aspp/classifier.py:26-29).
+//
+// Why a second main loop: every conv launch of the 128-wide kernel fits one model - time = bytes the L2 hands to the LDS /
+// ~13 TB/s - so the lever is bytes per FLOP, i.e. the tile.  This kernel computes a (2*16*MTG) x 256
+// tile per workgroup (320 x 256: 7.0 B/kFLOP against 13-14 for the 128-wide tiles) with ONE workgroup of 8 waves per CU, and
+// replaces the co-resident second workgroup (which used to hide the DMA drain and the barrier of every K-step) by structure:
+//   * K advances in 32-channel slabs through a 4-slot LDS ring; three slabs are always in flight (global_load_lds, counted
+//     s_waitcnt vmcnt, raw s_barrier - a __syncthreads() would drain the DMA queue);
+//   * the 8 waves are two groups of 4 (one wave of each group per SIMD).  Group 0 owns the upper half of the tile's rows,
+//     group 1 the lower half, each wave 16*MTG rows x 64 columns.  The groups run the same loop half a phase apart: while one
+//     group issues its MFMAs for slab p, the other reads its fragments of slab p (or p+1) from LDS and issues its share of
+//     the DMA for slab p+3.  The matrix pipe of a SIMD is thus handed from one wave to the other at every barrier and never
+//     waits for LDS or DMA.
+// Intervals (I_k lies between barriers B_k and B_k+1):    I_2p: G0 read(p) | G1 mfma(p-1)      I_2p+1: G0 mfma(p) | G1 read(p)
+//   every wave waits for ITS DMA pieces of slab p+1 (vmcnt, two younger slabs stay in flight) at the end of I_2p+1, so that
+//   after B_2p+2 the slab is visible to group 0 and after B_2p+3 to group 1;
+//   slab p+3 lands in the slot of slab p-1, whose last reader (G1 in I_2p-1) finished its ds_reads (lgkmcnt(0)) before B_2p.
+// LDS image of a slab: A rows then W rows, 64 B (32 channels) per row, lane-linear per 1-KiB DMA piece (16 rows); the 16-B chunk
+// c of row r sits at chunk c ^ s(r), applied to the per-lane SOURCE address and to the ds_read_b128 address, with
+// s_A(r) = (-(r >> 2)) & 3 and s_W(r) = ((r >> 3) & 1) << 1: both make every ds_read_b128 lane group hit 64 distinct banks
+// (brute-forced over the instruction's four 16-lane groups; W rows are read in the permuted order of igemm_nt.hip).
+#include "igemm_common.h"
+
+namespace {
+
+template <int MTG> struct PPGeo {
+    static constexpr int BMG = 16 * MTG, BM = 2 * BMG, BN = 256;
+    static constexpr int SLAB_A = BM * 64, SLAB_W = BN * 64, SLAB = SLAB_A + SLAB_W;
+    static constexpr int NSLOT = 4, LDS_BYTES = NSLOT * SLAB;          // MTG 10: 144 KiB, MTG 8: 128 KiB
+    static constexpr int PA = BM / 16;                                // A pieces per slab (16 rows each), moved by group 0
+    static constexpr int NPA = PA / 4;                                // ... per wave of group 0
+    static constexpr int NPW = 4;                                     // W pieces per wave of group 1 (16 pieces per slab)
+    static_assert(PA % 4 == 0, "the A pieces must split evenly over the four waves of group 0");
+};
+
+template <int MTG, int EPI>
+__global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmParams p) {
+    using G = PPGeo<MTG>;
+    constexpr int BM = G::BM, BN = G::BN, BMG = G::BMG, SLAB = G::SLAB, SLAB_A = G::SLAB_A, NPA = G::NPA, NPW = G::NPW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wq = wave & 3;
+    const int nwg = p.m_tiles * p.n_tiles;
+    const int tile = mi_xcd_remap(blockIdx.x, nwg);
+    const int mt = tile / p.n_tiles, nt = tile - mt * p.n_tiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+    // ---- DMA roles: group 0 moves the A rows (NPA pieces per wave), group 1 the W rows (NPW pieces per wave) ------------------
+    const int prow = lane >> 2, pch = lane & 3;
+    const int sgn = (p.mode == MI_GATHER_FWD) ? 1 : -1;
+    const bool pointwise = p.T == 1 && p.pad == 0;
+    const char* d_base[NPA > NPW ? NPA : NPW];      // per piece: source of tap (0,0) / tap 0, channel 0 (+ swizzled chunk)
+    unsigned d_mask[NPA > NPW ? NPA : NPW];         // A: 9-bit tap validity; W: row < N
+    if (grp == 0) {
+        const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            const int row = (wq * NPA + i) * 16 + prow;
+            const int m = m0 + row;
+            const bool ok = m < p.M;
+            const int chunk = (pch ^ ((-(row >> 2)) & 3)) * 16;
+            if (pointwise) {
+                d_base[i] = reinterpret_cast<const char*>(p.A + (long)(ok ? m : 0) * p.Ca) + chunk;
+                d_mask[i] = ok ? 1u : 0u;
+                continue;
+            }
+            const int mm = ok ? m : 0;
+            const int b = mm / HoWo, rem = mm - b * HoWo;
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            const int h0 = ho - sgn * p.pad, w0 = wo - sgn * p.pad;          // tap (0,0) source; Ha == Ho, Wa == Wo (stride 1)
+            d_base[i] = reinterpret_cast<const char*>(p.A + ((long)b * p.Ha * p.Wa + (long)h0 * p.Wa + w0) * p.Ca) + chunk;
+            unsigned rb = 0, cb = 0;
+#pragma unroll
+            for (int kq = 0; kq < 3; ++kq) {
+                const bool live = kq < p.ksz;
+                rb |= (unsigned)(live & ((unsigned)(h0 + sgn * kq * p.dil) < (unsigned)p.Ha)) << kq;
+                cb |= (unsigned)(live & ((unsigned)(w0 + sgn * kq * p.dil) < (unsigned)p.Wa)) << kq;
+            }
+            unsigned msk;
+            if (p.ksz == 1) msk = rb & cb & 1u;
+            else msk = ((rb & 1u) ? cb : 0u) | ((rb & 2u) ? cb << 3 : 0u) | ((rb & 4u) ? cb << 6 : 0u);
+            d_mask[i] = ok ? msk : 0u;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int rl = (wq * NPW + i) * 16 + prow;
+            const int n = n0 + rl;
+            const int chunk = (pch ^ (((rl >> 3) & 1) << 1)) * 16;
+            d_base[i] = reinterpret_cast<const char*>(p.Wp + (long)(n < p.N ? n : 0) * p.Ca) + chunk;
+            d_mask[i] = n < p.N ? 0x1ffu : 0u;
+        }
+    }
+    const int spt = p.Ca >> 5;                          // slabs per tap
+    const int ns = p.T * spt;
+    const long w_tap_bytes = (long)p.N * p.Ca * 2;
+    int ld_s = 0, ld_t = 0, ld_c = 0;                   // next slab to stage: index, tap, 32-channel chunk within the tap
+    long ld_toff = 0;                                   // byte offset of the tap (A: spatial shift, W: tap plane)
+
+    auto tap_offset = [&](int t) -> long {
+        if (grp != 0) return (long)t * w_tap_bytes;
+        const int ky = t / p.ksz, kx = t - ky * p.ksz;
+        return (long)sgn * ((long)ky * p.dil * p.Wa + (long)kx * p.dil) * p.Ca * 2;
+    };
+    auto stage_next = [&]() {
+        char* dst = smem + (ld_s & 3) * SLAB + (grp == 0 ? wq * (NPA * 1024) : SLAB_A + wq * (NPW * 1024));
+        const long off = ld_toff + (long)ld_c * 64;
+        if (grp == 0) {
+#pragma unroll
+            for (int i = 0; i < NPA; ++i) glds16(((d_mask[i] >> ld_t) & 1u) ? d_base[i] + off : zero, dst + i * 1024);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NPW; ++i) glds16(d_mask[i] ? d_base[i] + off : zero, dst + i * 1024);
+        }
+        ++ld_s;
+        if (++ld_c == spt) {
+            ld_c = 0;
+            ++ld_t;
+            ld_toff = tap_offset(ld_t);
+        }
+    };
+
+    // ---- compute roles ---------------------------------------------------------------------------------------------------------
+    f32x4 acc[4][MTG];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MTG; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fq = lane >> 4;
+    const int a_off = (grp * BMG + frow) * 64 + ((fq ^ ((-(frow >> 2)) & 3)) << 4);                       // + j * 1024
+    const int w_off = SLAB_A + (wq * 64 + 8 * (frow >> 2) + (frow & 3)) * 64 + ((fq ^ (((frow >> 2) & 1) << 1)) << 4);   // + (32*(i>>1) + 4*(i&1)) * 64
+    bf16x8 wf[4], af[MTG];
+    auto read_frags = [&](int s) {
+        const char* base = smem + (s & 3) * SLAB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(base + w_off + (32 * (i >> 1) + 4 * (i & 1)) * 64);
+#pragma unroll
+        for (int j = 0; j < MTG; ++j) af[j] = *reinterpret_cast<const bf16x8*>(base + a_off + j * 1024);
+    };
+    auto mfma_all = [&]() {
+#pragma unroll
+        for (int j = 0; j < MTG; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+    };
+
+    // ---- prologue: three slabs in flight, slab 0 landed -------------------------------------------------------------------------
+    constexpr int NP = 0;   // (placeholder so that the waits below read as counts of PIECES per slab per wave)
+    (void)NP;
+    for (int s = 0; s < 3 && s < ns; ++s) stage_next();
+    if (ns >= 3) {
+        if (grp == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                                   // B_0
+    if (grp == 1) __builtin_amdgcn_s_barrier();                     // group 1 runs one interval behind (B_1)
+
+    const int dbg = p.zgw >> 8;          // experiment toggles (tools/ppexp.py): 1 no DMA in the loop, 2 no ds_reads, 4 no MFMAs
+    for (int s = 0; s < ns; ++s) {
+        // ---- read segment (G0: I_2s, G1: I_2s+1) ----
+        if (s + 3 < ns && !(dbg & 1)) stage_next();                               // slab s+3 -> the slot slab s-1 has left
+        if (!(dbg & 2) || s == 0) read_frags(s);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp == 1) {                                             // end of an odd interval: my pieces of slab s+1 must have landed
+            if (s + 3 < ns) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        // ---- MFMA segment (G0: I_2s+1, G1: I_2s+2) ----
+        __builtin_amdgcn_s_setprio(1);
+        if (!(dbg & 4)) mfma_all();
+        __builtin_amdgcn_s_setprio(0);
+        if (grp == 0) {
+            if (s + 3 < ns) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();                     // group 0 leaves one interval early: keep the barrier counts equal
+
+    if (EPI < 0 && (p.flags & (1 << 30))) {   // perf experiment: main loop only (keeps the accumulators alive, stores nothing)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < MTG; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
+    bf16x8 pres[MTG][2];
+    unsigned pbits[MTG];
+    igemm_fetch_epilogue<MTG, EPI>(p, m0, n0, grp, wq, frow, fq, pres, pbits);
+    igemm_epilogue<MTG, EPI>(p, acc, m0, n0, grp, wq, frow, fq, pres, pbits);
+}
+
+template <int MTG, int EPI>
+void launch_pp(dim3 grid, hipStream_t stream, const IgemmParams& p) {
+    static std::atomic<uint64_t> attr_done{0};
+    auto kern = igemm_pp_kernel<MTG, EPI>;
+    constexpr int lds = PPGeo<MTG>::LDS_BYTES;
+    mi_allow_dynamic_lds((const void*)kern, lds, attr_done);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p);
+}
+
+template <int MTG>
+void launch_pp_flags(dim3 grid, hipStream_t stream, const IgemmParams& p) {
+    if (p.flags == 69) return launch_pp<MTG, 69>(grid, stream, p);       // FrozenBN + ReLU + sign bits (conv forward)
+    if (p.flags == 128) return launch_pp<MTG, 128>(grid, stream, p);     // ReLU backward from sign bits (data gradient)
+    if (p.flags == 0) return launch_pp<MTG, 0>(grid, stream, p);         // plain bf16 store (downsample data gradient, ASPP data gradient)
+    if (p.flags == 1) return launch_pp<MTG, 1>(grid, stream, p);         // FrozenBN only (downsample forward)
+    if (p.flags == 48) return launch_pp<MTG, 48>(grid, stream, p);       // fp32 tap planes (ASPP forward)
+    launch_pp<MTG, -1>(grid, stream, p);
+}
+
+}  // namespace
+
+// Same contract as mi_conv_gemm, restricted to stride 1 / Ha == Ho / Ca % 32 == 0.  mi_conv_gemm dispatches here by its cost
+// model; exported so that the two main loops can be compared in one process (tools/kexp.py).  mtg = 0: choose the tile height.
+extern "C" int mi_conv_gemm_pp(const void* a, const void* wp, void* out, int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N, int ksize,
+                               int stride, int pad, int dil, int gather_mode, const float* scale, const float* bias, const void* res,
+                               const void* msk, void* mask_out, int flags, int zgw, float alpha, int mtg, void* stream) {
+    MI_REQUIRE(a && wp && out, "mi_conv_gemm_pp: null operand");
+    MI_REQUIRE(B > 0 && Ha > 0 && Wa > 0 && N > 0, "mi_conv_gemm_pp: non-positive dimension");
+    MI_REQUIRE(stride == 1 && Ha == Ho && Wa == Wo, "mi_conv_gemm_pp: stride-1, same-size convolutions only");
+    MI_REQUIRE(Ca > 0 && Ca % 32 == 0, "mi_conv_gemm_pp: Ca=%d must be a multiple of 32", Ca);
+    MI_REQUIRE(N % 8 == 0, "mi_conv_gemm_pp: N=%d must be a multiple of 8", N);
+    MI_REQUIRE(ksize == 1 || ksize == 3, "mi_conv_gemm_pp: ksize=%d (1 or 3)", ksize);
+    MI_REQUIRE(dil >= 1 && pad >= 0, "mi_conv_gemm_pp: bad dil/pad");
+    MI_REQUIRE(gather_mode == MI_GATHER_FWD || gather_mode == MI_GATHER_DGRAD, "mi_conv_gemm_pp: gather_mode");
+    MI_REQUIRE(mi_aligned16(a) && mi_aligned16(wp) && mi_aligned16(out), "mi_conv_gemm_pp: operands must be 16-byte aligned");
+    MI_REQUIRE(!(flags & MI_EPI_SCALE_BIAS) || (scale && bias && mi_aligned16(scale) && mi_aligned16(bias)), "mi_conv_gemm_pp: scale/bias");
+    MI_REQUIRE(!(flags & MI_EPI_RESIDUAL) || (res && mi_aligned16(res)), "mi_conv_gemm_pp: residual");
+    MI_REQUIRE(!(flags & MI_EPI_MASK) || (msk && mi_aligned16(msk)), "mi_conv_gemm_pp: mask");
+    MI_REQUIRE(!(flags & MI_EPI_BITMASK) || (msk && N % 16 == 0 && !(flags & MI_EPI_MASK)), "mi_conv_gemm_pp: bit mask needs N %% 16 == 0");
+    MI_REQUIRE(!(flags & MI_EPI_WRITE_MASK) || (mask_out && N % 16 == 0), "mi_conv_gemm_pp: mask_out needs N %% 16 == 0");
+    MI_REQUIRE(!(flags & MI_EPI_ZSPLIT) || (zgw > 0 && zgw % 4 == 0 && N % zgw == 0), "mi_conv_gemm_pp: zgw");
+    const long M = (long)B * Ho * Wo;
+    MI_REQUIRE(M < (1L << 31), "mi_conv_gemm_pp: pixel count overflows int32");
+    IgemmParams p;
+    p.A = (const __bf16*)a;
+    p.Wp = (const __bf16*)wp;
+    p.out = out;
+    p.scale = scale;
+    p.bias = bias;
+    p.res = (const __bf16*)res;
+    p.msk = (const __bf16*)msk;
+    p.mask_out = (uint16_t*)mask_out;
+    p.M = (int)M;
+    p.N = N;
+    p.Ca = Ca;
+    p.T = ksize * ksize;
+    p.Ho = Ho;
+    p.Wo = Wo;
+    p.Ha = Ha;
+    p.Wa = Wa;
+    p.ksz = ksize;
+    p.stride = 1;
+    p.pad = pad;
+    p.dil = dil;
+    p.mode = gather_mode;
+    p.flags = flags;
+    p.zgw = (zgw & 255) > 0 ? zgw : (zgw | 4);
+    p.alpha = alpha;
+    if (mtg != 8 && mtg != 10) {           // fewest rounds on 256 CUs, then the least padding
+        auto rounds = [&](int bm) { return (((M + bm - 1) / bm) * ((N + 255) / 256) + 255) / 256; };
+        mtg = rounds(320) < rounds(256) ? 10 : (rounds(256) < rounds(320) ? 8 : (((M + 319) / 320) * 320 <= ((M + 255) / 256) * 256 ? 10 : 8));
+    }
+    const int bm = 32 * mtg;
+    p.m_tiles = (int)((M + bm - 1) / bm);
+    p.n_tiles = (N + 255) / 256;
+    const dim3 grid(p.m_tiles * p.n_tiles);
+    if (mtg == 10) launch_pp_flags<10>(grid, (hipStream_t)stream, p);
+    else launch_pp_flags<8>(grid, (hipStream_t)stream, p);
+    MI_CHECK_LAUNCH("mi_conv_gemm_pp");
+    return MI_OK;
+}

@@ -77,11 +77,13 @@ def pack_weights_multi(wflat, sflat, wp, wpt, table_dev, n_desc, total_blocks):
 
 
 def conv_gemm(a, wp, out_hw, ksize=1, stride=1, pad=0, dil=1, mode=GATHER_FWD, scale=None, bias=None, res=None,
-              msk=None, relu=False, out_f32=False, zsplit=0, out=None, bits=None, mask_out=None, leaky=0.0, flop_cols=0):
+              msk=None, relu=False, out_f32=False, zsplit=0, out=None, bits=None, mask_out=None, leaky=0.0, flop_cols=0, wide=None):
     """out[b,ho,wo,n] = epi(sum_{t,c} a[b,src(ho,wo,t),c] * wp[t,n,c]);  a [B,Ha,Wa,Ca] bf16, wp [k*k,N,Ca] bf16.
     msk: bf16 [B,Ho,Wo,N] ReLU mask source; bits: the same mask as packed sign bits (int16 [B,Ho,Wo,N/16]);
     mask_out: int16 [B,Ho,Wo,N/16] receiving the sign bits of the result.
-    flop_cols: live columns of a padded ASPP operand (per zsplit plane, or of Ca == 704), for the FLOP accounting only."""
+    flop_cols: live columns of a padded ASPP operand (per zsplit plane, or of Ca == 704), for the FLOP accounting only.
+    wide: None = the library's own choice of main loop; 8 / 10 = force the wide-tile ping-pong loop (mi_conv_gemm_pp) with that
+    many 16-row MFMA tiles per wave (tests, tools/ppexp.py)."""
     _chk(a, torch.bfloat16, "a")
     _chk(wp, torch.bfloat16, "wp")
     B, Ha, Wa, Ca = a.shape
@@ -132,6 +134,10 @@ def conv_gemm(a, wp, out_hw, ksize=1, stride=1, pad=0, dil=1, mode=GATHER_FWD, s
     n_real = N * flop_cols // zsplit if (zsplit and flop_cols) else N
     ca_real = flop_cols if (Ca == ASPP_KPAD and flop_cols) else Ca
     flops = 2.0 * B * Ho * Wo * n_real * ca_real * ksize * ksize
+    if wide is not None:
+        check(_lib.lib().mi_conv_gemm_pp(_p(a), _p(wp), _p(out), B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, pad, dil, mode, _p(scale), _p(bias), _p(res),
+                                         _p(msk), _p(mask_out), flags, zsplit, float(leaky), int(wide), _stream()), "mi_conv_gemm_pp")
+        return out
     check(_timed("igemm_nt_kernel", flops, lambda: _lib.lib().mi_conv_gemm(
         _p(a), _p(wp), _p(out), B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, pad, dil, mode,
         _p(scale), _p(bias), _p(res), _p(msk), _p(mask_out), flags, zsplit, float(leaky), _stream()),

@@ -162,6 +162,47 @@ def test_pointwise_wide_conv_all_hot_epilogues_vs_torch(ci, co, B, H, W):
     assert torch.equal(y, y2)
 
 
+@pytest.mark.parametrize("B,H,W,ci,co,k,d", [(2, 13, 11, 64, 256, 3, 2), (1, 19, 23, 96, 288, 3, 4), (3, 9, 10, 128, 512, 1, 1), (2, 7, 5, 32, 40, 3, 1)])
+@pytest.mark.parametrize("mtg", [8, 10])
+def test_wide_tile_ping_pong_main_loop_vs_oracle_and_128_wide_kernel(B, H, W, ci, co, k, d, mtg):
+    """csrc/igemm_pp.hip called directly on small / ragged shapes (M and N tails inside one 320 x 256 tile, a single slab, taps
+    that fall into the padding): forward and data-gradient gathers with the epilogues the network launches.  Both main loops add
+    the products of one output element in the same order (tap-major, channels ascending, 32 per MFMA), so their results must be
+    BIT-equal; the oracle pins the value."""
+    pad = d if k == 3 else 0
+    x = synth.bf16_round(synth.uniform("pp.x", (B, ci, H, W)) * 4)
+    w = synth.bf16_round(synth.formula_tensor("pp.weight", (co, ci, k, k)))
+    dy = synth.bf16_round(synth.uniform("pp.dy", (B, co, H, W)) * 2)
+    xd, dyd = nhwc_bf16(x), nhwc_bf16(dy)
+    wd = dev(w)
+    wp, wpt = K.pack_weight_fwd(wd), K.pack_weight_dgrad(wd)
+    sc, sh = dev(1 + synth.uniform("pp.s", (co,))), dev(synth.uniform("pp.b", (co,)))
+    # forward, plain fp32 store: against exact math
+    y = K.conv_gemm(xd, wp, (H, W), k, 1, pad, d, out_f32=True, wide=mtg)
+    assert relmax(to_nchw(y), ref_ops.conv2d(x, w, None, 1, pad, d)) < 2e-5
+    # forward with FrozenBN + ReLU + sign bits (flags 69) and without ReLU (flags 1): bit-equal to the 128-wide kernel
+    base_ok = ci % 64 == 0                                  # the 128-wide kernel stages 64 channels per K-step, this one 32
+    if co % 16 == 0 and base_ok:
+        b0, b1 = (torch.zeros((B, H, W, co // 16), dtype=torch.int16, device=DEV) for _ in range(2))
+        y0 = K.conv_gemm(xd, wp, (H, W), k, 1, pad, d, scale=sc, bias=sh, relu=True, mask_out=b0)
+        y1 = K.conv_gemm(xd, wp, (H, W), k, 1, pad, d, scale=sc, bias=sh, relu=True, mask_out=b1, wide=mtg)
+        assert torch.equal(y0, y1) and torch.equal(b0, b1)
+        # data gradient with the ReLU mask read from sign bits (flags 128)
+        bits = b0[..., : ci // 16].contiguous() if ci % 16 == 0 and ci <= co else None
+        if bits is not None:
+            g0 = K.conv_gemm(dyd, wpt, (H, W), k, 1, pad, d, K.GATHER_DGRAD, bits=bits)
+            g1 = K.conv_gemm(dyd, wpt, (H, W), k, 1, pad, d, K.GATHER_DGRAD, bits=bits, wide=mtg)
+            assert torch.equal(g0, g1)
+    z1 = K.conv_gemm(xd, wp, (H, W), k, 1, pad, d, scale=sc, bias=sh, wide=mtg)
+    if base_ok:
+        assert torch.equal(K.conv_gemm(xd, wp, (H, W), k, 1, pad, d, scale=sc, bias=sh), z1)
+    want = ref_ops.conv2d(x, w, None, 1, pad, d) * sc.cpu().numpy().reshape(1, -1, 1, 1) + sh.cpu().numpy().reshape(1, -1, 1, 1)
+    assert relmax(to_nchw(z1), want) < 2.0 ** -8                           # bf16 output: one ulp of the largest magnitude
+    # data gradient, plain (flags 0): against exact math
+    dx = K.conv_gemm(dyd, wpt, (H, W), k, 1, pad, d, K.GATHER_DGRAD, out_f32=True, wide=mtg)
+    assert relmax(to_nchw(dx), ref_ops.conv2d_dgrad(dy, w, (H, W), 1, pad, d)) < 2e-5
+
+
 def test_conv_identity_weight_is_exact_shift_full_size():
     """Size-independent property at the BASELINE shape (B=8, 97x97, C=256, d=2): a one-hot tap weight makes the
     conv an exact spatial shift with zero fill - bit exact in bf16."""
