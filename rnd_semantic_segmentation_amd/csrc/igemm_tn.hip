@@ -10,6 +10,7 @@
 // Replaces the weight half of convolution_backward for reference core/components/resnet.py:22-30 convs and
 // (out_map 1) for the four ASPP convs of core/models/classifiers/aspp/classifier.py:12-20.
 #include "mi_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -32,8 +33,21 @@ struct WgradParams {
     int o_tiles, i_tiles;
 };
 
-__device__ __forceinline__ s16x4 tr_read(const char* addr) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(addr));
+// Transposed LDS read as INLINE ASM on a raw LDS byte address.  Through the builtin (or any load the compiler can see) hipcc
+// orders every LDS read behind ALL pending global_load_lds of the wave - it cannot prove that the DMA in flight targets the
+// other buffer - and emits s_waitcnt vmcnt(0) in front of the reads: the next tile's DMA was drained before the current
+// tile was even read, i.e. no DMA / MFMA overlap inside a workgroup (found in the ISA of both kernels of this file, round 2).
+// The asm form is invisible to that pass; the callers order reads against DMA themselves (counted vmcnt + barrier) and wait
+// with an explicit s_waitcnt lgkmcnt before the MFMAs (+ sched_barrier: cdna_hip_programming.md 5.4 rule 18).
+template <int OFF>
+__device__ __forceinline__ s16x4 tr_read_lds(unsigned lds_addr) {
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF));
+    return v;
+}
+
+__device__ __forceinline__ unsigned lds_address(const char* generic_ptr_into_lds) {
+    return (unsigned)(uintptr_t)((__attribute__((address_space(3))) const char*)generic_ptr_into_lds);
 }
 
 __device__ __forceinline__ void glds16_tn(const char* gsrc, char* lds_wave_base) {
@@ -147,36 +161,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradParams p) {
     const int g = lane >> 4, q = (lane & 15) >> 2, pc = lane & 3;
     const int rsw = (((g & 1) * 4 + q) << 1);                 // ((row & 7) << 1): ks*32 and half*16 are multiples of 8
     const int row_off = (g * 4 + q) * ROWB + (pc & 1) * 8;
+    const unsigned lds0 = lds_address(smem);
     auto compute = [&](int buf) {
-        const char* sy = smem + buf * STAGE_BYTES;
-        const char* sx = sy + TILE_BYTES;
+        const unsigned sy = lds0 + buf * STAGE_BYTES + row_off;
+        const unsigned sx = sy + TILE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 xf[4], yf[4];
+            union { bf16x8 v; s16x4 h[2]; } xf[4], yf[4];
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                const int ch = ((wi * 8 + a * 2 + (pc >> 1)) ^ rsw) << 4;
-                const char* base = sx + row_off + (ks * 32) * ROWB + ch;
-                const s16x4 lo = tr_read(base), hi = tr_read(base + 16 * ROWB);
-                union { bf16x8 v; s16x4 h[2]; } u;
-                u.h[0] = lo;
-                u.h[1] = hi;
-                xf[a] = u.v;
+                const unsigned base = sx + (ks * 32) * ROWB + (((wi * 8 + a * 2 + (pc >> 1)) ^ rsw) << 4);
+                xf[a].h[0] = tr_read_lds<0>(base);
+                xf[a].h[1] = tr_read_lds<16 * ROWB>(base);
             }
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const int ch = ((wo_ * 8 + b * 2 + (pc >> 1)) ^ rsw) << 4;
-                const char* base = sy + row_off + (ks * 32) * ROWB + ch;
-                const s16x4 lo = tr_read(base), hi = tr_read(base + 16 * ROWB);
-                union { bf16x8 v; s16x4 h[2]; } u;
-                u.h[0] = lo;
-                u.h[1] = hi;
-                yf[b] = u.v;
+                const unsigned base = sy + (ks * 32) * ROWB + (((wo_ * 8 + b * 2 + (pc >> 1)) ^ rsw) << 4);
+                yf[b].h[0] = tr_read_lds<0>(base);
+                yf[b].h[1] = tr_read_lds<16 * ROWB>(base);
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[a], yf[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[a].v, yf[b].v, acc[a][b], 0, 0, 0);
         }
     };
 
@@ -244,6 +253,268 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// =====================================================================================================================
+// 3x3 weight gradient with the three taps of a kernel row FUSED, wide-K ping-pong main loop (the dilated 3x3 family of
+// layer3 / layer4: reference core/components/resnet.py:22-25,100).
+//
+// Why: one workgroup per tap re-streams dy and x nine times through the L2 (15.6 L2 bytes per kFLOP at 128 x 128 tiles),
+// and the launch is bound by exactly that traffic.  The three taps (ky, 0..2) of one kernel row read x at pixel offsets
+// -d, 0, +d of the SAME image row, so one LDS window of 64 + 2d pixel rows feeds three MFMA groups against one dy tile:
+// 5.2 bytes per kFLOP.
+// Validity without masks: the contraction index is a PADDED pixel coordinate q = (b*H + h) * (W + 2d) + wp, every image
+// row carrying d zero slots on either side (staged from the zero page, no memory traffic).  For tap kx the x row paired
+// with dy row q is window row q + kx*d - d - q0, i.e. padded column wp + (kx-1)d: inside the image it is the right source
+// pixel, outside it is a pad slot = 0 - exactly the zero padding of the convolution.  Rows h + (ky-1)d outside the image are
+// zero-paged when the window is staged.  Cost: 2d / W more (all-zero) K rows: 4 % at d = 2, W = 97.
+// Main loop: as igemm_pp.hip - 8 waves in two groups that alternate between an MFMA segment (48 MFMAs per wave and 64-row
+// slab) and a read segment (40 ds_read_b64_tr_b16 + this wave's DMA pieces of slab s+3), 4-slot LDS ring, counted vmcnt.
+// Group 0 stages the dy rows, group 1 the x window.  Wave (wi = wave & 3, wo = group): 32 (i) x 64 (o) x 3 taps.
+// Output: fp32 partial planes slab[split][ky*3+kx][o][i], summed in fixed order by wgrad_reduce_kernel (deterministic).
+constexpr int P3_KS = 64, P3_XROWS = 80;                       // d <= 8
+constexpr int P3_DY_BYTES = P3_KS * ROWB, P3_X_BYTES = P3_XROWS * ROWB, P3_SLAB = P3_DY_BYTES + P3_X_BYTES;   // 16 + 20 KiB
+constexpr int P3_LDS = 4 * P3_SLAB;                            // 144 KiB: one workgroup per CU
+constexpr int P3_NPY = 4, P3_NPX = 5;                          // DMA pieces (4 rows x 256 B) per wave and slab: dy (group 0), x (group 1)
+
+struct WgradP3Params {
+    const __bf16* dY;
+    const __bf16* X;
+    float* slab;
+    int O, I, H, W, d, WP, BH;
+    long Q;
+    int S, slabs_per_split;
+    int o_tiles, i_tiles;
+    int dbg;             // experiment toggles (MI_P3_DBG): 1 no DMA in the loop, 2 no LDS reads, 4 no MFMAs, 8 no partial-plane stores
+};
+
+__global__ __launch_bounds__(512, 1) void wgrad_p3_kernel(WgradP3Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wq = wave & 3;
+    const int tiles = p.o_tiles * p.i_tiles;
+    const int logical = mi_xcd_remap(blockIdx.x, tiles * 3 * p.S);
+    const int tile = logical % tiles, rest = logical / tiles;
+    const int ky = rest % 3, split = rest / 3;
+    const int ot = tile / p.i_tiles, it = tile - ot * p.i_tiles;
+    const int o0 = ot * TO, i0 = it * TI;
+    const long q_begin = (p.dbg & 16) ? 0 : (long)split * p.slabs_per_split * P3_KS;      // dbg 16: every split streams the same (L2-hot) rows
+    long left = (p.Q - q_begin + P3_KS - 1) / P3_KS;
+    const int ns = (int)(left < 0 ? 0 : (left < p.slabs_per_split ? left : p.slabs_per_split));
+    // ---- DMA roles.  lane -> (row within the piece, physical 16-B chunk); it fetches logical chunk physical ^ ((row & 7) << 1).
+    const int prow = lane >> 4, pch = lane & 15;
+    // zero rows (pad slots, rows outside the image, tile tails): 16 lanes read the 256-B zero page as one contiguous row
+    const char* zero = reinterpret_cast<const char*>(g_zero_page_tn) + pch * 16;
+    // A wave stages a SPAN of consecutive padded coordinates per slab (16 dy rows or 20 window rows): piece j = rows 4j .. 4j+3.
+    // The span's first row is wave-uniform, so its coordinates (q, padded column wp, image row h, pixel index pix) live in
+    // scalar registers and advance with scalar arithmetic: 64 coordinates = n0 whole image rows + r0 columns (+ one carry).
+    // Fast path (3 of 4 slabs at W = 97): the whole span lies inside the real columns of one valid image row -> the rows are
+    // consecutive pixels, address = scalar base + a per-lane constant (2 vector ops per piece).  Otherwise every lane derives
+    // its row's coordinates from the scalars (one carry at most: the plan requires span <= WP).
+    constexpr int NPMAX = P3_NPX;
+    const int np = grp == 0 ? P3_NPY : P3_NPX;
+    const int span = np * 4;
+    const int dh = grp == 0 ? 0 : (ky - 1) * p.d;
+    const int n0 = P3_KS / p.WP, r0 = P3_KS - n0 * p.WP;
+    const int pix_step = n0 * p.W + r0;                 // minus 2d when the column wraps into the next image row
+    const int span0 = grp == 0 ? wq * (P3_NPY * 4) : wq * (P3_NPX * 4);
+    int s_q = (int)(q_begin + span0 - (grp == 0 ? 0 : p.d));                 // may be < 0 (first window rows of split 0)
+    int s_wp, s_h, s_pix;
+    {
+        const long qs = (long)s_q + p.WP;                                     // >= 0 (d <= WP)
+        const int bh = (int)(qs / p.WP) - 1;
+        s_wp = (int)(qs % p.WP);
+        s_h = bh < 0 ? p.H - 1 : bh % p.H;                                    // row -1 precedes row 0 of image 0
+        s_pix = (bh + dh) * p.W + s_wp - p.d;
+    }
+    // the lane's channel chunk depends on (row & 7), i.e. on the parity of the piece: two per-lane constants
+    const __bf16* opnd = grp == 0 ? p.dY : p.X;
+    const int c0 = grp == 0 ? o0 : i0, cmax = grp == 0 ? p.O : p.I;
+    const unsigned row_bytes = (unsigned)cmax * 2u;
+    const int lch_e = pch ^ (((span0 + prow) & 7) << 1), lch_o = pch ^ (((span0 + prow + 4) & 7) << 1);
+    const bool ok_e = c0 + lch_e * 8 < cmax, ok_o = c0 + lch_o * 8 < cmax;
+    const unsigned off_e = prow * row_bytes + (c0 + lch_e * 8) * 2, off_o = prow * row_bytes + (c0 + lch_o * 8) * 2;
+    const char* opnd_b = reinterpret_cast<const char*>(opnd);
+    const int Qi = (int)p.Q;
+    int ld_s = 0;
+    auto stage_next = [&]() {
+        char* dst = smem + (ld_s & 3) * P3_SLAB + (grp == 0 ? wq * (P3_NPY * 1024) : P3_DY_BYTES + wq * (P3_NPX * 1024));
+        const bool fast = s_q >= 0 && s_q + span <= Qi && s_wp >= p.d && s_wp + span <= p.W + p.d && (unsigned)(s_h + dh) < (unsigned)p.H;
+        if (fast) {
+            const char* P = opnd_b + (unsigned long)(unsigned)s_pix * row_bytes;              // scalar
+#pragma unroll
+            for (int j = 0; j < NPMAX; ++j)
+                if (j < np) {
+                    const char* src = P + (j * 4 * row_bytes + ((j & 1) ? off_o : off_e));
+                    glds16_tn(((j & 1) ? ok_o : ok_e) ? src : zero, dst + j * 1024);
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NPMAX; ++j)
+                if (j < np) {
+                    const int r = j * 4 + prow;
+                    int wp = s_wp + r;
+                    const bool c = wp >= p.WP;
+                    wp -= c ? p.WP : 0;
+                    int h = s_h + (c ? 1 : 0);
+                    h = h >= p.H ? h - p.H : h;
+                    const int pix = s_pix + r - (c ? 2 * p.d : 0);
+                    const bool ok = ((j & 1) ? ok_o : ok_e) && (unsigned)(s_q + r) < (unsigned)Qi && (unsigned)(wp - p.d) < (unsigned)p.W &&
+                                    (unsigned)(h + dh) < (unsigned)p.H;
+                    const char* src = opnd_b + (unsigned long)(unsigned)(ok ? pix : 0) * row_bytes + (((j & 1) ? off_o : off_e) - prow * row_bytes);
+                    glds16_tn(ok ? src : zero, dst + j * 1024);
+                }
+        }
+        // the span's first row in the next slab (scalar)
+        s_q += P3_KS;
+        s_wp += r0;
+        const int c = s_wp >= p.WP ? 1 : 0;
+        s_wp -= c ? p.WP : 0;
+        s_h += n0 + c;
+        s_h = s_h >= p.H ? s_h - p.H : s_h;
+        s_pix += pix_step - (c ? 2 * p.d : 0);
+        ++ld_s;
+    };
+
+    // ---- compute roles: wave (wi, wo) owns i in [wi*32, +32) x o in [wo*64, +64) for the three taps kx
+    const int wi = wq, wo = grp;
+    f32x4 acc[3][2][4];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[kx][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int g = lane >> 4, q4 = (lane & 15) >> 2, pc = lane & 3;
+    const int rk0 = g * 4 + q4;
+    const int y_off = rk0 * ROWB + (pc & 1) * 8, y_sw = (rk0 & 7) << 1;
+    int x_off[3], x_sw[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int rk = rk0 + kx * p.d;
+        x_off[kx] = P3_DY_BYTES + rk * ROWB + (pc & 1) * 8;
+        x_sw[kx] = (rk & 7) << 1;
+    }
+    union Frag { bf16x8 v; s16x4 h[2]; };
+    Frag yf[2][4], xf[2][3][2];
+    const unsigned lds0 = lds_address(smem);
+    auto read_frags = [&](int s) {
+        unsigned sb = lds0 + (s & 3) * P3_SLAB;
+        asm volatile("" : "+v"(sb));          // opaque: keeps the 10 fragment offsets, not 40 precomputed per-slot addresses, in registers
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const unsigned base = sb + y_off + ((((wo * 4 + b) * 2 + (pc >> 1)) ^ y_sw) << 4);
+            yf[0][b].h[0] = tr_read_lds<0>(base);
+            yf[0][b].h[1] = tr_read_lds<16 * ROWB>(base);
+            yf[1][b].h[0] = tr_read_lds<32 * ROWB>(base);
+            yf[1][b].h[1] = tr_read_lds<48 * ROWB>(base);
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const unsigned base = sb + x_off[kx] + ((((wi * 2 + a) * 2 + (pc >> 1)) ^ x_sw[kx]) << 4);
+                xf[0][kx][a].h[0] = tr_read_lds<0>(base);
+                xf[0][kx][a].h[1] = tr_read_lds<16 * ROWB>(base);
+                xf[1][kx][a].h[0] = tr_read_lds<32 * ROWB>(base);
+                xf[1][kx][a].h[1] = tr_read_lds<48 * ROWB>(base);
+            }
+    };
+    auto mfma_half = [&](int ks) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[kx][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[ks][kx][a].v, yf[ks][b].v, acc[kx][a][b], 0, 0, 0);
+    };
+
+    // ---- main loop (interval scheme of igemm_pp.hip) ----------------------------------------------------------------------------
+    for (int s = 0; s < 3 && s < ns; ++s) stage_next();
+    if (ns >= 3) {
+        if (grp == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P3_NPY) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P3_NPX) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    const int dbg = p.dbg;
+    for (int s = 0; s < ns; ++s) {
+        if (s + 3 < ns && !(dbg & 1)) stage_next();
+        if (!(dbg & 2) || s == 0) read_frags(s);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp == 1) {
+            if (s + 3 < ns) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P3_NPX) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+        if (!(dbg & 4)) {
+            mfma_half(0);
+            mfma_half(1);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (grp == 0) {
+            if (s + 3 < ns) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P3_NPY) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+
+    // ---- partial planes: slab[split][ky*3+kx][o][i], i fastest; lane owns o = column, i .. i+3 = rows
+    if (dbg & 8) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) asm volatile("" ::"v"(acc[kx][a][b]));
+        return;
+    }
+    const int fcol = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        float* plane = p.slab + ((long)(split * 9 + ky * 3 + kx) * p.O) * p.I;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int o = o0 + wo * 64 + b * 16 + fcol;
+            if (o >= p.O) continue;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int i = i0 + wi * 32 + a * 16 + fq * 4;
+                if (i >= p.I) continue;
+                *reinterpret_cast<f32x4*>(plane + (long)o * p.I + i) = acc[kx][a][b];
+            }
+        }
+    }
+}
+
+// Split / grid of the fused 3x3 kernel; returns false when the shape should stay on the per-tap kernel.
+struct P3Plan { int S, slabs_per_split; long Q; int WP, o_tiles, i_tiles; };
+bool p3_plan(int B, int H, int W, int O, int I, int dil, bool force, P3Plan& pl) {
+    if (dil < 1 || dil > 8) return false;
+    pl.WP = W + 2 * dil;
+    pl.Q = (long)B * H * pl.WP;
+    pl.o_tiles = (O + TO - 1) / TO;
+    pl.i_tiles = (I + TI - 1) / TI;
+    const long ns = (pl.Q + P3_KS - 1) / P3_KS;
+    const int groups = pl.o_tiles * pl.i_tiles * 3;
+    long S = 256 / groups;
+    if (S < 1) S = 1;
+    if (S > ns) S = ns;
+    pl.slabs_per_split = (int)((ns + S - 1) / S);
+    pl.S = (int)((ns + pl.slabs_per_split - 1) / pl.slabs_per_split);
+    // one image-row carry per slab and per 20-row span; 32-bit coordinates
+    if (P3_KS / pl.WP + 1 > H || pl.WP < 20 || pl.Q >= (1L << 31) - 4096) return false;
+    if (force) return true;
+    // worth it when the tiles are mostly real channels and every workgroup has a real loop behind its prologue and its
+    // 192-KiB partial planes
+    return O >= 96 && I >= 96 && pl.slabs_per_split >= 8;
+}
+
 int pick_splits(long M, int tiles) {
     // 512 workgroup slots (256 CUs x 2 resident).  Minimise rounds x (K-steps per split + ~6 steps of fixed cost per
     // workgroup: prologue, pipeline fill, slab write); never fewer than 8 K-steps per split.
@@ -271,7 +542,41 @@ extern "C" size_t mi_conv_wgrad_workspace(int B, int Ho, int Wo, int O, int I, i
     const int T = ksize * ksize;
     const int tiles = ((O + TO - 1) / TO) * ((I + TI - 1) / TI) * T;
     const int S = pick_splits(M, tiles);
-    return (size_t)S * T * O * I * sizeof(float);
+    size_t need = (size_t)S * T * O * I * sizeof(float);
+    if (ksize == 3) {          // the fused-row kernel may be chosen for any dilation <= 8: budget for its largest split count
+        P3Plan pl;
+        for (int d = 1; d <= 8; d *= 2)
+            if (p3_plan(B, Ho, Wo, O, I, d, true, pl)) {
+                const size_t n3 = (size_t)pl.S * 9 * O * I * sizeof(float);
+                if (n3 > need) need = n3;
+            }
+    }
+    return need;
+}
+
+static int launch_p3(const void* dy, const void* x, float* ws, int H, int W, int O, int I, int dil, const P3Plan& pl, int BH, hipStream_t st) {
+    WgradP3Params q;
+    q.dY = (const __bf16*)dy;
+    q.X = (const __bf16*)x;
+    q.slab = ws;
+    q.O = O;
+    q.I = I;
+    q.H = H;
+    q.W = W;
+    q.d = dil;
+    q.WP = pl.WP;
+    q.BH = BH;
+    q.Q = pl.Q;
+    q.S = pl.S;
+    q.slabs_per_split = pl.slabs_per_split;
+    q.o_tiles = pl.o_tiles;
+    q.i_tiles = pl.i_tiles;
+    const char* dbg = getenv("MI_P3_DBG");
+    q.dbg = dbg ? atoi(dbg) : 0;
+    static std::atomic<uint64_t> attr{0};
+    mi_allow_dynamic_lds((const void*)wgrad_p3_kernel, P3_LDS, attr);
+    hipLaunchKernelGGL(wgrad_p3_kernel, dim3((unsigned)(pl.o_tiles * pl.i_tiles * 3 * pl.S)), dim3(512), P3_LDS, st, q);
+    return 0;
 }
 
 extern "C" int mi_conv_wgrad(const void* dy, const void* x, float* dw, int B, int Ha, int Wa, int I, int Ho, int Wo, int O,
@@ -294,6 +599,30 @@ extern "C" int mi_conv_wgrad(const void* dy, const void* x, float* dw, int B, in
     MI_REQUIRE(M < (1L << 31) && (long)B * Ha * Wa < (1L << 31), "mi_conv_wgrad: pixel count overflows int32");
     const size_t need = mi_conv_wgrad_workspace(B, Ho, Wo, O, I, ksize);
     if (workspace_bytes < need) return mi_set_error(MI_ENOMEM, "mi_conv_wgrad: workspace %zu < %zu", workspace_bytes, need);
+    // 3x3, stride 1, pad == dilation <= 8: the fused-row kernel (three taps per x window, ping-pong main loop).
+    // MI_WGRAD_P3: 0 = never (default), 1 = by the plan's own rule, 2 = whenever the geometry allows (tests: tiny shapes).
+    // Opt-in because it does not win yet: at 256 -> 256, d = 2, M = 75 272 it takes 127 us against 131 us for the per-tap
+    // kernel (512 -> 512: 404 vs 405).  Its parts, measured with the MI_P3_DBG toggles (tools/wgexp.py): MFMAs alone 42 us,
+    // LDS->register reads 25 us, DMA alone 49 us - the same with L2-hot rows, i.e. the L2 -> LDS path delivers ~43 GB/s per CU
+    // to this access pattern whatever the source (the 64-B-row slabs of igemm_pp.hip get half their lines from the L1) -,
+    // partial-plane stores 14 us, slab reducer 23 us.  With the DMA at 115 % of the MFMA time the ping-pong's read segments
+    // (which carry the DMA issue) outlast the MFMA segments and the two hardly overlap (main loop 80 us).
+    static int p3_mode = -1;
+    if (p3_mode < 0) {
+        const char* e = getenv("MI_WGRAD_P3");
+        p3_mode = e ? atoi(e) : 0;
+    }
+    if (p3_mode && out_map == 0 && ksize == 3 && stride == 1 && Ha == Ho && Wa == Wo && pad == dil) {
+        P3Plan pl;
+        if (p3_plan(B, Ho, Wo, O, I, dil, p3_mode == 2, pl) && (size_t)pl.S * 9 * O * I * sizeof(float) <= workspace_bytes) {
+            launch_p3(dy, x, (float*)workspace, Ho, Wo, O, I, dil, pl, B * Ho, (hipStream_t)stream);
+            MI_CHECK_LAUNCH("mi_conv_wgrad (fused 3x3 rows)");
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((I + 63) / 64), (unsigned)O), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dw,
+                               scale_o, pl.S, 9, O, I, accumulate, 0, 1);
+            MI_CHECK_LAUNCH("mi_conv_wgrad reduce");
+            return MI_OK;
+        }
+    }
     WgradParams p;
     p.dY = (const __bf16*)dy;
     p.X = (const __bf16*)x;
