@@ -167,6 +167,9 @@ int mi_upsample_softmax(const float* low, float* probs, uint8_t* pred, int B, in
 /* ---- optimiser: torch.optim.SGD(momentum, weight_decay) on flat fp32 buffers (aspp_trainer.py:25-26,94-95)
  * g' = g + wd*p; buf = mu*buf + g'; p -= lr*buf  (buf zero-initialised == torch's first-step buf = g'). */
 int mi_sgd_step(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float weight_decay, void* stream);
+/* the same update with hyper = {lr, momentum, weight_decay} read from DEVICE memory at run time: under HIP graph capture a
+ * by-value argument is frozen into the graph, a pointer is not - the poly learning rate changes every step. */
+int mi_sgd_step_dev(float* p, const float* g, float* buf, size_t n, const float* hyper /*[3], device*/, void* stream);
 
 /* ---- stem tail: FrozenBN + ReLU + 3x3/stride 2/pad 1 max-pool fused (resnet.py:138-141) ----------------------
  * y: conv1 output [B][Hc][Wc][C] bf16 NHWC; pool [B][Hp][Wp][C] bf16; idx one byte per pooled element: the winning

@@ -44,6 +44,34 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
     }
 }
 
+// the same update with the hyper-parameters read from device memory: a captured HIP graph replays with whatever learning rate
+// the host wrote into `hyper` before the launch (a by-value kernel argument would be frozen into the graph)
+__global__ void sgd_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, size_t n4, size_t n,
+                               const float* __restrict__ hyper) {
+    const float lr = hyper[0], mu = hyper[1], wd = hyper[2];
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+        const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 bv = reinterpret_cast<f32x4*>(buf)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gg = gv[e] + wd * pv[e];
+            bv[e] = mu * bv[e] + gg;
+            pv[e] = pv[e] - lr * bv[e];
+        }
+        reinterpret_cast<f32x4*>(buf)[i] = bv;
+        reinterpret_cast<f32x4*>(p)[i] = pv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = (n4 << 2) + threadIdx.x;
+        const float gg = g[i] + wd * p[i];
+        const float b = mu * buf[i] + gg;
+        buf[i] = b;
+        p[i] = p[i] - lr * b;
+    }
+}
+
 __global__ void relu_mask_kernel(const bf16x8* __restrict__ x, const bf16x8* __restrict__ m, bf16x8* __restrict__ y, size_t n8) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
@@ -74,6 +102,18 @@ extern "C" int mi_sgd_step(float* p, const float* g, float* buf, size_t n, float
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, buf, n4, n, lr, momentum, weight_decay);
     MI_CHECK_LAUNCH("mi_sgd_step");
+    return MI_OK;
+}
+
+extern "C" int mi_sgd_step_dev(float* p, const float* g, float* buf, size_t n, const float* hyper, void* stream) {
+    MI_REQUIRE(p && g && buf && hyper && n > 0, "mi_sgd_step_dev: bad argument");
+    MI_REQUIRE(mi_aligned16(p) && mi_aligned16(g) && mi_aligned16(buf), "mi_sgd_step_dev: flat buffers must be 16-byte aligned");
+    const size_t n4 = n >> 2;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sgd_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, buf, n4, n, hyper);
+    MI_CHECK_LAUNCH("mi_sgd_step_dev");
     return MI_OK;
 }
 

@@ -16,6 +16,22 @@ class FusedSGD(torch.optim.SGD):
             raise NotImplementedError("FusedSGD implements the reference's configuration: dampening=0, nesterov=False")
         super().__init__(params, lr=lr, momentum=momentum, weight_decay=weight_decay)
         self._flat_mom = {}          # id(store) -> flat momentum buffer
+        self.device_hyper = None     # 3-float device tensor (lr, momentum, weight_decay): set by set_device_hyper() for HIP-graph replay
+
+    def set_device_hyper(self, enable=True):
+        """Graph mode: step() reads lr / momentum / weight_decay of group 0 from a device tensor that push_hyper() refreshes from
+        param_groups before every replay (kernel arguments passed by value would be frozen into the captured graph)."""
+        if not enable:
+            self.device_hyper = None
+            return
+        dev = self.param_groups[0]["params"][0].device
+        g = self.param_groups[0]
+        self.device_hyper = torch.tensor([g["lr"], g["momentum"], g["weight_decay"]], dtype=torch.float32, device=dev)
+
+    def push_hyper(self):
+        """Stream-ordered update of the learning rate (a fill kernel carrying the value as its argument: no host staging buffer
+        that a later step could overwrite before the copy has run)."""
+        self.device_hyper[0:1].fill_(float(self.param_groups[0]["lr"]))
 
     def zero_grad(self, set_to_none=True):
         """Engine-written gradients are OVERWRITTEN by the next backward (no memset of 170 MB); gradients that
@@ -67,7 +83,10 @@ class FusedSGD(torch.optim.SGD):
             if whole:
                 for p in params:
                     flat = self._momentum_view(p, st)
-                K.sgd_step(st.data, st.grad, flat, lr, mu, wd)       # one launch for the whole module
+                if self.device_hyper is not None:
+                    K.sgd_step_dev(st.data, st.grad, flat, self.device_hyper)
+                else:
+                    K.sgd_step(st.data, st.grad, flat, lr, mu, wd)       # one launch for the whole module
                 st.generation += 1
             else:
                 for p in params:

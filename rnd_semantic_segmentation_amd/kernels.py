@@ -368,6 +368,13 @@ def sgd_step(p, g, buf, lr, momentum, weight_decay):
           "mi_sgd_step")
 
 
+def sgd_step_dev(p, g, buf, hyper):
+    """sgd_step with (lr, momentum, weight_decay) in a 3-float device tensor (graph-capturable: see mi355seg.h)."""
+    for t, n in ((p, "p"), (g, "g"), (buf, "buf"), (hyper, "hyper")):
+        _chk(t, torch.float32, n)
+    check(_lib.lib().mi_sgd_step_dev(_p(p), _p(g), _p(buf), p.numel(), _p(hyper), _stream()), "mi_sgd_step_dev")
+
+
 def relu_mask(x, msk, out=None):
     """y = msk > 0 ? x : 0;  msk is a bf16 tensor of x's shape, or packed sign bits (int16, x.numel()/16 words)."""
     _chk(x, torch.bfloat16, "x")

@@ -273,3 +273,41 @@ def test_r101_129_bf16_engine_vs_reference_under_cpu_autocast():
     a_ours, a_ref16 = float((pred == g32["pred"]).mean()), float((g16["pred"] == g32["pred"]).mean())
     print("r101@129 vs fp32 reference: engine %.3e (agree %.4f) | reference under CPU bf16 autocast %.3e (agree %.4f)" % (e_ours, a_ours, e_ref16, a_ref16))
     assert e_ours < 1.5 * e_ref16 + 1e-3 and a_ours > a_ref16 - 0.01
+
+
+def test_hip_graph_replay_of_the_training_step_is_bit_equal_to_eager(tmp_path, monkeypatch):
+    """MI_GRAPH=1: after three eager steps ASPPTrainer captures one whole step (zero_grad, forward, fused loss, backward on two
+    streams, both fused SGD launches; the learning rate travels through device memory) into a HIP graph and replays it.  Same
+    kernels in the same per-stream order: every loss must be BIT-equal to the eager run, also while the poly LR decays."""
+    import logging
+    from rnd_semantic_segmentation_amd.host import config as hc
+    from rnd_semantic_segmentation_amd.host.trainer import ASPPTrainer
+    cfg = hc.CfgNode(hc.default_tree())
+    cfg.merge_from_list(["MODEL.FREEZE_BN", True, "MODEL.NUM_CLASSES", 19, "SOLVER.BASE_LR", 5e-4, "OUTPUT_DIR", str(tmp_path)])
+    cfg.freeze()
+    x, lab = _cases.net_inputs(2, 129, 71)
+    xt, lt = torch.from_numpy(x), torch.from_numpy(lab)
+
+    def run(graph):
+        monkeypatch.setenv("MI_GRAPH", "1" if graph else "0")
+        tr = ASPPTrainer("aspp", cfg, [None] * 50, 0, logger=logging.getLogger("graph-test"))
+        with torch.no_grad():
+            for m in (tr.feature_extractor, tr.classifier):
+                synth.load_formula_weights(m)
+                m._store.generation += 1
+        losses = []
+        for _ in range(9):
+            loss, lr = tr.train_step(xt, lt, 40)
+            tr.iteration += 1
+            losses.append(loss)
+        torch.cuda.synchronize()
+        captured = getattr(tr, "_graph", {}).get("graph") is not None
+        w = dict(tr.classifier.named_parameters())["conv2d_list.0.bias"].detach().clone()
+        return [float(l) for l in losses], captured, w
+
+    eager, cap0, w0 = run(False)
+    graph, cap1, w1 = run(True)
+    print("eager", eager, "\ngraph", graph)
+    assert not cap0 and cap1
+    assert eager == graph and torch.equal(w0, w1)
+    assert eager[-1] < eager[0]
