@@ -218,6 +218,194 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradParams p) {
     }
 }
 
+// ---- 128 (o) x 256 (i) tile, 32 pixels per K step --------------------------------------------------------------------------
+// The 128 x 128 kernel above is bound by the bytes the L2 hands to the LDS (15.6 per kFLOP; the L2 -> LDS path sustains
+// ~43 GB/s per CU).  Widening the tile over the INPUT channels to 256 with a 32-pixel step keeps the MFMA
+// work per step (32 per wave) and the two-workgroups-per-CU structure (48 KiB of LDS, 128 accumulator registers) and moves
+// 24 KiB instead of 32 KiB per step: 11.4 bytes per kFLOP.  Used for stride-1 convs with I >= 256 (every layer3 / layer4 / ASPP
+// weight gradient).  Same slab layout, same reducer.
+constexpr int TI2 = 256, KP2 = 32;
+constexpr int XROWB = 512;                                  // one pixel row of the x tile: 256 channels bf16
+constexpr int Y2_BYTES = KP2 * ROWB, X2_BYTES = KP2 * XROWB;  // 8 KiB + 16 KiB
+constexpr int STAGE2_BYTES = Y2_BYTES + X2_BYTES, NSTAGE2 = 3, LDS2_BYTES = NSTAGE2 * STAGE2_BYTES;   // 72 KiB: two workgroups per CU
+
+// MODE 1: unit stride, k x k taps   2: 1x1, stride 1
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void wgrad_tn256_kernel(WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles = p.o_tiles * p.i_tiles;
+    const int logical = mi_xcd_remap(blockIdx.x, tiles * p.T * p.S);
+    const int tile = logical % tiles, rest = logical / tiles;
+    const int t = rest % p.T, split = rest / p.T;
+    const int ot = tile / p.i_tiles, it = tile - ot * p.i_tiles;
+    const int o0 = ot * TO, i0 = it * TI2;
+    const int ky = t / p.ksz, kx = t - ky * p.ksz;
+    const int m_begin = split * p.rows_per_split;
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+    const int nk = (m_end - m_begin + KP2 - 1) / KP2;
+    const char* zero = reinterpret_cast<const char*>(g_zero_page_tn);
+
+    // DMA: wave w moves dy pieces 2w, 2w+1 (4 rows x 256 B each) and x pieces 4w .. 4w+3 (2 rows x 512 B each)
+    const int yrow_l = lane >> 4, ych = lane & 15, xrow_l = lane >> 5, xch = lane & 31;
+    const int dys = ky * p.dil - p.pad, dxs = kx * p.dil - p.pad;
+    int y_m[2], x_m[4], x_ho[4], x_wo[4];
+    const char* y_ptr[2];
+    const char* x_ptr[4];
+    bool y_col[2], x_col[4];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave * 2 + j) * 4 + yrow_l;
+        const int lch = ych ^ ((row & 7) << 1);
+        y_m[j] = m_begin + row;
+        y_col[j] = o0 + lch * 8 < p.O;
+        y_ptr[j] = reinterpret_cast<const char*>(p.dY + (long)y_m[j] * p.O + o0 + lch * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wave * 4 + j) * 2 + xrow_l;
+        const int lch = xch ^ ((row & 7) << 1);
+        const int m = m_begin + row;
+        x_m[j] = m;
+        const int b = m / HoWo, rem = m - b * HoWo;
+        x_ho[j] = rem / p.Wo;
+        x_wo[j] = rem - x_ho[j] * p.Wo;
+        x_col[j] = i0 + lch * 8 < p.I;
+        x_ptr[j] = reinterpret_cast<const char*>(p.X + ((long)m + (long)dys * p.Wa + dxs) * p.I + i0 + lch * 8);
+    }
+    const int step_q = KP2 / p.Wo, step_r = KP2 - step_q * p.Wo;
+    const long y_step = (long)KP2 * p.O * 2, x_step = (long)KP2 * p.I * 2;
+
+    auto stage = [&](int buf) {
+        char* sy = smem + buf * STAGE2_BYTES + wave * 2048;
+        char* sx = smem + buf * STAGE2_BYTES + Y2_BYTES + wave * 4096;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            glds16_tn((y_m[j] < m_end && y_col[j]) ? y_ptr[j] : zero, sy + j * 1024);
+            y_m[j] += KP2;
+            y_ptr[j] += y_step;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bool ok = x_m[j] < m_end && x_col[j];
+            if (MODE == 1) {
+                const int hs = x_ho[j] + dys, ws = x_wo[j] + dxs;
+                ok = ok && (unsigned)hs < (unsigned)p.Ha && (unsigned)ws < (unsigned)p.Wa;
+            }
+            glds16_tn(ok ? x_ptr[j] : zero, sx + j * 1024);
+            x_m[j] += KP2;
+            x_ptr[j] += x_step;
+            if (MODE == 1) {
+                x_wo[j] += step_r;
+                x_ho[j] += step_q;
+                if (x_wo[j] >= p.Wo) {
+                    x_wo[j] -= p.Wo;
+                    ++x_ho[j];
+                }
+                while (x_ho[j] >= p.Ho) x_ho[j] -= p.Ho;
+            }
+        }
+    };
+
+    // MFMA orientation: D rows = i (A operand = X^T), D cols = o (B operand = dY^T); wave owns 128 (i) x 64 (o)
+    const int wi = wave & 1, wo_ = wave >> 1;
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int g = lane >> 4, q = (lane & 15) >> 2, pc = lane & 3;
+    const int rsw = (((g & 1) * 4 + q) << 1);
+    const unsigned lds0 = lds_address(smem);
+    const unsigned y_off = (g * 4 + q) * ROWB + (pc & 1) * 8, x_off = Y2_BYTES + (g * 4 + q) * XROWB + (pc & 1) * 8;
+    auto compute = [&](int buf) {
+        const unsigned sb = lds0 + buf * STAGE2_BYTES;
+        union { bf16x8 v; s16x4 h[2]; } xf[8], yf[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const unsigned base = sb + y_off + (((wo_ * 8 + b * 2 + (pc >> 1)) ^ rsw) << 4);
+            yf[b].h[0] = tr_read_lds<0>(base);
+            yf[b].h[1] = tr_read_lds<16 * ROWB>(base);
+        }
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            const unsigned base = sb + x_off + (((wi * 16 + a * 2 + (pc >> 1)) ^ rsw) << 4);
+            xf[a].h[0] = tr_read_lds<0>(base);
+            xf[a].h[1] = tr_read_lds<16 * XROWB>(base);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[a].v, yf[b].v, acc[a][b], 0, 0, 0);
+    };
+
+    // Three-stage ring, two stages in flight: a K step of this kernel is bound by the round trip of its DMA (the per-step
+    // drain + barrier of the 128 x 128 kernel leaves the MFMA pipe idle ~70 % of a step), so stage kt+2 is issued before stage kt
+    // is computed.  One raw barrier per step: it publishes stage kt (every wave waited for its own six pieces: counted vmcnt, one
+    // younger stage stays in flight) and proves that every wave has finished reading stage kt-1, whose slot stage kt+2 then takes.
+    if (nk > 0) {
+        stage(0);
+        if (nk > 1) stage(1);
+        int slot = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < nk) stage(slot == 0 ? 2 : slot - 1);          // slot of stage kt-1 == (kt+2) % 3
+            compute(slot);
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+    }
+
+    float* slab = p.slab + ((long)(split * p.T + t) * p.O) * p.I;
+    const int fcol = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int o = o0 + wo_ * 64 + b * 16 + fcol;
+        if (o >= p.O) continue;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            const int i = i0 + wi * 128 + a * 16 + fq * 4;
+            if (i >= p.I) continue;
+            *reinterpret_cast<f32x4*>(slab + (long)o * p.I + i) = acc[a][b];
+        }
+    }
+}
+
+int pick_splits256(long M, int tiles) {
+    // as pick_splits, for 32-pixel steps: 512 slots, ~12 steps of fixed cost per workgroup, never fewer than 16 steps per split
+    const long steps = (M + KP2 - 1) / KP2;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= 128; ++s) {
+        const long per = (steps + s - 1) / s;
+        if (s > 1 && per < 16) break;
+        const long rounds = ((long)tiles * s + 511) / 512;
+        const double cost = (double)rounds * (double)(per + 12);
+        if (cost < best_cost - 1e-9) {
+            best_cost = cost;
+            best = s;
+        }
+    }
+    return best;
+}
+
+inline bool use_tn256(int I, int stride, int Ha, int Ho, int Wa, int Wo) {
+    static int on = -1;
+    if (on < 0) {
+        // opt-in: measured SLOWER than the 128 x 128 kernel (B = 8, 97 x 97: 1x1 256 <-> 1024 71 us vs 58 us, 3x3 256 144 vs 129,
+        // 3x3 512 397 vs 406; with a drain + barrier per step instead of the ring: 81 / 139 us).  27 % fewer L2 bytes do not pay
+        // for twice the K steps: a step of these kernels costs one DMA round trip whatever it moves.
+        const char* e = getenv("MI_WGRAD_TI256");
+        on = e ? atoi(e) : 0;
+    }
+    return on && I >= 256 && stride == 1 && Ha == Ho && Wa == Wo;
+}
+
 // dw[o][i][t] = scale[o] * sum_s slab[s][t][o][i]   (fixed summation order -> reproducible).
 // One workgroup per (o, 64 consecutive i): threads (t-major) read slab rows coalesced over i, the T x 64 block is
 // transposed through LDS and written out as 64*T contiguous floats (OIHW keeps t fastest).
@@ -543,6 +731,11 @@ extern "C" size_t mi_conv_wgrad_workspace(int B, int Ho, int Wo, int O, int I, i
     const int tiles = ((O + TO - 1) / TO) * ((I + TI - 1) / TI) * T;
     const int S = pick_splits(M, tiles);
     size_t need = (size_t)S * T * O * I * sizeof(float);
+    if (I >= 256) {           // the 128 x 256 tile kernel splits differently
+        const int S2 = pick_splits256(M, ((O + TO - 1) / TO) * ((I + TI2 - 1) / TI2) * T);
+        const size_t n2 = (size_t)S2 * T * O * I * sizeof(float);
+        if (n2 > need) need = n2;
+    }
     if (ksize == 3) {          // the fused-row kernel may be chosen for any dilation <= 8: budget for its largest split count
         P3Plan pl;
         for (int d = 1; d <= 8; d *= 2)
@@ -640,6 +833,23 @@ extern "C" int mi_conv_wgrad(const void* dy, const void* x, float* dw, int B, in
     p.pad = pad;
     p.dil = dil;
     p.o_tiles = (O + TO - 1) / TO;
+    const bool wide = use_tn256(I, stride, Ha, Ho, Wa, Wo);
+    if (wide) {
+        p.i_tiles = (I + TI2 - 1) / TI2;
+        p.S = pick_splits256(M, p.o_tiles * p.i_tiles * p.T);
+        const long steps2 = (M + KP2 - 1) / KP2;
+        p.rows_per_split = (int)(((steps2 + p.S - 1) / p.S) * KP2);
+        static std::atomic<uint64_t> attr2[2];
+        mi_allow_dynamic_lds((const void*)wgrad_tn256_kernel<1>, LDS2_BYTES, attr2[0]);
+        mi_allow_dynamic_lds((const void*)wgrad_tn256_kernel<2>, LDS2_BYTES, attr2[1]);
+        const unsigned nb = (unsigned)(p.o_tiles * p.i_tiles * p.T * p.S);
+        if (ksize == 1 && pad == 0)
+            hipLaunchKernelGGL(wgrad_tn256_kernel<2>, dim3(nb), dim3(256), LDS2_BYTES, (hipStream_t)stream, p);
+        else
+            hipLaunchKernelGGL(wgrad_tn256_kernel<1>, dim3(nb), dim3(256), LDS2_BYTES, (hipStream_t)stream, p);
+        MI_CHECK_LAUNCH("mi_conv_wgrad (128 x 256 tile)");
+    }
+    if (!wide) {
     p.i_tiles = (I + TI - 1) / TI;
     p.S = pick_splits(M, p.o_tiles * p.i_tiles * p.T);
     const long steps = (M + KP - 1) / KP;
@@ -657,6 +867,7 @@ extern "C" int mi_conv_wgrad(const void* dy, const void* x, float* dw, int B, in
     else
         hipLaunchKernelGGL(wgrad_tn_kernel<0>, dim3(nblocks), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
     MI_CHECK_LAUNCH("mi_conv_wgrad");
+    }
     int o_real = O;
     if (out_map == 1) o_real = 36 * ncls;
     else ncls = 1;

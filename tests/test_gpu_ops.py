@@ -162,7 +162,7 @@ def test_pointwise_wide_conv_all_hot_epilogues_vs_torch(ci, co, B, H, W):
     assert torch.equal(y, y2)
 
 
-@pytest.mark.parametrize("B,H,W,ci,co,k,d", [(2, 13, 11, 64, 256, 3, 2), (1, 19, 23, 96, 288, 3, 4), (3, 9, 10, 128, 512, 1, 1), (2, 7, 5, 32, 40, 3, 1)])
+@pytest.mark.parametrize("B,H,W,ci,co,k,d", [(2, 13, 11, 64, 256, 3, 2), (1, 19, 23, 96, 288, 3, 4), (3, 9, 10, 128, 512, 1, 1), (2, 7, 5, 32, 64, 3, 1)])
 @pytest.mark.parametrize("mtg", [8, 10])
 def test_wide_tile_ping_pong_main_loop_vs_oracle_and_128_wide_kernel(B, H, W, ci, co, k, d, mtg):
     """csrc/igemm_pp.hip called directly on small / ragged shapes (M and N tails inside one 320 x 256 tile, a single slab, taps
@@ -512,10 +512,12 @@ def test_errors_are_reported_not_thrown_across_the_abi():
         K.relu_mask(torch.zeros(8, dtype=torch.bfloat16), torch.zeros(8, dtype=torch.bfloat16))
 
 
-@pytest.mark.parametrize("B,H,W,ci,co,k,d", [(1, 1, 1, 64, 64, 1, 1), (1, 2, 3, 64, 72, 3, 1), (1, 5, 4, 128, 64, 3, 6), (3, 1, 7, 64, 8, 3, 2)])
+@pytest.mark.parametrize("B,H,W,ci,co,k,d", [(1, 1, 1, 64, 64, 1, 1), (1, 2, 3, 64, 72, 3, 1), (1, 5, 4, 128, 64, 3, 6), (3, 1, 7, 64, 8, 3, 2),
+                                             (2, 9, 7, 256, 64, 3, 2), (1, 11, 5, 320, 136, 1, 1), (2, 6, 9, 576, 72, 3, 4)])
 def test_tiny_and_ragged_conv_shapes(B, H, W, ci, co, k, d):
     """Degenerate geometry: a single pixel, images smaller than the dilation (every off-centre tap is padding), N = 8 and
-    N = 72 (below / not a multiple of the 128-column tile), M far below one tile.  Forward, data and weight gradients
+    N = 72 (below / not a multiple of the 128-column tile), M far below one tile; Cin = 256 / 320 / 576 select the 128 x 256
+    weight-gradient tile (whole, with a 64-channel tail, with two tiles and a tail).  Forward, data and weight gradients
     against fp32 torch on the same bf16 operands."""
     import torch.nn.functional as F
     g = torch.Generator().manual_seed(B * 7 + H * 5 + W + co)
