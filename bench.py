@@ -6,9 +6,12 @@ B = 8 per GPU, on N MI355X of one node (weak scaling), synthetic data resident i
 
 One step = reference core/trainers/aspp_trainer.py:77-95 (poly LR, zero_grad, forward, CE loss, backward, both SGD
 steps) through host/trainer.py:ASPPTrainer.train_step on the HIP engine; N > 1 adds the RCCL gradient average.
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the MFMA implicit-GEMM conv,
-igemm_nt_kernel): algorithmic FLOPs / its launch time measured with HIP events on the launch stream inside the
-timed region.  `cpu_baseline` times the oracle's torch-CPU port of the same step on the host cores (rank 0, N = 1).
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the one with the largest total launch time in
+the instrumented steps): algorithmic FLOPs / its launch time measured with HIP events on the launch stream inside the
+timed region; `kernels` lists every timed kernel, `kernel_families` the north-star groups (dilated 3x3 family, ASPP head:
+fraction of the MFMA peak; the K = 256 <-> N = 1024 pointwise class: fraction of the HBM peak).  `cpu_baseline` times the
+oracle's torch-CPU port of the same step on all granted host cores (rank 0, N = 1).  MI_GRAPH=1 replays the step as a HIP
+graph (no per-launch events then).
 """
 import argparse
 import json
@@ -23,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md chip table
+PEAK_HBM_TBS = 8.0             # HBM3E peak, same table (6.29 TB/s measured with a float4 copy)
 ALG_GFLOP_PER_IMAGE = 2518.5   # fwd + dgrad + wgrad of all 108 convs at 769x769
 
 
@@ -41,16 +45,40 @@ def synthetic_batch(batch, size, rank, device):
     return x.to(device), lab.to(device)
 
 
-def cpu_baseline(size, budget_s=25.0):
+def granted_cores():
+    """Cores this process may actually use: the scheduler affinity capped by the cgroup CPU quota (a 1-GPU box exposes every
+    core of the host in the affinity mask but grants a 16-core share; running 100+ threads on it takes minutes per step)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = int(txt[0]) / int(txt[1])
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    quota = q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    if quota is not None:
+        n = min(n, max(1, int(quota)))
+    else:
+        n = min(n, 16)                                # no quota visible: the documented share of a 1-GPU box
+    return max(1, n)
+
+
+def cpu_baseline(size, budget_s=40.0):
     """The oracle's stock-PyTorch CPU restatement of the same training step (kind 'port'), B = 1, bounded sample."""
     from oracle import ref_model
     from rnd_semantic_segmentation_amd.host import synth
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))                    # a 1-GPU box grants a 16-core share
-    torch.set_num_threads(cores)
+    cores = granted_cores()
+    torch.set_num_threads(cores)                      # every core this process is granted (SURVEY 8d)
     fe, cls = ref_model.RefFeatureExtractor(), ref_model.RefASPP()
     synth.load_formula_weights(fe)
     synth.load_formula_weights(cls)
@@ -58,7 +86,7 @@ def cpu_baseline(size, budget_s=25.0):
     x, lab = synthetic_batch(1, size, 0, "cpu")
     ref_model.ref_train_step(fe, cls, of, oc, x, lab, 0, 100, 5e-4)      # warm-up (oneDNN primitive creation)
     n, t0 = 0, time.time()
-    while n < 2 and (n == 0 or time.time() - t0 < budget_s):
+    while n < 3 and (n == 0 or time.time() - t0 < budget_s):
         ref_model.ref_train_step(fe, cls, of, oc, x, lab, n + 1, 100, 5e-4)
         n += 1
     dt = time.time() - t0
@@ -137,7 +165,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    events = [] if not args.no_kernel_events else None
+    events = [] if not (args.no_kernel_events or os.environ.get("MI_GRAPH") == "1") else None
     t0 = time.perf_counter()
     for i in range(args.steps):
         # per-launch HIP events cost ~6 % of a step, so only every 8th timed step is instrumented; an instrumented step also keeps the
@@ -172,38 +200,69 @@ def main():
         }
         if events:
             inst_steps = (args.steps + 7) // 8
-            by = {}
-            shapes = {}
+            by, shapes = {}, {}
+            fam = {"dilated3x3_family": [0.0, 0.0, 0], "aspp_head": [0.0, 0.0, 0], "pointwise_k256_n1024_class": [0.0, 0.0, 0]}
             for name, e0, e1, flops, tag in events:
-                sh = shapes.setdefault(tag, [0.0, 0.0, 0])
-                sh[0] += e0.elapsed_time(e1) * 1e-3
-                sh[1] += flops
-                sh[2] += 1
-                d = by.setdefault(name, [0.0, 0.0, 0])
-                d[0] += e0.elapsed_time(e1) * 1e-3
-                d[1] += flops
-                d[2] += 1
+                dt = e0.elapsed_time(e1) * 1e-3
+                for d, key in ((shapes, tag), (by, name)):
+                    v = d.setdefault(key, [0.0, 0.0, 0])
+                    v[0] += dt
+                    v[1] += flops
+                    v[2] += 1
+                kind, ksz, cin, cout, m = tag[0], tag[1], tag[2], tag[3], tag[4]
+                dil = tag[6] if len(tag) > 6 else 1
+                f = None
+                if kind == "aspp_aux" or (kind == "fwd" and tag[5] & 32) or (kind in ("fwd", "dgrad") and cin == kernels.ASPP_KPAD) or (kind == "wgrad" and tag[5] == 1):
+                    f = "aspp_head"                        # Z = X Wall^T, col2im | im2col, dX = G Wall, dWall = G^T X, bias sums
+                elif ksz == 3 and dil > 1 and cin >= 256:
+                    f = "dilated3x3_family"                # layer3 d2 (22 convs), layer4 d2 / d4 (3): forward, data and weight gradients
+                elif kind in ("fwd", "dgrad") and ksz == 1 and cin == 256 and cout == 1024 and tag[5] in (71, 130):
+                    f = "pointwise_k256_n1024_class"       # conv3 forward + residual, conv1 data gradient + residual: HBM-bound
+                if f:
+                    fam[f][0] += dt
+                    fam[f][1] += (2.0 * m * (cin + 2 * cout) + 2.0 * m * cout / 8) if f.startswith("pointwise") else flops
+                    fam[f][2] += 1
             dom = max(by, key=lambda k: by[k][0])
             tsec, fl, n = by[dom]
-            traffic = None     # HBM bytes per launch from the committed PMC passes (profiles/pmc.json, see profiles/make_pmc_json.py)
+            # HBM bytes per launch of that kernel come from separate rocprofv3 --pmc passes (profiles/pmc.json, written by
+            # profiles/make_pmc_json.py from the passes of tools/profile_round.sh): counters cannot be read inside this process.
+            traffic, traffic_src = None, None
             try:
-                traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc.json")))[dom]["hbm_bytes_per_launch"]
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc.json")))
+                key = dom.split("+")[0]
+                traffic = pmc[key]["hbm_bytes_per_launch"]
+                traffic_src = {"file": "profiles/pmc.json", "profiled_commit": pmc.get("_meta", {}).get("commit"), "round": pmc.get("_meta", {}).get("round")}
             except (OSError, KeyError, ValueError):
                 pass
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(fl / tsec / 1e12, 2), "peak": PEAK_BF16_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(fl / tsec / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                               "unit": "TFLOP/s", "frac": round(fl / tsec / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                                "launches_per_step": n // inst_steps, "avg_launch_us": round(1e6 * tsec / n, 2),
                                "alg_gflop_per_launch": round(fl / n / 1e9, 3), "ms_per_step_in_kernel": round(1e3 * tsec / inst_steps, 3),
                                "instrumented_steps": inst_steps,
-                               "note": "per-launch durations from the instrumented steps, which run single-stream; the other timed steps run "
-                                       "the forward as two half-batch lanes and the weight gradients beside the data-gradient chain "
-                                       "on extra HIP streams"}
-            out["kernels"] = {k: {"ms_per_step": round(1e3 * v[0] / inst_steps, 3), "tflops": round(v[1] / v[0] / 1e12, 2),
+                               "note": "dominant = largest total launch time in the instrumented steps (HIP events on the launch stream around "
+                                       "every launch of every 8th timed step; those steps run single-stream so that an event pair times one "
+                                       "kernel alone; the other timed steps run the forward as two half-batch lanes and the weight gradients "
+                                       "beside the data-gradient chain on extra HIP streams)"}
+            out["kernels"] = {k: {"ms_per_step": round(1e3 * v[0] / inst_steps, 3), "tflops": round(v[1] / v[0] / 1e12, 2) if v[1] else None,
+                                  "frac_of_mfma_peak": round(v[1] / v[0] / 1e12 / PEAK_BF16_TFLOPS, 4) if v[1] else None,
                                   "launches_per_step": v[2] // inst_steps} for k, v in by.items()}
+            families = {}
+            for k, (tsec_f, work, n_f) in fam.items():
+                if not n_f:
+                    continue
+                if k.startswith("pointwise"):
+                    families[k] = {"bound": "hbm", "ms_per_step": round(1e3 * tsec_f / inst_steps, 3), "launches_per_step": n_f // inst_steps,
+                                   "achieved_tb_s": round(work / tsec_f / 1e12, 3), "peak_tb_s": PEAK_HBM_TBS,
+                                   "frac_of_hbm_peak": round(work / tsec_f / 1e12 / PEAK_HBM_TBS, 4),
+                                   "alg_bytes": "per launch: bf16 A + residual + output, sign bits in / out"}
+                else:
+                    families[k] = {"bound": "mfma", "ms_per_step": round(1e3 * tsec_f / inst_steps, 3), "launches_per_step": n_f // inst_steps,
+                                   "tflops": round(work / tsec_f / 1e12, 2), "frac_of_mfma_peak": round(work / tsec_f / 1e12 / PEAK_BF16_TFLOPS, 4)}
+            out["kernel_families"] = families
         if events and os.environ.get("MI_BENCH_SHAPES"):
-            note("in-step per-shape table: kind k Cin N M flags | launches/step  us/launch  TFLOP/s  ms/step")
+            note("in-step per-shape table: kind k Cin N M flags dil | launches/step  us/launch  TFLOP/s  ms/step")
             for tag, (tsec, fl, n) in sorted(shapes.items(), key=lambda kv: -kv[1][0]):
-                note("%-6s k%d Cin%-5d N%-5d M%-7d f%-4d | %3d  %8.1f  %7.0f  %6.3f" % (tag + (n // inst_steps, 1e6 * tsec / n, fl / tsec / 1e12, 1e3 * tsec / inst_steps)))
+                note("%-8s k%d Cin%-5d N%-5d M%-7d f%-4d d%-2d | %3d  %8.1f  %7.0f  %6.3f" % (tuple(tag[:7]) + (n // inst_steps, 1e6 * tsec / n, fl / tsec / 1e12, 1e3 * tsec / inst_steps)))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.size)
         print(json.dumps(out), flush=True)

@@ -86,6 +86,8 @@ int mi_conv_gemm(const void* a, const void* wp, void* out,
  * stride 1, Ha == Ho, Wa == Wo, Ca % 32 == 0.  mi_conv_gemm picks it by its own cost model; this entry point exists so that
  * the two main loops can be compared on one shape in one process.  mtg: 16-row MFMA tiles per wave (8 or 10 -> 256 or 320
  * tile rows), 0 = choose. */
+/* which main loop mi_conv_gemm takes for a shape: 1 = igemm_pp_kernel (wide tile), 0 = igemm_nt_kernel (measurement tools) */
+int mi_conv_gemm_route(int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N, int ksize, int stride, int flags);
 int mi_conv_gemm_pp(const void* a, const void* wp, void* out,
                     int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N,
                     int ksize, int stride, int pad, int dil, int gather_mode,

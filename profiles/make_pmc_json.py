@@ -14,8 +14,8 @@ import json
 import sys
 from collections import defaultdict
 
-KERNELS = {"igemm_nt_kernel": "igemm_nt_kernel", "wgrad_tn_kernel": "wgrad_tn_kernel", "wgrad_reduce_kernel": "wgrad_reduce_kernel",
-           "upce_pass1_kernel": "upce_pass1_kernel"}
+KERNELS = {"igemm_nt_kernel": "igemm_nt_kernel", "igemm_pp_kernel": "igemm_pp_kernel", "wgrad_tn_kernel": "wgrad_tn_kernel",
+           "wgrad_reduce_kernel": "wgrad_reduce_kernel", "upce_pass1_kernel": "upce_pass1_kernel"}
 
 
 def load(d):
@@ -47,6 +47,13 @@ def main():
                   "mfma_busy_frac": round(mf / (gui / 8 * 1024), 4), "clock_ghz": round(gui / 8 / da[(k, "GRBM_GUI_ACTIVE")], 3),
                   "hbm_read_bytes_per_launch": round(fetch), "hbm_write_bytes_per_launch": round(write),
                   "hbm_bytes_per_launch": round(fetch + write)}
+    import subprocess
+    try:
+        commit = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except OSError:
+        commit = None
+    out["_meta"] = {"commit": commit or None, "round": sys.argv[5] if len(sys.argv) > 5 else None,
+                    "note": "per launch, averaged over every launch of the kernel in `bench.py --steps 5 --warmup 3` (single-stream schedule)"}
     dst = sys.argv[4] if len(sys.argv) > 4 else "profiles/pmc.json"
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out, indent=1))

@@ -23,6 +23,7 @@ SIGNATURES = {
     "mi_pack_weight_dgrad": (I, [P, P, P, I, I, I, P]),
     "mi_pack_weights_multi": (I, [P, P, P, P, P, I, I, P]),
     "mi_conv_gemm": (I, [P, P, P] + [I] * 12 + [P, P, P, P, P, I, I, F, P]),
+    "mi_conv_gemm_route": (I, [I] * 10),
     "mi_conv_gemm_pp": (I, [P, P, P] + [I] * 12 + [P, P, P, P, P, I, I, F, I, P]),
     "mi_conv_wgrad_workspace": (Z, [I] * 6),
     "mi_conv_wgrad": (I, [P, P, P] + [I] * 11 + [P, I, I, I, Z, P, Z, P]),

@@ -342,6 +342,18 @@ extern "C" int mi_conv_gemm_pp(const void* a, const void* wp, void* out, int B, 
                                int stride, int pad, int dil, int gather_mode, const float* scale, const float* bias, const void* res,
                                const void* msk, void* mask_out, int flags, int zgw, float alpha, int mtg, void* stream);
 
+// 1 = the launch goes to the wide-tile ping-pong main loop (igemm_pp_kernel), 0 = to igemm_nt_kernel
+extern "C" int mi_conv_gemm_route(int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N, int ksize, int stride, int flags) {
+    static int pp_on = -1;
+    if (pp_on < 0) {
+        const char* e = getenv("MI_IGEMM_PP");
+        pp_on = e ? atoi(e) : 1;
+    }
+    const long M = (long)B * Ho * Wo;
+    return pp_on && stride == 1 && Ha == Ho && Wa == Wo && !(flags & (MI_EPI_RESIDUAL | MI_EPI_MASK | MI_EPI_LEAKY)) && (long)ksize * ksize * Ca >= 1024 &&
+           Ca % 32 == 0 && M >= 320 * 64 && N >= 256;
+}
+
 extern "C" int mi_conv_gemm(const void* a, const void* wp, void* out, int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N,
                             int ksize, int stride, int pad, int dil, int gather_mode, const float* scale, const float* bias,
                             const void* res, const void* msk, void* mask_out, int flags, int zgw, float alpha, void* stream) {
@@ -371,13 +383,7 @@ extern "C" int mi_conv_gemm(const void* a, const void* wp, void* out, int B, int
     // L2 bytes per kFLOP.  Measured per shape against this kernel in one process (tools/ppexp.py, B = 8, 97 x 97): 3x3 256 +16 %,
     // 3x3 512 +13 %, 1x1 2048->512 +18 %, 1x1 1024->256 / 1024->2048 / ASPP forward +6 %; the short contractions (K <= 704)
     // are epilogue-bound and stay here.  MI_IGEMM_PP=0 switches the dispatch off.
-    static int pp_on = -1;
-    if (pp_on < 0) {
-        const char* e = getenv("MI_IGEMM_PP");
-        pp_on = e ? atoi(e) : 1;
-    }
-    if (pp_on && stride == 1 && Ha == Ho && Wa == Wo && !(flags & (MI_EPI_RESIDUAL | MI_EPI_MASK | MI_EPI_LEAKY)) && (long)ksize * ksize * Ca >= 1024 &&
-        M >= 320 * 64 && N >= 256)
+    if (mi_conv_gemm_route(B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, flags))
         return mi_conv_gemm_pp(a, wp, out, B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, pad, dil, gather_mode, scale, bias, res, msk, mask_out, flags, zgw,
                                alpha, 0, stream);
     IgemmParams p;

@@ -138,10 +138,13 @@ def conv_gemm(a, wp, out_hw, ksize=1, stride=1, pad=0, dil=1, mode=GATHER_FWD, s
         check(_lib.lib().mi_conv_gemm_pp(_p(a), _p(wp), _p(out), B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, pad, dil, mode, _p(scale), _p(bias), _p(res),
                                          _p(msk), _p(mask_out), flags, zsplit, float(leaky), int(wide), _stream()), "mi_conv_gemm_pp")
         return out
-    check(_timed("igemm_nt_kernel", flops, lambda: _lib.lib().mi_conv_gemm(
+    kern = "igemm_nt_kernel"
+    if PROFILE is not None and _lib.lib().mi_conv_gemm_route(B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, flags):
+        kern = "igemm_pp_kernel"
+    check(_timed(kern, flops, lambda: _lib.lib().mi_conv_gemm(
         _p(a), _p(wp), _p(out), B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, pad, dil, mode,
         _p(scale), _p(bias), _p(res), _p(msk), _p(mask_out), flags, zsplit, float(leaky), _stream()),
-        tag=("dgrad" if mode == GATHER_DGRAD else "fwd", ksize, Ca, N, B * Ho * Wo, flags)), "mi_conv_gemm")
+        tag=("dgrad" if mode == GATHER_DGRAD else "fwd", ksize, Ca, N, B * Ho * Wo, flags, dil)), "mi_conv_gemm")
     return out
 
 
@@ -175,7 +178,7 @@ def conv_wgrad(dy, x, dw, ksize=1, stride=1, pad=0, dil=1, scale=None, accumulat
     flops = 2.0 * B * Ho * Wo * o_real * I * ksize * ksize
     check(_timed("wgrad_tn_kernel+reduce", flops, lambda: L.mi_conv_wgrad(
         _p(dy), _p(x), _p(dw), B, Ha, Wa, I, Ho, Wo, O, ksize, stride, pad, dil, _p(scale),
-        int(accumulate), out_map, int(ncls), dw.numel(), _p(ws), ws.numel(), _stream()), tag=("wgrad", ksize, I, O, B * Ho * Wo, 0)), "mi_conv_wgrad")
+        int(accumulate), out_map, int(ncls), dw.numel(), _p(ws), ws.numel(), _stream()), tag=("wgrad", ksize, I, O, B * Ho * Wo, out_map, dil)), "mi_conv_wgrad")
     return dw
 
 
@@ -207,7 +210,8 @@ def aspp_col2im(z, bias4, B, H, W, K, rates):
     _chk(z, torch.float32, "z")
     _chk(bias4, torch.float32, "bias4")
     low = torch.empty((B, H, W, K), dtype=torch.float32, device=z.device)
-    check(_lib.lib().mi_aspp_col2im(_p(z), _p(bias4), _p(low), B, H, W, K, _rates(rates), _stream()), "mi_aspp_col2im")
+    check(_timed("aspp_col2im_kernel", 0.0, lambda: _lib.lib().mi_aspp_col2im(_p(z), _p(bias4), _p(low), B, H, W, K, _rates(rates), _stream()),
+                 tag=("aspp_aux", 0, 0, 0, B * H * W, 0, 0)), "mi_aspp_col2im")
     return low
 
 
@@ -215,7 +219,8 @@ def aspp_im2col(dlow, rates):
     _chk(dlow, torch.float32, "dlow")
     B, H, W, K = dlow.shape
     g = torch.empty((B, H, W, ASPP_KPAD), dtype=torch.bfloat16, device=dlow.device)
-    check(_lib.lib().mi_aspp_im2col(_p(dlow), _p(g), B, H, W, K, _rates(rates), _stream()), "mi_aspp_im2col")
+    check(_timed("aspp_im2col_kernel", 0.0, lambda: _lib.lib().mi_aspp_im2col(_p(dlow), _p(g), B, H, W, K, _rates(rates), _stream()),
+                 tag=("aspp_aux", 0, 0, 0, B * H * W, 0, 0)), "mi_aspp_im2col")
     return g
 
 
@@ -225,7 +230,8 @@ def aspp_bias_grad(dlow, dbias4, accumulate=False):
     B, H, W, K = dlow.shape
     L = _lib.lib()
     ws = _workspace(L.mi_colsum_workspace(B * H * W, K), dlow.device, "colsum")
-    check(L.mi_aspp_bias_grad(_p(dlow), _p(dbias4), B * H * W, K, int(accumulate), _p(ws), ws.numel(), _stream()), "mi_aspp_bias_grad")
+    check(_timed("colsum_kernels", 0.0, lambda: L.mi_aspp_bias_grad(_p(dlow), _p(dbias4), B * H * W, K, int(accumulate), _p(ws), ws.numel(), _stream()),
+                 tag=("aspp_aux", 0, 0, 0, B * H * W, 0, 0)), "mi_aspp_bias_grad")
     return dbias4
 
 
