@@ -163,11 +163,10 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmParams p) {
     __builtin_amdgcn_s_barrier();                                   // B_0
     if (grp == 1) __builtin_amdgcn_s_barrier();                     // group 1 runs one interval behind (B_1)
 
-    const int dbg = p.zgw >> 8;          // experiment toggles (tools/ppexp.py): 1 no DMA in the loop, 2 no ds_reads, 4 no MFMAs
     for (int s = 0; s < ns; ++s) {
         // ---- read segment (G0: I_2s, G1: I_2s+1) ----
-        if (s + 3 < ns && !(dbg & 1)) stage_next();                               // slab s+3 -> the slot slab s-1 has left
-        if (!(dbg & 2) || s == 0) read_frags(s);
+        if (s + 3 < ns) stage_next();                               // slab s+3 -> the slot slab s-1 has left
+        read_frags(s);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         if (grp == 1) {                                             // end of an odd interval: my pieces of slab s+1 must have landed
@@ -177,7 +176,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmParams p) {
         __builtin_amdgcn_s_barrier();
         // ---- MFMA segment (G0: I_2s+1, G1: I_2s+2) ----
         __builtin_amdgcn_s_setprio(1);
-        if (!(dbg & 4)) mfma_all();
+        mfma_all();
         __builtin_amdgcn_s_setprio(0);
         if (grp == 0) {
             if (s + 3 < ns) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPA) : "memory");
@@ -266,7 +265,7 @@ extern "C" int mi_conv_gemm_pp(const void* a, const void* wp, void* out, int B, 
     p.dil = dil;
     p.mode = gather_mode;
     p.flags = flags;
-    p.zgw = (zgw & 255) > 0 ? zgw : (zgw | 4);
+    p.zgw = zgw > 0 ? zgw : 4;
     p.alpha = alpha;
     if (mtg != 8 && mtg != 10) {           // fewest rounds on 256 CUs, then the least padding
         auto rounds = [&](int bm) { return (((M + bm - 1) / bm) * ((N + 255) / 256) + 255) / 256; };

@@ -201,7 +201,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradParams p) {
             __syncthreads();
         }
     }
-
     // slab[split][t][o][i], i fastest: lane owns o = col, i..i+3 = rows
     float* slab = p.slab + ((long)(split * p.T + t) * p.O) * p.I;
     const int fcol = lane & 15, fq = lane >> 4;

@@ -70,29 +70,7 @@ def run(label, ci, co, k, d, flags, zg=0, rounds=3, iters=20):
     print("%-22s equal=%s/%s  " % (label, eq10, eq8) + "  ".join("%s %6.1f us %5.0f TF" % (n, min(v) * 1e6, flops / min(v) / 1e12) for n, v in res.items()))
 
 
-def toggles(label, ci, co, k, d, flags, iters=20):
-    """Where does an interval of the ping-pong loop go?  Main loop only (no stores), components switched off one at a time."""
-    x = torch.randn((B, H, H, ci), device="cuda").to(torch.bfloat16)
-    wp = K.pack_weight_fwd(torch.randn((co, ci, k, k), device="cuda") * 0.05)
-    out = torch.zeros((B, H, H, co), device="cuda", dtype=torch.bfloat16)
-    bits = torch.zeros((B, H, H, co // 16), device="cuda", dtype=torch.int16)
-    sc, sh = torch.rand(co, device="cuda") + 0.5, torch.randn(co, device="cuda")
-    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    pad = d if k == 3 else 0
-    ns = k * k * ci // 32
-    for dbg, name in ((0, "all"), (1, "no DMA"), (2, "no ds_read"), (4, "no MFMA"), (3, "MFMA only"), (6, "DMA only"), (5, "ds_read only"), (7, "barriers only")):
-        f = lambda: L.mi_conv_gemm_pp(P(x), P(wp), P(out), B, H, H, ci, H, H, co, k, 1, pad, d, 0, P(sc), P(sh), None, P(bits), P(bits), flags, dbg << 8,
-                                      ctypes.c_float(0.0), 10, st)
-        assert f() == 0, L.mi_last_error()
-        t = min(timeit(f, iters) for _ in range(3))
-        print("  %-22s %-14s %7.1f us  (%5.0f ns per slab)" % (label, name, t * 1e6, t * 1e9 / ns))
-
-
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "toggles":
-        toggles("3x3 256 d2", 256, 256, 3, 2, 69)
-        toggles("1x1 2048->512", 2048, 512, 1, 1, 69)
-        sys.exit(0)
     run("3x3 256 d2 fwd f69", 256, 256, 3, 2, 69)
     run("3x3 256 d2 dgrad f128", 256, 256, 3, 2, 128)
     run("3x3 512 d4 fwd f69", 512, 512, 3, 4, 69)

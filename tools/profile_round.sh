@@ -2,7 +2,7 @@
 # Round profile on the GPU box: rocprofv3 kernel stats of bench.py (default two-stream schedule, and single-stream), then the
 # three PMC passes (single stream: MI_WGRAD_STREAM=0 MI_BATCH_LANES=1, so that counters and durations are attributable per kernel).  Outputs under gpurun_out/<tag>_*.
 # usage: bash tools/profile_round.sh <tag>
-tag=${1:-r01}
+tag=${1:-r02}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 B="python3 $root/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-kernel-events"
@@ -16,3 +16,5 @@ grep -h "^{" $root/gpurun_out/${tag}_stats.log $root/gpurun_out/${tag}_stats_1s.
 # the trace CSVs are large: keep only stats + counter collections
 rm -f $root/gpurun_out/${tag}_*/bench_kernel_trace.csv
 ls -la $root/gpurun_out/${tag}_*/ | head -40
+# counters -> profiles/pmc.json (FETCH_SIZE x2 / WRITE_SIZE per MI355X_MICROARCH.md), stamped with the commit being profiled
+python3 $root/profiles/make_pmc_json.py $root/gpurun_out/${tag}_pmcA $root/gpurun_out/${tag}_pmcB $root/gpurun_out/${tag}_pmcC $root/gpurun_out/${tag}_pmc.json $tag > /dev/null 2>&1 || echo "pmc json failed"
