@@ -422,7 +422,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         float s = 0.f;
         if (ii < ni) {
             const float* src = slab + (long)t * plane + (long)o * I + ib + ii;
-            for (int k = 0; k < S; ++k) s += src[(long)k * T * plane];
+            const long sstride = (long)T * plane;
+            // eight partial planes per batch: the loads are issued together (this kernel lives on bytes in flight), the additions
+            // keep the ascending-split order, so the sum is the same fixed-order sum as a plain loop
+            int k = 0;
+            for (; k + 8 <= S; k += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[(long)(k + u) * sstride];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+            for (; k < S; ++k) s += src[(long)k * sstride];
         }
         tile[ii * T + t] = s * sc;
     }
