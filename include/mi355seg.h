@@ -220,6 +220,18 @@ int mi_stem_f32(const float* x_nchw, const float* w, const float* scale, const f
                 int B, int H, int W, void* stream);
 int mi_maxpool_f32(const float* y_nhwc, float* pool_nhwc, int B, int Hc, int Wc, int C, void* stream);
 
+/* ---- data-parallel gradient exchange over RCCL (csrc/comm.hip) ----------------------------------------------
+ * For hosts that do not go through torch.distributed (the Python product does: host/ddp.py, backend "nccl" = RCCL).  One process
+ * per GPU; rank 0 calls mi_comm_unique_id and passes the 128 bytes to the other ranks by its own means; every rank calls
+ * mi_comm_init_rank; per step each bucket of the flat fp32 gradient buffer is averaged in place with mi_allreduce_bucket on a
+ * side stream (order it after the bucket's weight-gradient launches with an event) and the optimizer stream waits for that
+ * stream before mi_sgd_step.  librccl.so is resolved at the first call (dlopen; a copy already in the process is reused).
+ * dtype: 0 = fp32, 1 = bf16; average != 0 divides by the number of ranks (ncclAvg). */
+int mi_comm_unique_id(void* id128 /* host, 128 bytes out */);
+int mi_comm_init_rank(void** comm /* out */, int nranks, const void* id128 /* host */, int rank);
+int mi_comm_destroy(void* comm);
+int mi_allreduce_bucket(void* ptr, size_t count, int dtype, int average, void* comm, void* stream);
+
 /* ---- elementwise helpers ------------------------------------------------------------------------ */
 /* y = msk > 0 ? x : 0 (bf16, n % 8 == 0): ReLU backward across an autograd boundary.  bits != 0: `msk` is the packed
  * sign-bit tensor written by MI_EPI_WRITE_MASK (same element order). */

@@ -53,6 +53,10 @@ SIGNATURES = {
     "mi_conv_f32": (I, [P, P, P] + [I] * 11 + [P, P, P, I, P]),
     "mi_stem_f32": (I, [P, P, P, P, P, I, I, I, P]),
     "mi_maxpool_f32": (I, [P, P, I, I, I, I, P]),
+    "mi_comm_unique_id": (I, [P]),
+    "mi_comm_init_rank": (I, [P, I, P, I]),
+    "mi_comm_destroy": (I, [P]),
+    "mi_allreduce_bucket": (I, [P, Z, I, I, P, P]),
     "mi_relu_mask": (I, [P, P, P, Z, I, P]),
     "mi_frozen_bn_fold": (I, [P, P, P, P, P, P, I, P]),
 }

@@ -224,3 +224,63 @@ def test_two_rank_gloo_fada_iteration(tmp_path):
     od.step()
     want = torch.cat([p.detach().reshape(-1) for m in (fe, cls, D) for p in m.parameters()]).numpy()
     assert np.abs(p0 - want).max() <= 5e-6 * np.abs(want).max()
+
+
+# ------------------------------------------------------------------------------------------------ overlapped exchange
+def _overlap_worker(rank, world, port, tmpdir):
+    """Stand-in for engine.StageEngine.backward: the real engine reports finished gradient ranges block by block, last block
+    first, through FlatStore.grad_hooks (engine.py: `hook(store, lo, hi)` after each bottleneck's weight gradients are enqueued).
+    Here autograd produces the gradients and the hooks are fired the same way, so that buckets are exchanged BEFORE finish()."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    try:
+        out = {}
+        for mode in ("serial", "overlap", "bf16"):
+            fe, cls = _models()
+            st_cls = engine.FlatStore(list(cls.named_parameters()), torch.device("cpu"))
+            st_fe = engine.FlatStore(list(fe.named_parameters()), torch.device("cpu"))
+            red = ddp.GradAllReducer([st_cls, st_fe], bucket_bytes=64 << 10, overlap=mode != "serial", payload="bf16" if mode == "bf16" else "fp32")
+            assert len(red.buckets[id(st_fe)]) >= 4
+            x, lab = _batch(rank)
+            torch.nn.functional.cross_entropy(cls(fe(x), lab.shape[-2:]), lab.long(), ignore_index=255).backward()
+            local = {"cls": st_cls.grad.clone(), "fe": st_fe.grad.clone()}
+            launched_early = 0
+            # head first (its gradients complete first), then the backbone's parameters in reverse layout order, four "blocks"
+            for hook in st_cls.grad_hooks:
+                hook(st_cls, 0, st_cls.total)
+            cuts = [st_fe.offsets[i] for i in range(len(st_fe.offsets) - 1, -1, -max(1, len(st_fe.offsets) // 4))] + [0]
+            hi = st_fe.total
+            for lo in cuts:
+                for hook in st_fe.grad_hooks:
+                    hook(st_fe, lo, hi)
+                hi = lo
+                launched_early = sum(b.launched for b in red.buckets[id(st_fe)])
+            if mode == "serial":
+                assert launched_early == 0                                  # overlap off: nothing leaves before finish()
+            else:
+                assert launched_early == len(red.buckets[id(st_fe)])        # every bucket was exchanged by a hook, none left for finish()
+            red.finish()
+            assert not any(b.launched for b in red.buckets[id(st_fe)])      # reset for the next step
+            out[mode] = {"cls": st_cls.grad.clone(), "fe": st_fe.grad.clone(), "local": local}
+        torch.save(out, os.path.join(tmpdir, "overlap_%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_overlapped_bucket_exchange_and_bf16_payload(tmp_path):
+    port = _free_port()
+    mp.spawn(_overlap_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / ("overlap_%d.pt" % r)) for r in range(2))
+    for tag in ("cls", "fe"):
+        want = (r0["serial"]["local"][tag] + r1["serial"]["local"][tag]) / 2
+        # fp32 payload: overlapped == serial == the average of the two local gradients, identical on both ranks
+        for mode in ("serial", "overlap"):
+            assert torch.equal(r0[mode][tag], r1[mode][tag])
+            assert torch.allclose(r0[mode][tag], want, rtol=1e-6, atol=1e-12)
+        assert torch.equal(r0["serial"][tag], r0["overlap"][tag])
+        # bf16 payload: each rank's contribution rounded to bf16, summed in fp32, average rounded to bf16 once
+        exp = ((r0["bf16"]["local"][tag].to(torch.bfloat16).float() + r1["bf16"]["local"][tag].to(torch.bfloat16).float()) / 2).to(torch.bfloat16).float()
+        assert torch.equal(r0["bf16"][tag], exp) and torch.equal(r1["bf16"][tag], exp)
+        err = (r0["bf16"][tag] - want).abs().max() / want.abs().max()
+        assert err < 2.0 ** -7, err                                         # two bf16 roundings of an fp32 average

@@ -86,3 +86,34 @@ def test_opt_in_kernel_variants_and_single_stream_schedule_stay_correct():
         r = run(["-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider"] + sel, env)
         assert r.returncode == 0, (env, r.stdout[-3000:])
         assert " passed" in r.stdout and " failed" not in r.stdout
+
+
+def test_rccl_entry_points_of_the_cabi_single_rank_communicator():
+    """mi_comm_unique_id / mi_comm_init_rank / mi_allreduce_bucket / mi_comm_destroy (include/mi355seg.h): the
+    exchange a non-Python host drives itself.  One rank is all this box has: a 1-rank communicator must return the bucket
+    unchanged for sum and for average, fp32 and bf16, on a side stream, and report errors as codes."""
+    code = r'''
+import ctypes, torch
+from rnd_semantic_segmentation_amd import _lib
+L = _lib.lib()
+uid = ctypes.create_string_buffer(128)
+assert L.mi_comm_unique_id(uid) == 0, L.mi_last_error()
+comm = ctypes.c_void_p()
+assert L.mi_comm_init_rank(ctypes.byref(comm), 1, uid, 0) == 0, L.mi_last_error()
+side = torch.cuda.Stream()
+for dtype, code_ in ((torch.float32, 0), (torch.bfloat16, 1)):
+    x = (torch.arange(100003, device="cuda") % 251).to(dtype)
+    want = x.clone()
+    ev = torch.cuda.Event(); ev.record(); side.wait_event(ev)
+    for avg in (0, 1):
+        assert L.mi_allreduce_bucket(ctypes.c_void_p(x.data_ptr()), x.numel(), code_, avg, comm, ctypes.c_void_p(side.cuda_stream)) == 0, L.mi_last_error()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert torch.equal(x, want), dtype
+assert L.mi_allreduce_bucket(None, 4, 0, 0, comm, None) == -22
+assert L.mi_allreduce_bucket(ctypes.c_void_p(16), 4, 7, 0, comm, None) == -22 and b"dtype" in L.mi_last_error()
+assert L.mi_comm_destroy(comm) == 0
+print("rccl c-abi ok")
+'''
+    r = run(["-c", code], {})
+    assert r.returncode == 0 and "rccl c-abi ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
