@@ -36,12 +36,13 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
 // the stores (out / res may alias as far as the compiler knows): one HBM round trip per 16 rows.
 template <int MT, int EPI, bool WANT_RES = true>
 __device__ __forceinline__ void igemm_fetch_epilogue(const IgemmParams& p, int m0, int n0, int wm, int wn, int frow, int fq, bf16x8 (&pres)[MT][2],
-                                                     unsigned (&pbits)[MT]) {
+                                                     unsigned (&pbits)[MT], const int* mrow = nullptr) {
     const int flags = (EPI >= 0 ? EPI : p.flags) & (WANT_RES ? ~0 : ~MI_EPI_RESIDUAL);
     const int nbp = n0 + wn * 64 + 8 * fq;
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
-        const int m = m0 + wm * (MT * 16) + j * 16 + frow;
+        // mrow (igemm_pw_kernel): the tile's rows are padded pixel coordinates; mrow[j] is the pixel of this lane's row j, or -1
+        const int m = mrow ? (mrow[j] < 0 ? p.M : mrow[j]) : m0 + wm * (MT * 16) + j * 16 + frow;
         const long o0 = (long)(m < p.M ? m : 0) * p.N + (nbp < p.N ? nbp : 0);
         const long o1 = (long)(m < p.M ? m : 0) * p.N + (nbp + 32 < p.N ? nbp + 32 : 0);
         if (flags & MI_EPI_RESIDUAL) {
@@ -62,7 +63,8 @@ __device__ __forceinline__ void igemm_fetch_epilogue(const IgemmParams& p, int m
 // global memory; igemm_store_staged() then writes the tile out with row-contiguous lanes.
 template <int MT, int EPI, bool STAGED = false>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[4][MT], int m0, int n0, int wm, int wn, int frow, int fq,
-                                               bf16x8 (&pres)[MT][2], unsigned (&pbits)[MT], char* stage = nullptr, bool mask_lds = false) {
+                                               bf16x8 (&pres)[MT][2], unsigned (&pbits)[MT], char* stage = nullptr, bool mask_lds = false,
+                                               const int* mrow = nullptr) {
     const int flags = EPI >= 0 ? EPI : p.flags;
     // ---- epilogue: lane owns pixel m (D col) and two groups of 8 contiguous channels: h = 0 -> nb .. nb+7 (MFMA tiles 0, 1),
     //      h = 1 -> nb+32 .. nb+39 (tiles 2, 3); tile i holds channels nb + 32*(i>>1) + 4*(i&1) + (0..3) ------------------------
@@ -96,7 +98,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
     }
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
-        const int m = m0 + wm * (MT * 16) + j * 16 + frow;
+        const int m = mrow ? (mrow[j] < 0 ? p.M : mrow[j]) : m0 + wm * (MT * 16) + j * 16 + frow;
         if (m >= p.M) continue;
         const long o = (long)m * p.N + nb;       // group h starts at o + 32*h
         f32x4 v[4];

@@ -19,11 +19,14 @@
 //   every wave waits for ITS DMA pieces of slab p+1 (vmcnt, two younger slabs stay in flight) at the end of I_2p+1, so that
 //   after B_2p+2 the slab is visible to group 0 and after B_2p+3 to group 1;
 //   slab p+3 lands in the slot of slab p-1, whose last reader (G1 in I_2p-1) finished its ds_reads (lgkmcnt(0)) before B_2p.
+// (Tried and dropped: issuing half of a slab's DMA pieces at the head of the MFMA segment instead of the read segment - the
+// MFMA segments stretch more than the read segments shrink: 3x3 256 main loop 86 vs 73.5 us.)
 // LDS image of a slab: A rows then W rows, 64 B (32 channels) per row, lane-linear per 1-KiB DMA piece (16 rows); the 16-B chunk
 // c of row r sits at chunk c ^ s(r), applied to the per-lane SOURCE address and to the ds_read_b128 address, with
 // s_A(r) = (-(r >> 2)) & 3 and s_W(r) = ((r >> 3) & 1) << 1: both make every ds_read_b128 lane group hit 64 distinct banks
 // (brute-forced over the instruction's four 16-lane groups; W rows are read in the permuted order of igemm_nt.hip).
 #include "igemm_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -199,6 +202,226 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmParams p) {
     igemm_epilogue<MTG, EPI>(p, acc, m0, n0, grp, wq, frow, fq, pres, pbits);
 }
 
+// =====================================================================================================================
+// igemm_pw_kernel: the ping-pong main loop for 3x3 convs with the three taps of a kernel row sharing ONE A window.
+//
+// The 3x3 launches of igemm_pp_kernel are held back by the L2 -> LDS stream (35 us of DMA beside 42 us of MFMA at 256 -> 256,
+// issued from the read segments, which then outlast the MFMA segments).  The taps (ky, 0..2) read the SAME input row at
+// columns w-d, w, w+d: one LDS window of 320 + 2d pixel rows serves all three, so the A traffic falls to a third
+// (68.5 KiB instead of 108 KiB per three phases) and group 0 issues its DMA once per three phases.
+// As in the fused-row weight gradient the tile rows are PADDED pixel coordinates q = (b*H + h) * (W + 2d) + wp with d zero
+// slots on either side of every image row: the A row of output row q for tap kx is window row (q - q0) + d * (1 + sgn*(kx-1))
+// for every q, inside the image the right source pixel, outside a pad slot = the convolution's zero padding - no per-tap
+// validity.  Pad rows are computed (2d / W more rows) and not stored; the epilogue maps q back to the pixel.
+// K order: ky, 32-channel chunk c, kx.  LDS: two A windows (336 rows x 64 B) + a six-slot ring of W slabs (256 x 64 B), 138 KiB.
+// Group 0 stages window (ky, c)+1 during the first phase of window (ky, c) and waits for it (vmcnt(0): it issues nothing else)
+// at the end of the window's last MFMA segment, five intervals later; group 1 streams the W slabs four phases ahead.
+// sgn = +1 forward (source = out + (tap-1)*d), -1 data gradient (source = out - (tap-1)*d; weights packed [tap][i][o]).
+template <int MTG> struct PWGeo {
+    static constexpr int BMG = 16 * MTG, BM = 2 * BMG, BN = 256;
+    static constexpr int WROWS = 336, WIN = WROWS * 64;             // A window: BM + 2d rows rounded up to whole 16-row pieces (d <= 8)
+    static constexpr int NWIN = 2, NWS = 6, SLAB_W = BN * 64;
+    static constexpr int W0 = NWIN * WIN, LDS_BYTES = W0 + NWS * SLAB_W;     // 42 KiB + 96 KiB
+    static constexpr int PA = WROWS / 16;                           // 21 pieces: wave wq of group 0 moves pieces wq*5 .. wq*5+4, wave 0 also piece 20
+    static constexpr int NPW = 4;
+    static_assert(BM + 16 <= WROWS, "window too small");
+};
+
+template <int MTG, int EPI>
+__global__ __launch_bounds__(512, 1) void igemm_pw_kernel(IgemmParams p) {
+    using G = PWGeo<MTG>;
+    constexpr int BM = G::BM, BN = G::BN, BMG = G::BMG, WIN = G::WIN, W0 = G::W0, SLAB_W = G::SLAB_W, NPW = G::NPW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wq = wave & 3;
+    const int nwg = p.m_tiles * p.n_tiles;
+    const int tile = mi_xcd_remap(blockIdx.x, nwg);
+    const int mt = tile / p.n_tiles, nt = tile - mt * p.n_tiles;
+    const int q0 = mt * BM, n0 = nt * BN;
+    const int d = p.dil, WP = p.Wa + 2 * d, H = p.Ha, W = p.Wa;
+    const int Q = p.M;                                   // padded coordinates: B * H * (W + 2d) (set by the launcher; p.zgw holds the pixel count)
+    const int sgn = (p.mode == MI_GATHER_FWD) ? 1 : -1;
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+    const int prow = lane >> 2, pch = lane & 3;
+    const int spt = p.Ca >> 5;                           // 32-channel chunks
+    const int nwnd = 3 * spt, nph = 9 * spt;
+
+    // ---- group 0: A windows --------------------------------------------------------------------------------------------------
+    constexpr int NPA = 6;
+    const char* a_base[NPA];       // source of the row for ky = 1, chunk 0 (+ swizzled 16-B chunk)
+    unsigned a_ok[NPA];            // bit ky: the row exists for that kernel row
+    const int a_np = (grp == 0) ? (wq == 0 ? 6 : 5) : 0;
+    if (grp == 0) {
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            const int piece = (i < 5) ? wq * 5 + i : 20;
+            const int row = piece * 16 + prow;
+            const int chunk = (pch ^ ((-(row >> 2)) & 3)) * 16;
+            const int qw = q0 - d + row;
+            const int qs = qw + WP;                                           // >= 0
+            const int bh = qs / WP - 1, wp = qs - (bh + 1) * WP;
+            const bool real = (unsigned)qw < (unsigned)Q && (unsigned)(wp - d) < (unsigned)W;
+            const int h = bh < 0 ? 0 : bh % H;
+            unsigned ok = 0;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) ok |= (unsigned)(real && (unsigned)(h + sgn * (ky - 1) * d) < (unsigned)H) << ky;
+            a_ok[i] = (i < a_np) ? ok : 0u;
+            a_base[i] = reinterpret_cast<const char*>(p.A + ((long)(real ? bh : 0) * W + (real ? wp - d : 0)) * p.Ca) + chunk;
+        }
+    }
+    int lw = 0, lw_ky = 0, lw_c = 0;                     // next window to stage
+    const long ky_bytes = (long)sgn * d * W * p.Ca * 2;  // one kernel row up / down
+    auto stage_window = [&]() {
+        char* dst = smem + (lw & 1) * WIN;
+        const long off = (long)(lw_ky - 1) * ky_bytes + (long)lw_c * 64;
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            if (i < a_np) {
+                const int piece = (i < 5) ? wq * 5 + i : 20;
+                glds16(((a_ok[i] >> lw_ky) & 1u) ? a_base[i] + off : zero, dst + piece * 1024);
+            }
+        }
+        ++lw;
+        if (++lw_c == spt) {
+            lw_c = 0;
+            ++lw_ky;
+        }
+    };
+    // ---- group 1: W slabs -------------------------------------------------------------------------------------------------------
+    const char* w_base[NPW];
+    bool w_ok[NPW];
+    if (grp == 1) {
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int rl = (wq * NPW + i) * 16 + prow;
+            const int n = n0 + rl;
+            const int chunk = (pch ^ (((rl >> 3) & 1) << 1)) * 16;
+            w_ok[i] = n < p.N;
+            w_base[i] = reinterpret_cast<const char*>(p.Wp + (long)(w_ok[i] ? n : 0) * p.Ca) + chunk;
+        }
+    }
+    const long w_tap_bytes = (long)p.N * p.Ca * 2;
+    int ls = 0, ls_ky = 0, ls_c = 0, ls_kx = 0;          // next W slab to stage (phase order: ky, c, kx)
+    auto stage_w = [&]() {
+        char* dst = smem + W0 + (ls % G::NWS) * SLAB_W + wq * (NPW * 1024);
+        const long off = (long)(ls_ky * 3 + ls_kx) * w_tap_bytes + (long)ls_c * 64;
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) glds16(w_ok[i] ? w_base[i] + off : zero, dst + i * 1024);
+        ++ls;
+        if (++ls_kx == 3) {
+            ls_kx = 0;
+            if (++ls_c == spt) {
+                ls_c = 0;
+                ++ls_ky;
+            }
+        }
+    };
+
+    // ---- compute roles ---------------------------------------------------------------------------------------------------------
+    f32x4 acc[4][MTG];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MTG; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fq = lane >> 4;
+    int a_off[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int rb = grp * BMG + frow + d * (1 + sgn * (kx - 1));          // window row of this lane's row 0 for tap kx
+        a_off[kx] = rb * 64 + ((fq ^ ((-(rb >> 2)) & 3)) << 4);               // (rb + 16 j) >> 2 has the same low two bits
+    }
+    const int w_off = (wq * 64 + 8 * (frow >> 2) + (frow & 3)) * 64 + ((fq ^ (((frow >> 2) & 1) << 1)) << 4);
+    bf16x8 wf[4], af[MTG];
+    auto read_frags = [&](int wnd, int kx, int ph) {
+        const char* wb = smem + W0 + (ph % G::NWS) * SLAB_W + w_off;
+        const char* ab = smem + (wnd & 1) * WIN + (kx == 0 ? a_off[0] : (kx == 1 ? a_off[1] : a_off[2]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(wb + (32 * (i >> 1) + 4 * (i & 1)) * 64);
+#pragma unroll
+        for (int j = 0; j < MTG; ++j) af[j] = *reinterpret_cast<const bf16x8*>(ab + j * 1024);
+    };
+    auto mfma_all = [&]() {
+#pragma unroll
+        for (int j = 0; j < MTG; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+    };
+
+    // ---- prologue: window 0 and W slabs 0..3 in flight; window 0 and slab 0 landed ------------------------------------------------
+    if (grp == 0) {
+        stage_window();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        for (int s = 0; s < 4 && s < nph; ++s) stage_w();
+        if (nph >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                                   // B_0
+    if (grp == 1) __builtin_amdgcn_s_barrier();                     // group 1 runs one interval behind
+
+    int wnd = 0, kx = 0;
+    for (int ph = 0; ph < nph; ++ph) {
+        // ---- read segment (G0: I_2ph, G1: I_2ph+1) ----
+        if (grp == 0) {
+            if (kx == 0 && wnd + 1 < nwnd) stage_window();          // window wnd+1 -> the slot window wnd-1 has left (last read in I_2ph-1)
+        } else {
+            if (ph + 4 < nph) stage_w();                            // slab ph+4 -> the slot of slab ph-2
+        }
+        read_frags(wnd, kx, ph);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp == 1) {                                             // end of an odd interval: my pieces of slab ph+1 must have landed
+            if (ph + 4 < nph) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        // ---- MFMA segment (G0: I_2ph+1, G1: I_2ph+2) ----
+        __builtin_amdgcn_s_setprio(1);
+        mfma_all();
+        __builtin_amdgcn_s_setprio(0);
+        if (grp == 0 && kx == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // window wnd+1 (issued five intervals ago)
+        __builtin_amdgcn_s_barrier();
+        if (++kx == 3) {
+            kx = 0;
+            ++wnd;
+        }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+
+    // ---- epilogue: padded coordinate of each of the lane's rows -> pixel (or -1: pad slot / beyond the last image) ------------------
+    int mrow[MTG];
+    {
+        const int qb = q0 + grp * BMG + frow;
+        int bh = qb / WP, wp = qb - bh * WP;
+#pragma unroll
+        for (int j = 0; j < MTG; ++j) {
+            const bool real = (qb + 16 * j) < Q && (unsigned)(wp - d) < (unsigned)W;
+            mrow[j] = real ? bh * W + wp - d : -1;
+            wp += 16;                                    // WP >= 16 (launcher): at most one carry
+            if (wp >= WP) {
+                wp -= WP;
+                ++bh;
+            }
+        }
+    }
+    IgemmParams pe = p;
+    pe.M = p.zgw;                                        // the epilogue's bound is the pixel count
+    bf16x8 pres[MTG][2];
+    unsigned pbits[MTG];
+    igemm_fetch_epilogue<MTG, EPI>(pe, 0, n0, grp, wq, frow, fq, pres, pbits, mrow);
+    igemm_epilogue<MTG, EPI>(pe, acc, 0, n0, grp, wq, frow, fq, pres, pbits, nullptr, false, mrow);
+}
+
+template <int EPI>
+void launch_pw(dim3 grid, hipStream_t stream, const IgemmParams& p) {
+    static std::atomic<uint64_t> attr_done{0};
+    auto kern = igemm_pw_kernel<10, EPI>;
+    constexpr int lds = PWGeo<10>::LDS_BYTES;
+    mi_allow_dynamic_lds((const void*)kern, lds, attr_done);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p);
+}
+
 template <int MTG, int EPI>
 void launch_pp(dim3 grid, hipStream_t stream, const IgemmParams& p) {
     static std::atomic<uint64_t> attr_done{0};
@@ -267,6 +490,29 @@ extern "C" int mi_conv_gemm_pp(const void* a, const void* wp, void* out, int B, 
     p.flags = flags;
     p.zgw = zgw > 0 ? zgw : 4;
     p.alpha = alpha;
+    // 3x3 with the hot epilogues: the shared-window kernel (mtg == 0 only: an explicit 8 / 10 selects igemm_pp_kernel).
+    // MI_IGEMM_PW: 0 = off (default: measured 90 vs 85 us at 3x3 256, 311 vs 290 at 3x3 512 - see DESIGN.md section 8), 1 = by rule,
+    // 2 = always when the geometry allows (tests on tiny shapes)
+    static int pw_mode = -1;
+    if (pw_mode < 0) {
+        const char* e = getenv("MI_IGEMM_PW");
+        pw_mode = e ? atoi(e) : 0;
+    }
+    const int WPad = Wa + 2 * dil;
+    const long Qp = (long)B * Ha * WPad;
+    if ((mtg == 3 || (mtg == 0 && pw_mode)) && ksize == 3 && pad == dil && dil <= 8 && WPad >= 16 && (flags == 69 || flags == 128) && Qp < (1L << 31) &&
+        (pw_mode == 2 || mtg == 3 || M >= 320 * 64)) {
+        p.M = (int)Qp;                     // the kernel's rows are padded coordinates; the pixel count travels in zgw (unused by these epilogues)
+        p.zgw = (int)M;
+        p.m_tiles = (int)((Qp + 319) / 320);
+        p.n_tiles = (N + 255) / 256;
+        const dim3 gridw(p.m_tiles * p.n_tiles);
+        if (flags == 69) launch_pw<69>(gridw, (hipStream_t)stream, p);
+        else launch_pw<128>(gridw, (hipStream_t)stream, p);
+        MI_CHECK_LAUNCH("mi_conv_gemm_pp (shared window)");
+        return MI_OK;
+    }
+    if (mtg == 3) return mi_set_error(MI_EINVAL, "mi_conv_gemm_pp: mtg 3 (shared-window kernel) needs a 3x3 conv with pad == dil <= 8 and flags 69 or 128");
     if (mtg != 8 && mtg != 10) {           // fewest rounds on 256 CUs, then the least padding
         auto rounds = [&](int bm) { return (((M + bm - 1) / bm) * ((N + 255) / 256) + 255) / 256; };
         mtg = rounds(320) < rounds(256) ? 10 : (rounds(256) < rounds(320) ? 8 : (((M + 319) / 320) * 320 <= ((M + 255) / 256) * 256 ? 10 : 8));

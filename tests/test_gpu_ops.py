@@ -163,13 +163,16 @@ def test_pointwise_wide_conv_all_hot_epilogues_vs_torch(ci, co, B, H, W):
 
 
 @pytest.mark.parametrize("B,H,W,ci,co,k,d", [(2, 13, 11, 64, 256, 3, 2), (1, 19, 23, 96, 288, 3, 4), (3, 9, 10, 128, 512, 1, 1), (2, 7, 5, 32, 64, 3, 1)])
-@pytest.mark.parametrize("mtg", [8, 10])
+@pytest.mark.parametrize("mtg", [8, 10, 3])
 def test_wide_tile_ping_pong_main_loop_vs_oracle_and_128_wide_kernel(B, H, W, ci, co, k, d, mtg):
     """csrc/igemm_pp.hip called directly on small / ragged shapes (M and N tails inside one 320 x 256 tile, a single slab, taps
     that fall into the padding): forward and data-gradient gathers with the epilogues the network launches.  Both main loops add
     the products of one output element in the same order (tap-major, channels ascending, 32 per MFMA), so their results must be
     BIT-equal; the oracle pins the value."""
     pad = d if k == 3 else 0
+    shared_window = mtg == 3                 # igemm_pw_kernel: 3x3 only, the two hot epilogues only (flags 69 forward, 128 data gradient)
+    if shared_window and (k != 3 or W + 2 * d < 16):
+        pytest.skip("the shared-window kernel is the 3x3 kernel")
     x = synth.bf16_round(synth.uniform("pp.x", (B, ci, H, W)) * 4)
     w = synth.bf16_round(synth.formula_tensor("pp.weight", (co, ci, k, k)))
     dy = synth.bf16_round(synth.uniform("pp.dy", (B, co, H, W)) * 2)
@@ -177,6 +180,28 @@ def test_wide_tile_ping_pong_main_loop_vs_oracle_and_128_wide_kernel(B, H, W, ci
     wd = dev(w)
     wp, wpt = K.pack_weight_fwd(wd), K.pack_weight_dgrad(wd)
     sc, sh = dev(1 + synth.uniform("pp.s", (co,))), dev(synth.uniform("pp.b", (co,)))
+    if shared_window:
+        # FrozenBN + ReLU + sign bits (69): bf16 output within one ulp of exact math, sign bits consistent with the output
+        bo = torch.zeros((B, H, W, co // 16), dtype=torch.int16, device=DEV)
+        yo = K.conv_gemm(xd, wp, (H, W), k, 1, pad, d, scale=sc, bias=sh, relu=True, mask_out=bo, wide=3)
+        want = np.maximum(ref_ops.conv2d(x, w, None, 1, pad, d) * sc.cpu().numpy().reshape(1, -1, 1, 1) + sh.cpu().numpy().reshape(1, -1, 1, 1), 0)
+        assert relmax(to_nchw(yo), want) < 2.0 ** -8
+        bits = (bo.view(torch.uint8).cpu().numpy()[..., None] >> np.arange(8)) & 1            # [B,H,W,co/8,8]
+        assert np.array_equal(bits.reshape(B, H, W, co).astype(bool), (yo.float().cpu().numpy() > 0))
+        if ci % 64 == 0:                     # the 128-wide kernel can run the same launch: bit-equal
+            b0 = torch.zeros_like(bo)
+            y0 = K.conv_gemm(xd, wp, (H, W), k, 1, pad, d, scale=sc, bias=sh, relu=True, mask_out=b0, wide=None)
+            assert torch.equal(y0, yo) and torch.equal(b0, bo)
+        # data gradient through the ReLU mask of a [B,H,W,ci] activation (128)
+        if ci % 16 == 0 and co % 32 == 0:
+            mb = torch.randint(-32768, 32767, (B, H, W, ci // 16), dtype=torch.int16, device=DEV)
+            g1 = K.conv_gemm(dyd, wpt, (H, W), k, 1, pad, d, K.GATHER_DGRAD, bits=mb, wide=3)
+            keep = ((mb.view(torch.uint8).cpu().numpy()[..., None] >> np.arange(8)) & 1).reshape(B, H, W, ci).astype(bool)
+            gw = np.where(np.transpose(keep, (0, 3, 1, 2)), ref_ops.conv2d_dgrad(dy, w, (H, W), 1, pad, d), 0)
+            assert relmax(to_nchw(g1), gw) < 2.0 ** -8
+            if co % 64 == 0:
+                assert torch.equal(K.conv_gemm(dyd, wpt, (H, W), k, 1, pad, d, K.GATHER_DGRAD, bits=mb, wide=None), g1)
+        return
     # forward, plain fp32 store: against exact math
     y = K.conv_gemm(xd, wp, (H, W), k, 1, pad, d, out_f32=True, wide=mtg)
     assert relmax(to_nchw(y), ref_ops.conv2d(x, w, None, 1, pad, d)) < 2e-5

@@ -60,6 +60,16 @@ def run(label, ci, co, k, d, flags, zg=0, rounds=3, iters=20):
         print("  !! outputs differ: max|d| mtg10 %.3e mtg8 %.3e (|out| max %.3e)" % (d10, d8, outs[0].float().abs().max().item()))
     flops = 2.0 * B * H * H * ci * co * k * k
     res = {"base": [], "pp10": [], "pp8": [], "base-loop": [], "pp10-loop": []}
+    pw_ok = k == 3 and flags in (69, 128)
+    if pw_ok:
+        outs.append(torch.zeros_like(outs[0]))
+        bits_out.append(torch.zeros_like(bits_out[0]) if bits_out[0] is not None else None)
+        assert pp(3, 3) == 0, L.mi_last_error()
+        torch.cuda.synchronize()
+        eqw = torch.equal(outs[0], outs[3]) and (bits_out[0] is None or torch.equal(bits_out[0], bits_out[3]))
+        dw_ = (outs[0].float() - outs[3].float()).abs().max().item()
+        print("  shared-window kernel (K order ky, c, kx instead of ky, kx, c): bit-equal %s, max|d| %.3e of |out| max %.3e" % (eqw, dw_, outs[0].float().abs().max().item()))
+        res["pw"] = []
     nost = 1 << 30
     for _ in range(rounds):
         res["base"].append(timeit(lambda: base(0), iters))
@@ -67,6 +77,8 @@ def run(label, ci, co, k, d, flags, zg=0, rounds=3, iters=20):
         res["pp8"].append(timeit(lambda: pp(8, 2), iters))
         res["base-loop"].append(timeit(lambda: base(0, nost), iters))
         res["pp10-loop"].append(timeit(lambda: pp(10, 1, nost), iters))
+        if pw_ok:
+            res["pw"].append(timeit(lambda: pp(3, 3), iters))
     print("%-22s equal=%s/%s  " % (label, eq10, eq8) + "  ".join("%s %6.1f us %5.0f TF" % (n, min(v) * 1e6, flops / min(v) / 1e12) for n, v in res.items()))
 
 
