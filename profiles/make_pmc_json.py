@@ -48,10 +48,16 @@ def main():
                   "hbm_read_bytes_per_launch": round(fetch), "hbm_write_bytes_per_launch": round(write),
                   "hbm_bytes_per_launch": round(fetch + write)}
     import subprocess
-    try:
-        commit = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
-    except OSError:
-        commit = None
+    import os
+    commit = None
+    stamp = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".commit_stamp")     # written before a gpurun call: the GPU box has no .git
+    if os.path.exists(stamp):
+        commit = open(stamp).read().strip()
+    if not commit:
+        try:
+            commit = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+        except OSError:
+            commit = None
     out["_meta"] = {"commit": commit or None, "round": sys.argv[5] if len(sys.argv) > 5 else None,
                     "note": "per launch, averaged over every launch of the kernel in `bench.py --steps 5 --warmup 3` (single-stream schedule)"}
     dst = sys.argv[4] if len(sys.argv) > 4 else "profiles/pmc.json"

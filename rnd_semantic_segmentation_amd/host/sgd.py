@@ -84,6 +84,8 @@ class FusedSGD(torch.optim.SGD):
                 for p in params:
                     flat = self._momentum_view(p, st)
                 if self.device_hyper is not None:
+                    if not torch.cuda.is_current_stream_capturing():     # an eager step between graph replays: refresh the device copy
+                        self.push_hyper()
                     K.sgd_step_dev(st.data, st.grad, flat, self.device_hyper)
                 else:
                     K.sgd_step(st.data, st.grad, flat, lr, mu, wd)       # one launch for the whole module
