@@ -690,17 +690,231 @@ __global__ __launch_bounds__(512, 1) void wgrad_p3_kernel(WgradP3Params p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// wgrad_q3_kernel: the fused-row idea in the structure that the per-tap kernel has proven - 4 waves, TWO workgroups per CU that
+// cover each other's DMA waits, double-buffered 64-coordinate slabs with a drain + barrier per step - and a tile that keeps the
+// partial planes at 96 KiB per workgroup so that 504 workgroups (two per CU) still cost the same 49.5 MB of slabs:
+// 64 (o) x 128 (i) x the three taps of a kernel row.  Per step a workgroup moves 8 KiB of dy + 17.4 KiB of x window for
+// 3.1 MFLOP: 8.1 L2 bytes per kFLOP (15.6 per tap, 5.2 in wgrad_p3_kernel) and 48 MFMAs per wave and DMA round trip instead of 32,
+// with a third of the steps.  Padded contraction coordinate, scalar span addressing and x-window reads as in wgrad_p3_kernel.
+// dy rows are 128 B (64 channels): DMA pieces of 8 rows, 16-B chunk c of row r at chunk c ^ (((r >> 1) & 3) << 1), which makes
+// the 8 rows x 32 B of a transposed-read half-wave cover all 64 banks.
+constexpr int Q3_TO = 64;
+constexpr int Q3_YROWB = 128;
+constexpr int Q3_DY_BYTES = P3_KS * Q3_YROWB, Q3_STAGE = Q3_DY_BYTES + P3_X_BYTES;      // 8 KiB + 20 KiB
+constexpr int Q3_LDS = 2 * Q3_STAGE;                                                    // 56 KiB: two workgroups per CU
+
+__global__ __launch_bounds__(256, 2) void wgrad_q3_kernel(WgradP3Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wq = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles = p.o_tiles * p.i_tiles;
+    const int logical = mi_xcd_remap(blockIdx.x, tiles * 3 * p.S);
+    const int tile = logical % tiles, rest = logical / tiles;
+    const int ky = rest % 3, split = rest / 3;
+    const int ot = tile / p.i_tiles, it = tile - ot * p.i_tiles;
+    const int o0 = ot * Q3_TO, i0 = it * TI;
+    const long q_begin = (long)split * p.slabs_per_split * P3_KS;
+    long left = (p.Q - q_begin + P3_KS - 1) / P3_KS;
+    const int ns = (int)(left < 0 ? 0 : (left < p.slabs_per_split ? left : p.slabs_per_split));
+    const int Qi = (int)p.Q;
+    const int n0 = P3_KS / p.WP, r0 = P3_KS - n0 * p.WP;
+    const int pix_step = n0 * p.W + r0;
+
+    // ---- dy span: rows 16 wq .. 16 wq + 15 (two pieces of 8 rows x 128 B) ------------------------------------------------------
+    const int yprow = lane >> 3, ypch = lane & 7;
+    const char* yzero = reinterpret_cast<const char*>(g_zero_page_tn) + ypch * 16;
+    const int yspan0 = wq * 16;
+    const int ylch = ypch ^ ((((yspan0 + yprow) >> 1) & 3) << 1);
+    const bool yok = o0 + ylch * 8 < p.O;
+    const unsigned yrow_bytes = (unsigned)p.O * 2u;
+    const unsigned yoff = yprow * yrow_bytes + (o0 + ylch * 8) * 2;
+    const char* dy_b = reinterpret_cast<const char*>(p.dY);
+    int y_q = (int)(q_begin + yspan0), y_wp, y_pix;
+    {
+        const int bh = y_q / p.WP;
+        y_wp = y_q - bh * p.WP;
+        y_pix = bh * p.W + y_wp - p.d;
+    }
+    // ---- x span: window rows 20 wq .. 20 wq + 19 (five pieces of 4 rows x 256 B) ---------------------------------------------------
+    const int xprow = lane >> 4, xpch = lane & 15;
+    const char* xzero = reinterpret_cast<const char*>(g_zero_page_tn) + xpch * 16;
+    const int dh = (ky - 1) * p.d;
+    const int xspan0 = wq * 20;
+    const int xlch_e = xpch ^ (((xspan0 + xprow) & 7) << 1), xlch_o = xpch ^ (((xspan0 + xprow + 4) & 7) << 1);
+    const bool xok_e = i0 + xlch_e * 8 < p.I, xok_o = i0 + xlch_o * 8 < p.I;
+    const unsigned xrow_bytes = (unsigned)p.I * 2u;
+    const unsigned xoff_e = xprow * xrow_bytes + (i0 + xlch_e * 8) * 2, xoff_o = xprow * xrow_bytes + (i0 + xlch_o * 8) * 2;
+    const char* x_b = reinterpret_cast<const char*>(p.X);
+    int x_q = (int)(q_begin + xspan0 - p.d), x_wp, x_h, x_pix;
+    {
+        const long qs = (long)x_q + p.WP;
+        const int bh = (int)(qs / p.WP) - 1;
+        x_wp = (int)(qs % p.WP);
+        x_h = bh < 0 ? p.H - 1 : bh % p.H;
+        x_pix = (bh + dh) * p.W + x_wp - p.d;
+    }
+
+    auto stage = [&](int buf) {
+        char* ydst = smem + buf * Q3_STAGE + wq * 2048;
+        char* xdst = smem + buf * Q3_STAGE + Q3_DY_BYTES + wq * 5120;
+        // dy: real iff the padded column is an image column (the image row always exists for dy)
+        if (y_q + 16 <= Qi && y_wp >= p.d && y_wp + 16 <= p.W + p.d) {
+            const char* P = dy_b + (unsigned long)(unsigned)y_pix * yrow_bytes;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) glds16_tn(yok ? P + (j * 8 * yrow_bytes + yoff) : yzero, ydst + j * 1024);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = j * 8 + yprow;
+                int wp = y_wp + r;
+                const bool c = wp >= p.WP;
+                wp -= c ? p.WP : 0;
+                const int pix = y_pix + r - (c ? 2 * p.d : 0);
+                const bool ok = yok && (unsigned)(y_q + r) < (unsigned)Qi && (unsigned)(wp - p.d) < (unsigned)p.W;
+                glds16_tn(ok ? dy_b + (unsigned long)(unsigned)pix * yrow_bytes + (yoff - yprow * yrow_bytes) : yzero, ydst + j * 1024);
+            }
+        }
+        if (x_q >= 0 && x_q + 20 <= Qi && x_wp >= p.d && x_wp + 20 <= p.W + p.d && (unsigned)(x_h + dh) < (unsigned)p.H) {
+            const char* P = x_b + (unsigned long)(unsigned)x_pix * xrow_bytes;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) glds16_tn(((j & 1) ? xok_o : xok_e) ? P + (j * 4 * xrow_bytes + ((j & 1) ? xoff_o : xoff_e)) : xzero, xdst + j * 1024);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int r = j * 4 + xprow;
+                int wp = x_wp + r;
+                const bool c = wp >= p.WP;
+                wp -= c ? p.WP : 0;
+                int h = x_h + (c ? 1 : 0);
+                h = h >= p.H ? h - p.H : h;
+                const int pix = x_pix + r - (c ? 2 * p.d : 0);
+                const bool ok = ((j & 1) ? xok_o : xok_e) && (unsigned)(x_q + r) < (unsigned)Qi && (unsigned)(wp - p.d) < (unsigned)p.W &&
+                                (unsigned)(h + dh) < (unsigned)p.H;
+                glds16_tn(ok ? x_b + (unsigned long)(unsigned)pix * xrow_bytes + (((j & 1) ? xoff_o : xoff_e) - xprow * xrow_bytes) : xzero, xdst + j * 1024);
+            }
+        }
+        // both spans advance by 64 coordinates (scalar)
+        y_q += P3_KS;
+        y_wp += r0;
+        const int cy = y_wp >= p.WP ? 1 : 0;
+        y_wp -= cy ? p.WP : 0;
+        y_pix += pix_step - (cy ? 2 * p.d : 0);
+        x_q += P3_KS;
+        x_wp += r0;
+        const int cx = x_wp >= p.WP ? 1 : 0;
+        x_wp -= cx ? p.WP : 0;
+        x_h += n0 + cx;
+        x_h = x_h >= p.H ? x_h - p.H : x_h;
+        x_pix += pix_step - (cx ? 2 * p.d : 0);
+    };
+
+    // ---- compute: wave owns i in [32 wq, +32) x all 64 o x three taps -----------------------------------------------------------
+    f32x4 acc[3][2][4];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[kx][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int g = lane >> 4, q4 = (lane & 15) >> 2, pc = lane & 3;
+    const int rk0 = g * 4 + q4;
+    const unsigned y_off = rk0 * Q3_YROWB + (pc >> 1) * 16 + (pc & 1) * 8;
+    const int y_sw = (rk0 >> 1) & 3;
+    unsigned x_off[3];
+    int x_sw[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int rk = rk0 + kx * p.d;
+        x_off[kx] = Q3_DY_BYTES + rk * ROWB + (pc & 1) * 8;
+        x_sw[kx] = (rk & 7) << 1;
+    }
+    const unsigned lds0 = lds_address(smem);
+    auto compute = [&](int buf) {
+        unsigned sb = lds0 + buf * Q3_STAGE;
+        asm volatile("" : "+v"(sb));
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            union { bf16x8 v; s16x4 h[2]; } yf[4], xf[3][2];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const unsigned base = sb + y_off + ((b ^ y_sw) << 5);
+                if (ks == 0) {
+                    yf[b].h[0] = tr_read_lds<0>(base);
+                    yf[b].h[1] = tr_read_lds<16 * Q3_YROWB>(base);
+                } else {
+                    yf[b].h[0] = tr_read_lds<32 * Q3_YROWB>(base);
+                    yf[b].h[1] = tr_read_lds<48 * Q3_YROWB>(base);
+                }
+            }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const unsigned base = sb + x_off[kx] + ((((wq * 2 + a) * 2 + (pc >> 1)) ^ x_sw[kx]) << 4);
+                    if (ks == 0) {
+                        xf[kx][a].h[0] = tr_read_lds<0>(base);
+                        xf[kx][a].h[1] = tr_read_lds<16 * ROWB>(base);
+                    } else {
+                        xf[kx][a].h[0] = tr_read_lds<32 * ROWB>(base);
+                        xf[kx][a].h[1] = tr_read_lds<48 * ROWB>(base);
+                    }
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        acc[kx][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kx][a].v, yf[b].v, acc[kx][a][b], 0, 0, 0);
+        }
+    };
+
+    if (ns > 0) {
+        stage(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int s = 0; s < ns; ++s) {
+            const int cur = s & 1;
+            if (s + 1 < ns) stage(cur ^ 1);
+            compute(cur);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+
+    const int fcol = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        float* plane = p.slab + ((long)(split * 9 + ky * 3 + kx) * p.O) * p.I;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int o = o0 + b * 16 + fcol;
+            if (o >= p.O) continue;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int i = i0 + wq * 32 + a * 16 + fq * 4;
+                if (i >= p.I) continue;
+                *reinterpret_cast<f32x4*>(plane + (long)o * p.I + i) = acc[kx][a][b];
+            }
+        }
+    }
+}
+
 // Split / grid of the fused 3x3 kernel; returns false when the shape should stay on the per-tap kernel.
 struct P3Plan { int S, slabs_per_split; long Q; int WP, o_tiles, i_tiles; };
-bool p3_plan(int B, int H, int W, int O, int I, int dil, bool force, P3Plan& pl) {
+// q3: the 4-wave / two-per-CU kernel (64-channel o tiles, 512 workgroup slots) instead of the 8-wave ping-pong kernel (128, 256)
+bool p3_plan(int B, int H, int W, int O, int I, int dil, bool force, P3Plan& pl, bool q3 = false) {
     if (dil < 1 || dil > 8) return false;
     pl.WP = W + 2 * dil;
     pl.Q = (long)B * H * pl.WP;
-    pl.o_tiles = (O + TO - 1) / TO;
+    pl.o_tiles = q3 ? (O + Q3_TO - 1) / Q3_TO : (O + TO - 1) / TO;
     pl.i_tiles = (I + TI - 1) / TI;
     const long ns = (pl.Q + P3_KS - 1) / P3_KS;
     const int groups = pl.o_tiles * pl.i_tiles * 3;
-    long S = 256 / groups;
+    long S = (q3 ? 512 : 256) / groups;
     if (S < 1) S = 1;
     if (S > ns) S = ns;
     pl.slabs_per_split = (int)((ns + S - 1) / S);
@@ -710,6 +924,7 @@ bool p3_plan(int B, int H, int W, int O, int I, int dil, bool force, P3Plan& pl)
     if (force) return true;
     // worth it when the tiles are mostly real channels and every workgroup has a real loop behind its prologue and its
     // 192-KiB partial planes
+    if (q3) return (long)O * I >= 256L * 256 && pl.slabs_per_split >= 8;       // smaller convs: the partial planes would outweigh the operands
     return O >= 96 && I >= 96 && pl.slabs_per_split >= 8;
 }
 
@@ -749,15 +964,16 @@ extern "C" size_t mi_conv_wgrad_workspace(int B, int Ho, int Wo, int O, int I, i
     if (ksize == 3) {          // the fused-row kernel may be chosen for any dilation <= 8: budget for its largest split count
         P3Plan pl;
         for (int d = 1; d <= 8; d *= 2)
-            if (p3_plan(B, Ho, Wo, O, I, d, true, pl)) {
-                const size_t n3 = (size_t)pl.S * 9 * O * I * sizeof(float);
-                if (n3 > need) need = n3;
-            }
+            for (int q3 = 0; q3 < 2; ++q3)
+                if (p3_plan(B, Ho, Wo, O, I, d, true, pl, q3 != 0)) {
+                    const size_t n3 = (size_t)pl.S * 9 * O * I * sizeof(float);
+                    if (n3 > need) need = n3;
+                }
     }
     return need;
 }
 
-static int launch_p3(const void* dy, const void* x, float* ws, int H, int W, int O, int I, int dil, const P3Plan& pl, int BH, hipStream_t st) {
+static int launch_p3(const void* dy, const void* x, float* ws, int H, int W, int O, int I, int dil, const P3Plan& pl, int BH, hipStream_t st, bool q3 = false) {
     WgradP3Params q;
     q.dY = (const __bf16*)dy;
     q.X = (const __bf16*)x;
@@ -776,6 +992,12 @@ static int launch_p3(const void* dy, const void* x, float* ws, int H, int W, int
     q.i_tiles = pl.i_tiles;
     const char* dbg = getenv("MI_P3_DBG");
     q.dbg = dbg ? atoi(dbg) : 0;
+    if (q3) {
+        static std::atomic<uint64_t> attrq{0};
+        mi_allow_dynamic_lds((const void*)wgrad_q3_kernel, Q3_LDS, attrq);
+        hipLaunchKernelGGL(wgrad_q3_kernel, dim3((unsigned)(pl.o_tiles * pl.i_tiles * 3 * pl.S)), dim3(256), Q3_LDS, st, q);
+        return 0;
+    }
     static std::atomic<uint64_t> attr{0};
     mi_allow_dynamic_lds((const void*)wgrad_p3_kernel, P3_LDS, attr);
     hipLaunchKernelGGL(wgrad_p3_kernel, dim3((unsigned)(pl.o_tiles * pl.i_tiles * 3 * pl.S)), dim3(512), P3_LDS, st, q);
@@ -814,6 +1036,23 @@ extern "C" int mi_conv_wgrad(const void* dy, const void* x, float* dw, int B, in
     if (p3_mode < 0) {
         const char* e = getenv("MI_WGRAD_P3");
         p3_mode = e ? atoi(e) : 0;
+    }
+    // the 4-wave fused-row kernel: MI_WGRAD_Q3 0 = never, 1 = by the plan's rule (default), 2 = whenever the geometry allows (tests)
+    static int q3_mode = -1;
+    if (q3_mode < 0) {
+        const char* e = getenv("MI_WGRAD_Q3");
+        q3_mode = e ? atoi(e) : 1;
+    }
+    if (q3_mode && !p3_mode && out_map == 0 && ksize == 3 && stride == 1 && Ha == Ho && Wa == Wo && pad == dil) {
+        P3Plan pl;
+        if (p3_plan(B, Ho, Wo, O, I, dil, q3_mode == 2, pl, true) && (size_t)pl.S * 9 * O * I * sizeof(float) <= workspace_bytes) {
+            launch_p3(dy, x, (float*)workspace, Ho, Wo, O, I, dil, pl, B * Ho, (hipStream_t)stream, true);
+            MI_CHECK_LAUNCH("mi_conv_wgrad (fused 3x3 rows, 4 waves)");
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((I + 63) / 64), (unsigned)O), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dw,
+                               scale_o, pl.S, 9, O, I, accumulate, 0, 1);
+            MI_CHECK_LAUNCH("mi_conv_wgrad reduce");
+            return MI_OK;
+        }
     }
     if (p3_mode && out_map == 0 && ksize == 3 && stride == 1 && Ha == Ho && Wa == Wo && pad == dil) {
         P3Plan pl;
