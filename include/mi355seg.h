@@ -103,6 +103,9 @@ int mi_conv_gemm_pp(const void* a, const void* wp, void* out,
  * dw[br][cls][i][tap] of the 4 stacked [ncls][I][3][3] tensors.  dw_elems = number of floats dw points at; the call
  * fails with MI_EINVAL instead of writing past it. */
 size_t mi_conv_wgrad_workspace(int B, int Ho, int Wo, int O, int I, int ksize);
+/* which kernel mi_conv_wgrad launches for a shape (measurement tools): 0 wgrad_tn_kernel (128 x 128 tile per tap), 1 wgrad_tn256_kernel
+ * (opt-in), 2 wgrad_p3_kernel (opt-in), 3 wgrad_q3_kernel (3x3 stride 1: the three taps of a kernel row fused, 64 x 128 tile) */
+int mi_conv_wgrad_route(int B, int Ha, int Wa, int I, int Ho, int Wo, int O, int ksize, int stride, int pad, int dil, int out_map);
 int mi_conv_wgrad(const void* dy, const void* x, float* dw,
                   int B, int Ha, int Wa, int I, int Ho, int Wo, int O,
                   int ksize, int stride, int pad, int dil,

@@ -26,6 +26,7 @@ SIGNATURES = {
     "mi_conv_gemm_route": (I, [I] * 10),
     "mi_conv_gemm_pp": (I, [P, P, P] + [I] * 12 + [P, P, P, P, P, I, I, F, I, P]),
     "mi_conv_wgrad_workspace": (Z, [I] * 6),
+    "mi_conv_wgrad_route": (I, [I] * 12),
     "mi_conv_wgrad": (I, [P, P, P] + [I] * 11 + [P, I, I, I, Z, P, Z, P]),
     "mi_aspp_pack_fwd": (I, [P, P, I, I, P]),
     "mi_aspp_pack_dgrad": (I, [P, P, I, I, P]),

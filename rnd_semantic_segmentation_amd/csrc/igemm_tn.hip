@@ -1004,6 +1004,19 @@ static int launch_p3(const void* dy, const void* x, float* ws, int H, int W, int
     return 0;
 }
 
+// which kernel mi_conv_wgrad launches for a shape: 0 wgrad_tn_kernel (128 x 128 per tap), 1 wgrad_tn256_kernel, 2 wgrad_p3_kernel,
+// 3 wgrad_q3_kernel (measurement tools; same rules as the dispatch below)
+extern "C" int mi_conv_wgrad_route(int B, int Ha, int Wa, int I, int Ho, int Wo, int O, int ksize, int stride, int pad, int dil, int out_map) {
+    const char* e3 = getenv("MI_WGRAD_P3");
+    const char* eq = getenv("MI_WGRAD_Q3");
+    const int p3_mode = e3 ? atoi(e3) : 0, q3_mode = eq ? atoi(eq) : 1;
+    const bool fused_ok = out_map == 0 && ksize == 3 && stride == 1 && Ha == Ho && Wa == Wo && pad == dil;
+    P3Plan pl;
+    if (fused_ok && q3_mode && !p3_mode && p3_plan(B, Ho, Wo, O, I, dil, q3_mode == 2, pl, true)) return 3;
+    if (fused_ok && p3_mode && p3_plan(B, Ho, Wo, O, I, dil, p3_mode == 2, pl)) return 2;
+    return use_tn256(I, stride, Ha, Ho, Wa, Wo) ? 1 : 0;
+}
+
 extern "C" int mi_conv_wgrad(const void* dy, const void* x, float* dw, int B, int Ha, int Wa, int I, int Ho, int Wo, int O,
                              int ksize, int stride, int pad, int dil, const float* scale_o, int accumulate, int out_map, int ncls,
                              size_t dw_elems, void* workspace, size_t workspace_bytes, void* stream) {

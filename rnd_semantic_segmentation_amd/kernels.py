@@ -176,7 +176,11 @@ def conv_wgrad(dy, x, dw, ksize=1, stride=1, pad=0, dil=1, scale=None, accumulat
         raise _lib.MiError("conv_wgrad(out_map=1) needs ncls with 36*ncls <= %d, got %r" % (O, ncls))
     o_real = 36 * ncls if out_map == 1 else O
     flops = 2.0 * B * Ho * Wo * o_real * I * ksize * ksize
-    check(_timed("wgrad_tn_kernel+reduce", flops, lambda: L.mi_conv_wgrad(
+    kern = "wgrad_tn_kernel+reduce"
+    if PROFILE is not None:
+        kern = ("wgrad_tn_kernel", "wgrad_tn256_kernel", "wgrad_p3_kernel", "wgrad_q3_kernel")[
+            L.mi_conv_wgrad_route(B, Ha, Wa, I, Ho, Wo, O, ksize, stride, pad, dil, out_map)] + "+reduce"
+    check(_timed(kern, flops, lambda: L.mi_conv_wgrad(
         _p(dy), _p(x), _p(dw), B, Ha, Wa, I, Ho, Wo, O, ksize, stride, pad, dil, _p(scale),
         int(accumulate), out_map, int(ncls), dw.numel(), _p(ws), ws.numel(), _stream()), tag=("wgrad", ksize, I, O, B * Ho * Wo, out_map, dil)), "mi_conv_wgrad")
     return dw
