@@ -317,6 +317,7 @@ class AsppFada:
     # -- one iteration, aspp_fada.py:66-127 ------------------------------------------------------------------------------------
     def train_step(self, src_input, src_label, tgt_input, max_iter):
         a, f = self.aspp, self.fada
+        a._throttle()                 # at most two iterations in flight (host/trainer.py RUN_AHEAD)
         self.iteration += 1
         lr = adjust_learning_rate(self.cfg.SOLVER.LR_METHOD, self.cfg.SOLVER.BASE_LR, self.iteration, max_iter, power=self.cfg.SOLVER.LR_POWER)
         lr_d = adjust_learning_rate(self.cfg.SOLVER.LR_METHOD, self.cfg.SOLVER.BASE_LR_D, self.iteration, max_iter, power=self.cfg.SOLVER.LR_POWER)
