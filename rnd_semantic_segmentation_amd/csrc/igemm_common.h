@@ -22,6 +22,7 @@ struct IgemmParams {
     int flags, zgw;
     float alpha;                  // LeakyReLU negative slope (MI_EPI_LEAKY)
     int m_tiles, n_tiles;
+    int korder;                   // igemm_pp_kernel: 0 = contraction runs tap-major (tap, then channels), 1 = channel-chunk-major (all taps of a chunk)
 };
 
 __device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {

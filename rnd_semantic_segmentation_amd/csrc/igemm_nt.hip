@@ -387,6 +387,7 @@ extern "C" int mi_conv_gemm(const void* a, const void* wp, void* out, int B, int
         return mi_conv_gemm_pp(a, wp, out, B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, pad, dil, gather_mode, scale, bias, res, msk, mask_out, flags, zgw,
                                alpha, 0, stream);
     IgemmParams p;
+    p.korder = 0;
     p.A = (const __bf16*)a;
     p.Wp = (const __bf16*)wp;
     p.out = out;

@@ -25,6 +25,7 @@
 // c of row r sits at chunk c ^ s(r), applied to the per-lane SOURCE address and to the ds_read_b128 address, with
 // s_A(r) = (-(r >> 2)) & 3 and s_W(r) = ((r >> 3) & 1) << 1: both make every ds_read_b128 lane group hit 64 distinct banks
 // (brute-forced over the instruction's four 16-lane groups; W rows are read in the permuted order of igemm_nt.hip).
+#include <type_traits>
 #include "igemm_common.h"
 #include <stdlib.h>
 
@@ -39,6 +40,20 @@ template <int MTG> struct PPGeo {
     static constexpr int NPW = 4;                                     // W pieces per wave of group 1 (16 pieces per slab)
     static_assert(PA % 4 == 0, "the A pieces must split evenly over the four waves of group 0");
 };
+
+#ifdef MI_PP_TRACE
+// Timeline experiment (tools/pptrace.py builds a second library with -DMI_PP_TRACE; never defined in the product build): wave 0 of each
+// group of ONE workgroup stamps s_memtime at six points of every k-step into spare LDS, dumped to this buffer at the end.
+constexpr int PP_TRACE_STEPS = 80, PP_TRACE_PTS = 6;
+__device__ unsigned g_pp_trace[2 * PP_TRACE_STEPS * PP_TRACE_PTS];
+#define PP_T(k)                                                                                                        \
+    if (tr_on && s < PP_TRACE_STEPS) {                                                                                 \
+        const unsigned t_ = (unsigned)__builtin_readcyclecounter();                                                    \
+        if (lane == 0) tr[s * PP_TRACE_PTS + (k)] = t_;                                                                \
+    }
+#else
+#define PP_T(k)
+#endif
 
 template <int MTG, int EPI>
 __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmParams p) {
@@ -97,10 +112,13 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmParams p) {
             const int n = n0 + rl;
             const int chunk = (pch ^ (((rl >> 3) & 1) << 1)) * 16;
             d_base[i] = reinterpret_cast<const char*>(p.Wp + (long)(n < p.N ? n : 0) * p.Ca) + chunk;
-            d_mask[i] = n < p.N ? 0x1ffu : 0u;
+            d_mask[i] = 0x1ffu;                  // rows past N re-read row 0: their accumulator columns are never stored
         }
+#pragma unroll
+        for (int i = NPW; i < (NPA > NPW ? NPA : NPW); ++i) d_base[i] = zero, d_mask[i] = 0u;      // pieces only group 0 has
     }
     const int spt = p.Ca >> 5;                          // slabs per tap
+    const bool tap_inner = (p.korder & 1) != 0;
     const int ns = p.T * spt;
     const long w_tap_bytes = (long)p.N * p.Ca * 2;
     int ld_s = 0, ld_t = 0, ld_c = 0;                   // next slab to stage: index, tap, 32-channel chunk within the tap
@@ -108,10 +126,27 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmParams p) {
 
     auto tap_offset = [&](int t) -> long {
         if (grp != 0) return (long)t * w_tap_bytes;
-        const int ky = t / p.ksz, kx = t - ky * p.ksz;
+        const int ky = p.ksz == 3 ? (t * 11) >> 5 : 0, kx = t - ky * p.ksz;          // t / 3 for t < 9
         return (long)sgn * ((long)ky * p.dil * p.Wa + (long)kx * p.dil) * p.Ca * 2;
     };
-    auto stage_next = [&]() {
+    auto advance_slab = [&]() {
+        ++ld_s;
+        if (tap_inner) {
+            // all taps of one 32-channel chunk back to back: the nine shifted reads of the same input rows follow each other
+            // within microseconds and hit L2 (a workgroup's rows + halo are ~90 KB per chunk; TCC hit rate 71 % -> 91 %, fabric
+            // fetches 6x lower at 3x3 256); tap-major order sweeps the whole 38-77 MB tensor between two reads of a row
+            if (++ld_t == p.T) {
+                ld_t = 0;
+                ++ld_c;
+            }
+            ld_toff = tap_offset(ld_t);
+        } else if (++ld_c == spt) {
+            ld_c = 0;
+            ++ld_t;
+            ld_toff = tap_offset(ld_t);
+        }
+    };
+    auto stage_next = [&]() {                           // prologue: a whole slab's pieces back to back
         char* dst = smem + (ld_s & 3) * SLAB + (grp == 0 ? wq * (NPA * 1024) : SLAB_A + wq * (NPW * 1024));
         const long off = ld_toff + (long)ld_c * 64;
         if (grp == 0) {
@@ -119,14 +154,9 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmParams p) {
             for (int i = 0; i < NPA; ++i) glds16(((d_mask[i] >> ld_t) & 1u) ? d_base[i] + off : zero, dst + i * 1024);
         } else {
 #pragma unroll
-            for (int i = 0; i < NPW; ++i) glds16(d_mask[i] ? d_base[i] + off : zero, dst + i * 1024);
+            for (int i = 0; i < NPW; ++i) glds16(d_base[i] + off, dst + i * 1024);
         }
-        ++ld_s;
-        if (++ld_c == spt) {
-            ld_c = 0;
-            ++ld_t;
-            ld_toff = tap_offset(ld_t);
-        }
+        advance_slab();
     };
 
     // ---- compute roles ---------------------------------------------------------------------------------------------------------
@@ -146,11 +176,40 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < MTG; ++j) af[j] = *reinterpret_cast<const bf16x8*>(base + a_off + j * 1024);
     };
-    auto mfma_all = [&]() {
+    // The MFMA segment also carries this wave's DMA pieces of the slab three ahead, one piece after every second MFMA column:
+    // a global_load_lds holds the issuing wave until the texture path accepts it (~27 cycles per 1 KB wave-instruction per CU at
+    // 64-byte row segments), so the 4-5 pieces issued back to back in the READ segment held it for 600-770 cycles and the read
+    // segments outlasted the MFMA segments (1.2k vs 0.8k cycles, s_memtime timeline of tools/pptrace.py).  Between MFMAs the
+    // same waits fall into the matrix pipe's shadow.  Past the last slab the pieces re-read slab 0 into the slot that slab
+    // s-1 has left (nobody reads it again): the vmcnt arithmetic stays the same in every step.
+    constexpr int NPMIN = NPA < NPW ? NPA : NPW, NPMAX = NPA > NPW ? NPA : NPW;
+    const char* src[NPMAX];                                           // this wave's piece sources of the slab three ahead
+    auto piece_sources = [&]() {                                      // read segment: VALU work under the fragment reads' latency
+        const bool live = ld_s < ns;                                  // scalar selects only
+        const long off = live ? ld_toff + (long)ld_c * 64 : 0;
+        const unsigned tap_bit = live ? 1u << ld_t : 1u;
 #pragma unroll
-        for (int j = 0; j < MTG; ++j)
+        for (int i = 0; i < NPMAX; ++i) {
+            src[i] = (d_mask[i] & tap_bit) ? d_base[i] + off : zero;
+            asm volatile("" : "+v"(src[i]));                          // materialise here: left alone, hipcc sinks the selects between the MFMAs
+        }
+    };
+    auto mfma_and_stage = [&]() {
+        char* dst = smem + (ld_s & 3) * SLAB + (grp == 0 ? wq * (NPA * 1024) : SLAB_A + wq * (NPW * 1024));
+#pragma unroll
+        for (int j = 0; j < MTG; ++j) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+            if ((j & 1) == 0 && (j >> 1) < NPMAX) {
+                const int i = j >> 1;
+                __builtin_amdgcn_sched_barrier(0);
+                // one instruction stream for both groups (W rows carry an all-ones mask); only the pieces one group has more of
+                // than the other sit behind a (wave-uniform) branch
+                if (i < NPMIN || (NPA > NPW ? grp == 0 : grp == 1)) glds16(src[i], dst + i * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        advance_slab();
     };
 
     // ---- prologue: three slabs in flight, slab 0 landed -------------------------------------------------------------------------
@@ -166,27 +225,37 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmParams p) {
     __builtin_amdgcn_s_barrier();                                   // B_0
     if (grp == 1) __builtin_amdgcn_s_barrier();                     // group 1 runs one interval behind (B_1)
 
+#ifdef MI_PP_TRACE
+    unsigned* tr = reinterpret_cast<unsigned*>(smem + 4 * SLAB) + grp * PP_TRACE_STEPS * PP_TRACE_PTS;
+    const bool tr_on = blockIdx.x == p.korder >> 8 && wq == 0;
+#endif
     for (int s = 0; s < ns; ++s) {
         // ---- read segment (G0: I_2s, G1: I_2s+1) ----
-        if (s + 3 < ns) stage_next();                               // slab s+3 -> the slot slab s-1 has left
+        PP_T(0)
+        PP_T(1)
         read_frags(s);
+        piece_sources();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if (grp == 1) {                                             // end of an odd interval: my pieces of slab s+1 must have landed
-            if (s + 3 < ns) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        PP_T(2)
+        // end of an odd interval: group 1's pieces of slab s+1 must have landed (only slab s+2 may still be in flight: it stages
+        // slab s+3 in the MFMA segment below)
+        if (grp == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
         __builtin_amdgcn_s_barrier();
+        PP_T(3)
         // ---- MFMA segment (G0: I_2s+1, G1: I_2s+2) ----
         __builtin_amdgcn_s_setprio(1);
-        mfma_all();
+        mfma_and_stage();                                           // + slab s+3 -> the slot slab s-1 has left
         __builtin_amdgcn_s_setprio(0);
-        if (grp == 0) {
-            if (s + 3 < ns) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPA) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        PP_T(4)
+        if (grp == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPA) : "memory");     // slab s+1 landed (s+2, s+3 in flight)
         __builtin_amdgcn_s_barrier();
+        PP_T(5)
     }
+#ifdef MI_PP_TRACE
+    if (tr_on && lane == 0)
+        for (int i = 0; i < PP_TRACE_STEPS * PP_TRACE_PTS; ++i) g_pp_trace[grp * PP_TRACE_STEPS * PP_TRACE_PTS + i] = tr[i];
+#endif
     if (grp == 0) __builtin_amdgcn_s_barrier();                     // group 0 leaves one interval early: keep the barrier counts equal
 
     if (EPI < 0 && (p.flags & (1 << 30))) {   // perf experiment: main loop only (keeps the accumulators alive, stores nothing)
@@ -426,7 +495,11 @@ template <int MTG, int EPI>
 void launch_pp(dim3 grid, hipStream_t stream, const IgemmParams& p) {
     static std::atomic<uint64_t> attr_done{0};
     auto kern = igemm_pp_kernel<MTG, EPI>;
+#ifdef MI_PP_TRACE
+    constexpr int lds = PPGeo<MTG>::LDS_BYTES + 2 * PP_TRACE_STEPS * PP_TRACE_PTS * 4;
+#else
     constexpr int lds = PPGeo<MTG>::LDS_BYTES;
+#endif
     mi_allow_dynamic_lds((const void*)kern, lds, attr_done);
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p);
 }
@@ -442,6 +515,12 @@ void launch_pp_flags(dim3 grid, hipStream_t stream, const IgemmParams& p) {
 }
 
 }  // namespace
+
+#ifdef MI_PP_TRACE
+extern "C" int mi_pp_trace_read(unsigned* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pp_trace), sizeof(unsigned) * n);
+}
+#endif
 
 // Same contract as mi_conv_gemm, restricted to stride 1 / Ha == Ho / Ca % 32 == 0.  mi_conv_gemm dispatches here by its cost
 // model; exported so that the two main loops can be compared in one process (tools/kexp.py).  mtg = 0: choose the tile height.
@@ -490,6 +569,15 @@ extern "C" int mi_conv_gemm_pp(const void* a, const void* wp, void* out, int B, 
     p.flags = flags;
     p.zgw = zgw > 0 ? zgw : 4;
     p.alpha = alpha;
+    static int korder = -1;              // MI_IGEMM_PP_KORDER=0: tap-major contraction (the order of igemm_nt_kernel; bit-equal to it)
+    if (korder < 0) {
+        const char* e = getenv("MI_IGEMM_PP_KORDER");
+        korder = e ? atoi(e) : 1;
+    }
+    p.korder = ksize > 1 ? korder : 0;
+#ifdef MI_PP_TRACE
+    if (const char* e = getenv("MI_PP_TRACE_WG")) p.korder |= atoi(e) << 8;
+#endif
     // 3x3 with the hot epilogues: the shared-window kernel (mtg == 0 only: an explicit 8 / 10 selects igemm_pp_kernel).
     // MI_IGEMM_PW: 0 = off (default: measured 90 vs 85 us at 3x3 256, 311 vs 290 at 3x3 512 - see DESIGN.md section 8), 1 = by rule,
     // 2 = always when the geometry allows (tests on tiny shapes)

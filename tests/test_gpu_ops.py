@@ -8,6 +8,8 @@ Tolerances (written where used):
   * bf16 outputs: one bf16 ulp of the largest magnitude (2^-8 relative).
   * integer results (argmax, histograms): bit exact.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -166,10 +168,21 @@ def test_pointwise_wide_conv_all_hot_epilogues_vs_torch(ci, co, B, H, W):
 @pytest.mark.parametrize("mtg", [8, 10, 3])
 def test_wide_tile_ping_pong_main_loop_vs_oracle_and_128_wide_kernel(B, H, W, ci, co, k, d, mtg):
     """csrc/igemm_pp.hip called directly on small / ragged shapes (M and N tails inside one 320 x 256 tile, a single slab, taps
-    that fall into the padding): forward and data-gradient gathers with the epilogues the network launches.  Both main loops add
-    the products of one output element in the same order (tap-major, channels ascending, 32 per MFMA), so their results must be
-    BIT-equal; the oracle pins the value."""
+    that fall into the padding): forward and data-gradient gathers with the epilogues the network launches.  The oracle pins the
+    value.  For 1x1 convs, and for 3x3 under MI_IGEMM_PP_KORDER=0 (tap-major contraction; tests/test_gpu_scripts.py runs this test
+    that way too), both main loops add the products of one output element in the same order (channels ascending, 32 per MFMA), so
+    their results must be BIT-equal; the default 3x3 order (all taps of a 32-channel chunk, then the next chunk) differs from the
+    128-wide kernel's in fp32 rounding only: within one bf16 ulp of the largest magnitude."""
     pad = d if k == 3 else 0
+    same_order = k == 1 or os.environ.get("MI_IGEMM_PP_KORDER") == "0"
+
+    def same(a, b):
+        if same_order or mtg == 3:
+            return torch.equal(a, b)
+        if a.dtype == torch.int16:           # sign bits: may flip where the value is within rounding of zero - checked through the values
+            return True
+        return relmax(a.float().cpu().numpy(), b.float().cpu().numpy()) < 2.0 ** -8
+
     shared_window = mtg == 3                 # igemm_pw_kernel: 3x3 only, the two hot epilogues only (flags 69 forward, 128 data gradient)
     if shared_window and (k != 3 or W + 2 * d < 16):
         pytest.skip("the shared-window kernel is the 3x3 kernel")
@@ -211,16 +224,16 @@ def test_wide_tile_ping_pong_main_loop_vs_oracle_and_128_wide_kernel(B, H, W, ci
         b0, b1 = (torch.zeros((B, H, W, co // 16), dtype=torch.int16, device=DEV) for _ in range(2))
         y0 = K.conv_gemm(xd, wp, (H, W), k, 1, pad, d, scale=sc, bias=sh, relu=True, mask_out=b0)
         y1 = K.conv_gemm(xd, wp, (H, W), k, 1, pad, d, scale=sc, bias=sh, relu=True, mask_out=b1, wide=mtg)
-        assert torch.equal(y0, y1) and torch.equal(b0, b1)
+        assert same(y0, y1) and same(b0, b1)
         # data gradient with the ReLU mask read from sign bits (flags 128)
         bits = b0[..., : ci // 16].contiguous() if ci % 16 == 0 and ci <= co else None
         if bits is not None:
             g0 = K.conv_gemm(dyd, wpt, (H, W), k, 1, pad, d, K.GATHER_DGRAD, bits=bits)
             g1 = K.conv_gemm(dyd, wpt, (H, W), k, 1, pad, d, K.GATHER_DGRAD, bits=bits, wide=mtg)
-            assert torch.equal(g0, g1)
+            assert same(g0, g1)
     z1 = K.conv_gemm(xd, wp, (H, W), k, 1, pad, d, scale=sc, bias=sh, wide=mtg)
     if base_ok:
-        assert torch.equal(K.conv_gemm(xd, wp, (H, W), k, 1, pad, d, scale=sc, bias=sh), z1)
+        assert same(K.conv_gemm(xd, wp, (H, W), k, 1, pad, d, scale=sc, bias=sh), z1)
     want = ref_ops.conv2d(x, w, None, 1, pad, d) * sc.cpu().numpy().reshape(1, -1, 1, 1) + sh.cpu().numpy().reshape(1, -1, 1, 1)
     assert relmax(to_nchw(z1), want) < 2.0 ** -8                           # bf16 output: one ulp of the largest magnitude
     # data gradient, plain (flags 0): against exact math

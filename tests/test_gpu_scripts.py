@@ -81,6 +81,7 @@ def test_opt_in_kernel_variants_and_single_stream_schedule_stay_correct():
     Environment switches are read once per process, so each runs the relevant parity tests in a child pytest."""
     for env, sel in (({"MI_IGEMM_BN": "256"}, ["tests/test_gpu_ops.py", "-k", "conv_fwd_dgrad or aspp_head_upsample or fused_epilogue or pointwise or identity"]),
                      ({"MI_IGEMM_PP": "0"}, ["tests/test_gpu_ops.py", "-k", "full_size or identity"]),
+                     ({"MI_IGEMM_PP_KORDER": "0"}, ["tests/test_gpu_ops.py", "-k", "identity or wide_tile"]),     # tap-major: bit-equal to the 128-wide kernel
                      ({"MI_IGEMM_PW": "1"}, ["tests/test_gpu_ops.py", "-k", "full_size or identity or wide_tile"]),
                      ({"MI_WGRAD_P3": "2"}, ["tests/test_gpu_ops.py", "-k", "conv_fwd_dgrad or fused_epilogue or tiny_and_ragged or wgrad_full or full_size_vs"]),
                      ({"MI_WGRAD_Q3": "2"}, ["tests/test_gpu_ops.py", "-k", "conv_fwd_dgrad or fused_epilogue or tiny_and_ragged or wgrad_full or full_size_vs"]),
