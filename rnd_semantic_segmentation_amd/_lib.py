@@ -10,7 +10,7 @@ import torch  # noqa: F401  (first: the process must bind torch's bundled HIP ru
 from ctypes import c_char_p, c_float, c_int, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355seg.so")
+LIB_PATH = os.environ.get("MI355SEG_LIB") or os.path.join(_HERE, "libmi355seg.so")      # override: kernel experiments (tools/)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mi355seg.h")
 
 P, I, F, Z = c_void_p, c_int, c_float, c_size_t

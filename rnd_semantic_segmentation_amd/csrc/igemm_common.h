@@ -30,6 +30,12 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Buffer form of the same DMA: per-lane 32-bit byte offset + scalar offset against a buffer resource; a lane whose offset is out
+// of range for the resource (bit 31 set, num_records < 2^31) writes zeros.
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soffset, char* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voffset, soffset, 0, 0);
+}
+
 
 // The epilogue's residual rows and ReLU sign bits (150-300 MB of HBM traffic per launch on the 1024/2048-channel tensors) are
 // fetched as ONE batch of independent loads per lane - before the main loop (they land behind the MFMA work) or right after

@@ -41,11 +41,15 @@ template <int MTG> struct PPGeo {
     static_assert(PA % 4 == 0, "the A pieces must split evenly over the four waves of group 0");
 };
 
+#ifndef PP_DMA_SEG
+#define PP_DMA_SEG 0      // 0: the DMA pieces of the slab three ahead are issued in the read segment, after the fragment reads; 1: between the MFMAs
+#endif
 #ifdef MI_PP_TRACE
 // Timeline experiment (tools/pptrace.py builds a second library with -DMI_PP_TRACE; never defined in the product build): wave 0 of each
 // group of ONE workgroup stamps s_memtime at six points of every k-step into spare LDS, dumped to this buffer at the end.
 constexpr int PP_TRACE_STEPS = 80, PP_TRACE_PTS = 6;
 __device__ unsigned g_pp_trace[2 * PP_TRACE_STEPS * PP_TRACE_PTS];
+__device__ unsigned g_pp_clock[4];
 #define PP_T(k)                                                                                                        \
     if (tr_on && s < PP_TRACE_STEPS) {                                                                                 \
         const unsigned t_ = (unsigned)__builtin_readcyclecounter();                                                    \
@@ -67,14 +71,23 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmParams p) {
     const int tile = mi_xcd_remap(blockIdx.x, nwg);
     const int mt = tile / p.n_tiles, nt = tile - mt * p.n_tiles;
     const int m0 = mt * BM, n0 = nt * BN;
-    const char* zero = reinterpret_cast<const char*>(g_zero_page);
 
     // ---- DMA roles: group 0 moves the A rows (NPA pieces per wave), group 1 the W rows (NPW pieces per wave) ------------------
+    // Buffer addressing: one resource per group (A shifted down by the largest negative tap excursion, or W), a 32-bit byte
+    // offset per piece and lane (tap with the lowest address, channel 0, + swizzled chunk) and the tap / channel-chunk
+    // displacement in the scalar offset.  A chunk that falls into the padding, or a row past M, gets bit 31 of its offset set:
+    // out of range for the resource, which then returns zeros - two VALU instructions per piece and k-step, no 64-bit selects.
     const int prow = lane >> 2, pch = lane & 3;
     const int sgn = (p.mode == MI_GATHER_FWD) ? 1 : -1;
     const bool pointwise = p.T == 1 && p.pad == 0;
-    const char* d_base[NPA > NPW ? NPA : NPW];      // per piece: source of tap (0,0) / tap 0, channel 0 (+ swizzled chunk)
-    unsigned d_mask[NPA > NPW ? NPA : NPW];         // A: 9-bit tap validity; W: row < N
+    constexpr int NPMIN = NPA < NPW ? NPA : NPW, NPMAX = NPA > NPW ? NPA : NPW;
+    const int span = (p.ksz - 1) * p.dil;                              // distance between the first and the last tap of a row / column
+    const int neg = pointwise ? 0 : (sgn > 0 ? p.pad : (span > p.pad ? span - p.pad : 0));     // rows / columns a source may lie before pixel 0
+    const long bias = ((long)neg * p.Wa + neg) * p.Ca * 2;
+    const char* rbase = grp == 0 ? reinterpret_cast<const char*>(p.A) - bias : reinterpret_cast<const char*>(p.Wp);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(rbase), 0, 0x7ffffff0, 0x00020000);
+    unsigned d_off[NPMAX];                           // per piece: byte offset of the lowest-address tap, channel 0 (+ swizzled chunk)
+    unsigned d_inv[NPMAX];                           // A: bit t set = tap t of this row lies in the padding (or the row is past M); W: 0
     if (grp == 0) {
         const int HoWo = p.Ho * p.Wo;
 #pragma unroll
@@ -84,15 +97,16 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmParams p) {
             const bool ok = m < p.M;
             const int chunk = (pch ^ ((-(row >> 2)) & 3)) * 16;
             if (pointwise) {
-                d_base[i] = reinterpret_cast<const char*>(p.A + (long)(ok ? m : 0) * p.Ca) + chunk;
-                d_mask[i] = ok ? 1u : 0u;
+                d_off[i] = (unsigned)((long)(ok ? m : 0) * p.Ca * 2 + chunk);
+                d_inv[i] = ok ? 0u : 0x1ffu;
                 continue;
             }
             const int mm = ok ? m : 0;
             const int b = mm / HoWo, rem = mm - b * HoWo;
             const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
             const int h0 = ho - sgn * p.pad, w0 = wo - sgn * p.pad;          // tap (0,0) source; Ha == Ho, Wa == Wo (stride 1)
-            d_base[i] = reinterpret_cast<const char*>(p.A + ((long)b * p.Ha * p.Wa + (long)h0 * p.Wa + w0) * p.Ca) + chunk;
+            const int hl = sgn > 0 ? h0 : h0 - span, wl = sgn > 0 ? w0 : w0 - span;       // the tap with the lowest address
+            d_off[i] = (unsigned)(bias + (((long)b * p.Ha + hl) * p.Wa + wl) * p.Ca * 2 + chunk);
             unsigned rb = 0, cb = 0;
 #pragma unroll
             for (int kq = 0; kq < 3; ++kq) {
@@ -103,32 +117,36 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmParams p) {
             unsigned msk;
             if (p.ksz == 1) msk = rb & cb & 1u;
             else msk = ((rb & 1u) ? cb : 0u) | ((rb & 2u) ? cb << 3 : 0u) | ((rb & 4u) ? cb << 6 : 0u);
-            d_mask[i] = ok ? msk : 0u;
+            d_inv[i] = ok ? ~msk & 0x1ffu : 0x1ffu;
         }
+#pragma unroll
+        for (int i = NPA; i < NPMAX; ++i) d_off[i] = 0u, d_inv[i] = 0x1ffu;          // pieces only group 1 has
     } else {
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
             const int rl = (wq * NPW + i) * 16 + prow;
             const int n = n0 + rl;
             const int chunk = (pch ^ (((rl >> 3) & 1) << 1)) * 16;
-            d_base[i] = reinterpret_cast<const char*>(p.Wp + (long)(n < p.N ? n : 0) * p.Ca) + chunk;
-            d_mask[i] = 0x1ffu;                  // rows past N re-read row 0: their accumulator columns are never stored
+            d_off[i] = (unsigned)((long)(n < p.N ? n : 0) * p.Ca * 2 + chunk);      // rows past N re-read row 0: their accumulator columns are never stored
+            d_inv[i] = 0u;
         }
 #pragma unroll
-        for (int i = NPW; i < (NPA > NPW ? NPA : NPW); ++i) d_base[i] = zero, d_mask[i] = 0u;      // pieces only group 0 has
+        for (int i = NPW; i < NPMAX; ++i) d_off[i] = 0u, d_inv[i] = 0x1ffu;          // pieces only group 0 has
     }
     const int spt = p.Ca >> 5;                          // slabs per tap
     const bool tap_inner = (p.korder & 1) != 0;
     const int ns = p.T * spt;
-    const long w_tap_bytes = (long)p.N * p.Ca * 2;
+    const unsigned w_tap_bytes = (unsigned)p.N * p.Ca * 2;
     int ld_s = 0, ld_t = 0, ld_c = 0;                   // next slab to stage: index, tap, 32-channel chunk within the tap
-    long ld_toff = 0;                                   // byte offset of the tap (A: spatial shift, W: tap plane)
+    unsigned ld_toff = 0;                               // byte displacement of the tap (A: spatial shift from the lowest tap, W: tap plane)
 
-    auto tap_offset = [&](int t) -> long {
-        if (grp != 0) return (long)t * w_tap_bytes;
+    auto tap_offset = [&](int t) -> unsigned {
+        if (grp != 0) return (unsigned)t * w_tap_bytes;
         const int ky = p.ksz == 3 ? (t * 11) >> 5 : 0, kx = t - ky * p.ksz;          // t / 3 for t < 9
-        return (long)sgn * ((long)ky * p.dil * p.Wa + (long)kx * p.dil) * p.Ca * 2;
+        const int dy = sgn > 0 ? ky : p.ksz - 1 - ky, dx = sgn > 0 ? kx : p.ksz - 1 - kx;    // data gradient: tap (ky, kx) reads out - (k - 1) * dil
+        return (unsigned)((dy * p.dil * p.Wa + dx * p.dil) * p.Ca * 2);
     };
+    ld_toff = tap_offset(0);
     auto advance_slab = [&]() {
         ++ld_s;
         if (tap_inner) {
@@ -146,16 +164,24 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmParams p) {
             ld_toff = tap_offset(ld_t);
         }
     };
+    unsigned src[NPMAX];                                              // this wave's piece offsets of the slab being staged
+    unsigned src_soff = 0;
+    auto piece_sources = [&]() {                                      // read segment: VALU work under the fragment reads' latency
+        const bool live = ld_s < ns;                                  // past the last slab: re-read slab 0 (scalar selects only)
+        src_soff = live ? ld_toff + (unsigned)ld_c * 64u : tap_offset(0);
+        const int tap = live ? ld_t : 0;
+#pragma unroll
+        for (int i = 0; i < NPMAX; ++i) {
+            src[i] = d_off[i] | (((d_inv[i] >> tap) & 1u) << 31);
+            asm volatile("" : "+v"(src[i]));                          // materialise here: left alone, hipcc sinks the work between the MFMAs
+        }
+    };
     auto stage_next = [&]() {                           // prologue: a whole slab's pieces back to back
         char* dst = smem + (ld_s & 3) * SLAB + (grp == 0 ? wq * (NPA * 1024) : SLAB_A + wq * (NPW * 1024));
-        const long off = ld_toff + (long)ld_c * 64;
-        if (grp == 0) {
+        piece_sources();
 #pragma unroll
-            for (int i = 0; i < NPA; ++i) glds16(((d_mask[i] >> ld_t) & 1u) ? d_base[i] + off : zero, dst + i * 1024);
-        } else {
-#pragma unroll
-            for (int i = 0; i < NPW; ++i) glds16(d_base[i] + off, dst + i * 1024);
-        }
+        for (int i = 0; i < NPMAX; ++i)
+            if (i < NPMIN || (NPA > NPW ? grp == 0 : grp == 1)) blds16(rsrc, src[i], src_soff, dst + i * 1024);
         advance_slab();
     };
 
@@ -176,24 +202,17 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < MTG; ++j) af[j] = *reinterpret_cast<const bf16x8*>(base + a_off + j * 1024);
     };
-    // The MFMA segment also carries this wave's DMA pieces of the slab three ahead, one piece after every second MFMA column:
-    // a global_load_lds holds the issuing wave until the texture path accepts it (~27 cycles per 1 KB wave-instruction per CU at
-    // 64-byte row segments), so the 4-5 pieces issued back to back in the READ segment held it for 600-770 cycles and the read
-    // segments outlasted the MFMA segments (1.2k vs 0.8k cycles, s_memtime timeline of tools/pptrace.py).  Between MFMAs the
-    // same waits fall into the matrix pipe's shadow.  Past the last slab the pieces re-read slab 0 into the slot that slab
-    // s-1 has left (nobody reads it again): the vmcnt arithmetic stays the same in every step.
-    constexpr int NPMIN = NPA < NPW ? NPA : NPW, NPMAX = NPA > NPW ? NPA : NPW;
-    const char* src[NPMAX];                                           // this wave's piece sources of the slab three ahead
-    auto piece_sources = [&]() {                                      // read segment: VALU work under the fragment reads' latency
-        const bool live = ld_s < ns;                                  // scalar selects only
-        const long off = live ? ld_toff + (long)ld_c * 64 : 0;
-        const unsigned tap_bit = live ? 1u << ld_t : 1u;
-#pragma unroll
-        for (int i = 0; i < NPMAX; ++i) {
-            src[i] = (d_mask[i] & tap_bit) ? d_base[i] + off : zero;
-            asm volatile("" : "+v"(src[i]));                          // materialise here: left alone, hipcc sinks the selects between the MFMAs
-        }
-    };
+    // Where the DMA pieces of the slab three ahead are issued (PP_DMA_SEG).  s_memtime timeline (tools/pptrace.py), 3x3 256:
+    //   * round-2 first version: pieces at the top of the read segment, each source a 64-bit select against the zero page
+    //     (7 VALU per piece).  The partner wave on the SIMD is in its MFMA segment at s_setprio 1, and the low-priority wave gets
+    //     about one vector issue slot per MFMA: the 35 VALU + 5 DMA took 600-770 cycles, the read segment 1.2k against an MFMA
+    //     segment of 0.8k (period 2.64k cycles per k-step).
+    //   * buffer addressing (2 VALU per piece, below): read segment 0.5k, period 2.1k cycles - but at a LOWER clock: the
+    //     main loop of a workgroup ran at 2.37 GHz before and runs at 1.7-1.9 GHz now (s_memtime / s_memrealtime), so wall time
+    //     improved by 7 %, not by 20 %.  The kernel is power-managed, not issue-bound, from here on.
+    //   * pieces between the MFMAs instead (PP_DMA_SEG 1): each costs the MFMA stream 33-40 cycles; 1-3 % slower in wall time.
+    // Past the last slab the pieces re-read slab 0 into the slot that slab s-1 has left (nobody reads it again): the vmcnt
+    // arithmetic is the same in every step.
     auto mfma_and_stage = [&]() {
         char* dst = smem + (ld_s & 3) * SLAB + (grp == 0 ? wq * (NPA * 1024) : SLAB_A + wq * (NPW * 1024));
 #pragma unroll
@@ -202,11 +221,13 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmParams p) {
             for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
             if ((j & 1) == 0 && (j >> 1) < NPMAX) {
                 const int i = j >> 1;
+#if PP_DMA_SEG
                 __builtin_amdgcn_sched_barrier(0);
                 // one instruction stream for both groups (W rows carry an all-ones mask); only the pieces one group has more of
                 // than the other sit behind a (wave-uniform) branch
-                if (i < NPMIN || (NPA > NPW ? grp == 0 : grp == 1)) glds16(src[i], dst + i * 1024);
+                if (i < NPMIN || (NPA > NPW ? grp == 0 : grp == 1)) blds16(rsrc, src[i], src_soff, dst + i * 1024);
                 __builtin_amdgcn_sched_barrier(0);
+#endif
             }
         }
         advance_slab();
@@ -228,6 +249,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmParams p) {
 #ifdef MI_PP_TRACE
     unsigned* tr = reinterpret_cast<unsigned*>(smem + 4 * SLAB) + grp * PP_TRACE_STEPS * PP_TRACE_PTS;
     const bool tr_on = blockIdx.x == p.korder >> 8 && wq == 0;
+    const unsigned long long tr_c0 = __builtin_readcyclecounter(), tr_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     for (int s = 0; s < ns; ++s) {
         // ---- read segment (G0: I_2s, G1: I_2s+1) ----
@@ -235,12 +257,20 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmParams p) {
         PP_T(1)
         read_frags(s);
         piece_sources();
+#if !PP_DMA_SEG
+        {
+            char* dst = smem + (ld_s & 3) * SLAB + (grp == 0 ? wq * (NPA * 1024) : SLAB_A + wq * (NPW * 1024));
+#pragma unroll
+            for (int i = 0; i < NPMAX; ++i)
+                if (i < NPMIN || (NPA > NPW ? grp == 0 : grp == 1)) blds16(rsrc, src[i], src_soff, dst + i * 1024);
+        }
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         PP_T(2)
         // end of an odd interval: group 1's pieces of slab s+1 must have landed (only slab s+2 may still be in flight: it stages
         // slab s+3 in the MFMA segment below)
-        if (grp == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+        if (grp == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP_DMA_SEG ? NPW : 2 * NPW) : "memory");
         __builtin_amdgcn_s_barrier();
         PP_T(3)
         // ---- MFMA segment (G0: I_2s+1, G1: I_2s+2) ----
@@ -253,8 +283,12 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmParams p) {
         PP_T(5)
     }
 #ifdef MI_PP_TRACE
-    if (tr_on && lane == 0)
+    if (tr_on && lane == 0) {
+        // loop duration in s_memtime ticks and in s_memrealtime ticks (100 MHz): the clock the loop ran at
+        g_pp_clock[grp * 2 + 0] = (unsigned)(__builtin_readcyclecounter() - tr_c0);
+        g_pp_clock[grp * 2 + 1] = (unsigned)(__builtin_amdgcn_s_memrealtime() - tr_r0);
         for (int i = 0; i < PP_TRACE_STEPS * PP_TRACE_PTS; ++i) g_pp_trace[grp * PP_TRACE_STEPS * PP_TRACE_PTS + i] = tr[i];
+    }
 #endif
     if (grp == 0) __builtin_amdgcn_s_barrier();                     // group 0 leaves one interval early: keep the barrier counts equal
 
@@ -520,6 +554,7 @@ void launch_pp_flags(dim3 grid, hipStream_t stream, const IgemmParams& p) {
 extern "C" int mi_pp_trace_read(unsigned* host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pp_trace), sizeof(unsigned) * n);
 }
+extern "C" int mi_pp_clock_read(unsigned* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pp_clock), sizeof(unsigned) * 4); }
 #endif
 
 // Same contract as mi_conv_gemm, restricted to stride 1 / Ha == Ho / Ca % 32 == 0.  mi_conv_gemm dispatches here by its cost
@@ -601,6 +636,11 @@ extern "C" int mi_conv_gemm_pp(const void* a, const void* wp, void* out, int B, 
         return MI_OK;
     }
     if (mtg == 3) return mi_set_error(MI_EINVAL, "mi_conv_gemm_pp: mtg 3 (shared-window kernel) needs a 3x3 conv with pad == dil <= 8 and flags 69 or 128");
+    {   // 32-bit buffer offsets (bit 31 marks a padded chunk): operands and the largest tap excursion must stay below 2 GiB
+        const long a_bytes = (long)B * Ha * Wa * Ca * 2 + 2L * ((long)(ksize - 1) * dil + pad) * (Wa + 1) * Ca * 2;
+        const long w_bytes = (long)ksize * ksize * N * Ca * 2;
+        MI_REQUIRE(a_bytes < (1L << 31) - (1L << 20) && w_bytes < (1L << 31) - (1L << 20), "mi_conv_gemm_pp: operand larger than 2 GiB");
+    }
     if (mtg != 8 && mtg != 10) {           // fewest rounds on 256 CUs, then the least padding
         auto rounds = [&](int bm) { return (((M + bm - 1) / bm) * ((N + 255) / 256) + 255) / 256; };
         mtg = rounds(320) < rounds(256) ? 10 : (rounds(256) < rounds(320) ? 8 : (((M + 319) / 320) * 320 <= ((M + 255) / 256) * 256 ? 10 : 8));

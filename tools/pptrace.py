@@ -11,18 +11,21 @@ SO = os.path.join(ROOT, "tools", "experiments", "libpptrace.so")
 sys.path.insert(0, ROOT)
 
 
-def build():
+def build(extra=()):
+    """extra: more -D flags; the library then gets a suffix (PPTRACE_SO selects it at run time)."""
     import __graft_entry__ as g
     csrc = os.path.join(ROOT, "rnd_semantic_segmentation_amd", "csrc")
+    so = SO if not extra else SO.replace(".so", "_" + "_".join(e.replace("=", "") for e in extra) + ".so")
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-result", "-DMI_PP_TRACE",
-           "-I", os.path.join(ROOT, "include"), "-o", SO] + g.SOURCES + ["-ldl"]
+           "-I", os.path.join(ROOT, "include"), "-o", so] + ["-D" + e for e in extra] + g.SOURCES + ["-ldl"]
     subprocess.run(cmd, check=True, cwd=csrc)
+    print(so)
 
 
 def main():
     import torch
     from rnd_semantic_segmentation_amd import kernels as K
-    L = ctypes.CDLL(SO)
+    L = ctypes.CDLL(os.environ.get("PPTRACE_SO", SO))
     B, H = 8, 97
     ci = co = int(os.environ.get("C", "256"))
     d = 2
@@ -38,9 +41,20 @@ def main():
         rc = L.mi_conv_gemm_pp(P(x), P(wp), P(out), B, H, H, ci, H, H, co, 3, 1, d, d, 0, P(sc), P(sh), None, None, P(bits), 69, 0, ctypes.c_float(0.0), 10, st)
         assert rc == 0
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        L.mi_conv_gemm_pp(P(x), P(wp), P(out), B, H, H, ci, H, H, co, 3, 1, d, d, 0, P(sc), P(sh), None, None, P(bits), 69, 0, ctypes.c_float(0.0), 10, st)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 20 * 1e3
+    print("3x3 %d d2 f69 (stamped build): %.1f us  %.0f TF" % (ci, us, 2.0 * B * H * H * ci * co * 9 / us / 1e6))
     STEPS, PTS = 80, 6
     buf = (ctypes.c_uint * (2 * STEPS * PTS))()
     assert L.mi_pp_trace_read(buf, 2 * STEPS * PTS) == 0
+    clk = (ctypes.c_uint * 4)()
+    assert L.mi_pp_clock_read(clk) == 0
+    print("main loop of the stamped workgroup: %d s_memtime ticks in %.2f us (s_memrealtime, 100 MHz) = %.3f GHz" % (clk[0], clk[1] / 100.0, clk[0] / (clk[1] * 10.0)))
     ns = min(STEPS, 9 * ci // 32)
     names = ["DMA issue", "frag read + lgkm wait", "vm wait(G1) + barrier 1", "MFMA segment", "vm wait(G0) + barrier 2", "(loop back)"]
     for g in range(2):
@@ -59,4 +73,4 @@ def main():
 
 
 if __name__ == "__main__":
-    build() if sys.argv[1:] == ["build"] else main()
+    build(sys.argv[2:]) if sys.argv[1:2] == ["build"] else main()
