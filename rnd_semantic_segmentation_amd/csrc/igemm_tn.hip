@@ -55,6 +55,12 @@ __device__ __forceinline__ void glds16_tn(const char* gsrc, char* lds_wave_base)
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Buffer form: per-lane 32-bit byte offset against a buffer resource; an offset at or past num_records (a row past the end of
+// this K-split, or bit 31 set for a channel chunk past O / I) writes zeros - no per-piece selects or 64-bit pointer updates.
+__device__ __forceinline__ void blds16_tn(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, char* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voffset, 0, 0, 0);
+}
+
 // Staging: tiles go global -> LDS directly (global_load_lds, 1 KiB = 4 pixel rows x 256 B per wave-instruction).
 // The LDS image is lane-linear per DMA; 16-B chunk c of pixel row r sits at physical chunk c ^ ((r & 7) << 1), applied to
 // the per-lane SOURCE address and to the transposed-read address.  With that XOR the 32 lanes of a
@@ -107,10 +113,35 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradParams p) {
     }
     const int step_q = KP / p.Wo, step_r = KP - step_q * p.Wo;
     const long y_step = (long)KP * p.O * 2, x_step = (long)KP * p.I * 2;
+    // MODE 2 (1x1, stride 1, no padding: source pixel = output pixel): one buffer resource per operand that covers exactly this
+    // split's pixel rows, so the rows past m_end read as zeros by range checking; one 32-bit add per piece and K step
+    unsigned vy[4], vx[4];
+    __amdgpu_buffer_rsrc_t rs_y, rs_x;
+    if (MODE == 2) {
+        const long rows = m_end > m_begin ? m_end - m_begin : 0;
+        rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.dY + (long)m_begin * p.O), 0, (int)(rows * p.O * 2), 0x00020000);
+        rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.X + (long)m_begin * p.I), 0, (int)(rows * p.I * 2), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = (wave * 4 + j) * 4 + prow;
+            vy[j] = (unsigned)(((long)row * p.O + o0 + r_lch[j] * 8) * 2) | (y_col[j] ? 0u : 0x80000000u);
+            vx[j] = (unsigned)(((long)row * p.I + i0 + r_lch[j] * 8) * 2) | (x_col[j] ? 0u : 0x80000000u);
+        }
+    }
 
     auto stage = [&](int buf) {
         char* sy = smem + buf * STAGE_BYTES + wave * 4096;
         char* sx = sy + TILE_BYTES;
+        if (MODE == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                blds16_tn(rs_y, vy[j], sy + j * 1024);
+                blds16_tn(rs_x, vx[j], sx + j * 1024);
+                vy[j] += (unsigned)y_step;
+                vx[j] += (unsigned)x_step;
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool row_ok = r_m[j] < m_end;
