@@ -202,15 +202,18 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < MTG; ++j) af[j] = *reinterpret_cast<const bf16x8*>(base + a_off + j * 1024);
     };
-    // Where the DMA pieces of the slab three ahead are issued (PP_DMA_SEG).  s_memtime timeline (tools/pptrace.py), 3x3 256:
+    // Where the DMA pieces of the slab three ahead are issued (PP_DMA_SEG).  s_memtime timeline of one workgroup
+    // (tools/pptrace.py; the stamps cost 13-28 % themselves, so only the proportions count), 3x3 256:
     //   * round-2 first version: pieces at the top of the read segment, each source a 64-bit select against the zero page
     //     (7 VALU per piece).  The partner wave on the SIMD is in its MFMA segment at s_setprio 1, and the low-priority wave gets
-    //     about one vector issue slot per MFMA: the 35 VALU + 5 DMA took 600-770 cycles, the read segment 1.2k against an MFMA
-    //     segment of 0.8k (period 2.64k cycles per k-step).
-    //   * buffer addressing (2 VALU per piece, below): read segment 0.5k, period 2.1k cycles - but at a LOWER clock: the
-    //     main loop of a workgroup ran at 2.37 GHz before and runs at 1.7-1.9 GHz now (s_memtime / s_memrealtime), so wall time
-    //     improved by 7 %, not by 20 %.  The kernel is power-managed, not issue-bound, from here on.
-    //   * pieces between the MFMAs instead (PP_DMA_SEG 1): each costs the MFMA stream 33-40 cycles; 1-3 % slower in wall time.
+    //     about one vector issue slot per MFMA: the 35 VALU + 5 DMA took 600-770 ticks, the read segment 1.2k against an MFMA
+    //     segment of 0.8k (2.64k ticks per k-step).
+    //   * buffer addressing (2 VALU per piece, below), pieces still in the read segment: read segment 0.65k, MFMA segment
+    //     0.9-0.95k, 2.1k ticks per k-step; wall time of the launch 90 -> 83 us (3x3 256), 297 -> 280 us (3x3 512).
+    //   * pieces between the MFMAs instead (PP_DMA_SEG 1): each costs the MFMA stream 33-40 ticks (the in-order wave cannot issue
+    //     its next MFMA until the texture path has taken the instruction); 1-3 % slower in wall time.
+    // The shader clock during the loop is 1.7-1.9 GHz (s_memtime / s_memrealtime; a bare MFMA loop on every CU runs at 2.1-2.4 GHz,
+    // tools/micro/l2lds.hip clock probe): the 2.5 PFLOP/s peak is a 2.4 GHz figure this kernel's power draw does not allow.
     // Past the last slab the pieces re-read slab 0 into the slot that slab s-1 has left (nobody reads it again): the vmcnt
     // arithmetic is the same in every step.
     auto mfma_and_stage = [&]() {

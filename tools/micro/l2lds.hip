@@ -95,6 +95,65 @@ __global__ __launch_bounds__(NT) void l2lds_kernel(const char* src, size_t wg_re
     if (acc == 0x12345679u) sink[blockIdx.x] = acc;
 }
 
+// Clock probe: the shader clock (s_memtime ticks per s_memrealtime 100 MHz tick) while every CU runs back-to-back MFMAs on
+// `waves` waves per SIMD (mfma = 1) or an LDS-DMA stream from L2 (mfma = 0), for `iters` iterations.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(1024) void clock_probe_kernel(const char* src, int mfma, int iters, unsigned* out) {
+    extern __shared__ char lds[];
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    f32x4 acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 a[8], b;
+    {   // operands: pseudo-random bf16 bit patterns in [-2, 2) (eight different A operands: no common subexpressions)
+        unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+        for (int j = 0; j < 8; ++j)
+            for (int i = 0; i < 8; ++i) {
+                h = h * 1664525u + 1013904223u;
+                a[j][i] = (__bf16)(((float)(h >> 8) / 8388608.0f - 1.0f) * 2.0f);
+            }
+        for (int i = 0; i < 8; ++i) {
+            h = h * 1664525u + 1013904223u;
+            b[i] = (__bf16)(((float)(h >> 8) / 8388608.0f - 1.0f) * 0.01f);
+        }
+    }
+    if (mfma == 2) {
+        typedef float f32x16 __attribute__((ext_vector_type(16)));
+        f32x16 c[4];
+        for (int i = 0; i < 4; ++i)
+            for (int k = 0; k < 16; ++k) c[i][k] = 0.f;
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b, c[i], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) acc[i][0] = c[i][0] + c[i][7];
+    } else if (mfma) {
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b, acc[i], 0, 0, 0);
+    } else {
+        const char* base = src + (size_t)blockIdx.x * 65536 + threadIdx.x * 16;
+        for (int it = 0; it < iters; ++it) {
+            glds16(base + (it & 3) * 8192, lds + (it & 3) * 8192 + (threadIdx.x >> 6) * 1024);
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    float sum = 0.f;
+    for (int i = 0; i < 8; ++i) sum += acc[i][0];
+    if (threadIdx.x == 0) {
+        out[blockIdx.x * 2 + 0] = (unsigned)(c1 - c0);
+        out[blockIdx.x * 2 + 1] = (unsigned)(r1 - r0);
+    }
+    if (sum == 1.2345f) out[0] = 0;
+}
+
+extern "C" int run_clock_probe(const void* src, int mfma, int iters, int grid, int threads, void* out, void* stream) {
+    hipFuncSetAttribute((const void*)clock_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(grid), dim3(threads), 65536, (hipStream_t)stream, (const char*)src, mfma, iters, (unsigned*)out);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 extern "C" int run_l2lds(const void* src, size_t src_bytes, int mode, int barrier, int stride, int seg, int blocks, int iters, int grid, void* sink, void* stream) {
     const int lpr = seg / 16;
     if (seg % 16 || stride % seg || NT % lpr || iters % 3) return -1;

@@ -8,6 +8,30 @@ sink = torch.zeros(4096, dtype=torch.int32, device="cuda")
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 ITERS = 3072            # stages of 16 KB per workgroup
 
+# shader clock under load: s_memtime ticks per microsecond of s_memrealtime (100 MHz)
+L.run_clock_probe.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+probe = torch.zeros(1024, dtype=torch.int32, device="cuda")
+for name, mfma, iters, grid, threads in (("MFMA 16x16x32 bf16 back to back, 1 wave / SIMD, every CU", 1, 40000, 256, 256),
+                                         ("MFMA 16x16x32 bf16 back to back, 2 waves / SIMD, every CU", 1, 40000, 256, 512),
+                                         ("MFMA 16x16x32 bf16 back to back, 4 waves / SIMD, every CU", 1, 20000, 256, 1024),
+                                         ("MFMA 32x32x16 bf16 back to back, 1 wave / SIMD, every CU", 2, 40000, 256, 256),
+                                         ("MFMA 32x32x16 bf16 back to back, 2 waves / SIMD, every CU", 2, 40000, 256, 512),
+                                         ("MFMA 16x16x32, 2 waves / SIMD, one CU only", 1, 40000, 1, 512),
+                                         ("LDS-DMA stream from L2, 2 waves / SIMD, every CU", 0, 20000, 256, 512)):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for rep in range(2):
+        e0.record()
+        assert L.run_clock_probe(src.data_ptr(), mfma, iters, grid, threads, probe.data_ptr(), st) == 0
+        e1.record()
+        torch.cuda.synchronize()
+    t = probe[:2].tolist()
+    waves = threads // 64
+    per_iter = 8 if mfma == 1 else 4
+    extra = "  %5.1f ticks per MFMA per SIMD, %.0f TFLOP/s chip by the event time" % (t[0] / (iters * per_iter * waves / 4), 2 * 16 * 16 * 32 * per_iter * (2 if mfma == 2 else 1) * iters * waves * grid / (e0.elapsed_time(e1) * 1e-3) / 1e12) if mfma else ""
+    print("clock probe, %-60s: %9d ticks in %8.2f us (events: %8.2f us) = %.3f GHz%s" % (name, t[0], t[1] / 100.0, e0.elapsed_time(e1) * 1e3, t[0] / (t[1] * 10.0), extra))
+if os.environ.get("CLOCK_ONLY"):
+    raise SystemExit(0)
+
 
 def run(mode, barrier, stride, seg, blocks, grid):
     def go():
