@@ -248,6 +248,118 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradParams p) {
     }
 }
 
+// ---- 1x1 / stride 1 weight gradient as a deeper stream: 32-pixel stages, 4-slot ring, three stages in flight ------------------
+// wgrad_tn_kernel<2> keeps ONE 64-pixel stage in flight per workgroup and drains it (vmcnt(0) + barrier) every step.  Same tile
+// (128 x 128, four waves, two workgroups per CU) and the same LDS image per 32 pixel rows here, but stages of 32 pixels (16 KiB)
+// through a 4-slot ring with three stages in flight (counted vmcnt, one barrier per stage): 96 KiB in flight per CU.
+// Buffer addressing as in wgrad_tn_kernel<2>: the rows past the split end (and the dummy stages past the last step, which
+// keep the vmcnt arithmetic uniform) are out of range for the resource and cost no memory traffic.
+// Measured (B = 8, 97 x 97, 256 <-> 1024): equal with Infinity-Cache-warm operands (50-51 us incl. reducer), 5 % faster with cold
+// ones (94 vs 100 us, `COLD=1 tools/wgexp.py`; a 5-slot ring with four stages in flight: 91 vs 95, no better), the training step
+// +1.5 % (the 70 launches of this class: 6.57 -> 6.27 ms).  The class stays far from the HBM read rate (2.8 TB/s in the step):
+// more bytes in flight are not what it lacks.
+constexpr int KP4 = 32, SLOT4 = 2 * KP4 * ROWB, NSLOT4 = 4, LDS4_BYTES = NSLOT4 * SLOT4;      // 16 KiB x 4 = 64 KiB
+
+__global__ __launch_bounds__(256, 2) void wgrad_s4_kernel(WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles = p.o_tiles * p.i_tiles;
+    const int logical = mi_xcd_remap(blockIdx.x, tiles * p.S);
+    const int tile = logical % tiles, split = logical / tiles;
+    const int ot = tile / p.i_tiles, it = tile - ot * p.i_tiles;
+    const int o0 = ot * TO, i0 = it * TI;
+    const int m_begin = split * p.rows_per_split;
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+    const int nk = (m_end - m_begin + KP4 - 1) / KP4;
+
+    // DMA: a stage is 8 + 8 pieces of 4 pixel rows x 256 B; wave w moves pieces 2w, 2w+1 of both tiles
+    const int prow = lane >> 4, pch = lane & 15;
+    const long rows = m_end > m_begin ? m_end - m_begin : 0;
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.dY + (long)m_begin * p.O), 0, (int)(rows * p.O * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.X + (long)m_begin * p.I), 0, (int)(rows * p.I * 2), 0x00020000);
+    unsigned vy[2], vx[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave * 2 + j) * 4 + prow;
+        const int lch = pch ^ ((row & 7) << 1);                // logical chunk this lane fetches (swizzle of wgrad_tn_kernel)
+        const int oc = o0 + lch * 8, ic = i0 + lch * 8;
+        vy[j] = (unsigned)(((long)row * p.O + oc) * 2) | (oc < p.O ? 0u : 0x80000000u);
+        vx[j] = (unsigned)(((long)row * p.I + ic) * 2) | (ic < p.I ? 0u : 0x80000000u);
+    }
+    const unsigned y_step = (unsigned)KP4 * p.O * 2, x_step = (unsigned)KP4 * p.I * 2;
+    auto stage = [&](int slot) {
+        char* sy = smem + slot * SLOT4 + wave * 2048;
+        char* sx = sy + KP4 * ROWB;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            blds16_tn(rs_y, vy[j], sy + j * 1024);
+            blds16_tn(rs_x, vx[j], sx + j * 1024);
+            vy[j] += y_step;
+            vx[j] += x_step;
+        }
+    };
+
+    const int wi = wave & 1, wo_ = wave >> 1;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int g = lane >> 4, q = (lane & 15) >> 2, pc = lane & 3;
+    const int rsw = (((g & 1) * 4 + q) << 1);
+    const int row_off = (g * 4 + q) * ROWB + (pc & 1) * 8;
+    const unsigned lds0 = lds_address(smem);
+    auto compute = [&](int slot) {
+        const unsigned sy = lds0 + slot * SLOT4 + row_off;
+        const unsigned sx = sy + KP4 * ROWB;
+        union { bf16x8 v; s16x4 h[2]; } xf[4], yf[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const unsigned base = sx + (((wi * 8 + a * 2 + (pc >> 1)) ^ rsw) << 4);
+            xf[a].h[0] = tr_read_lds<0>(base);
+            xf[a].h[1] = tr_read_lds<16 * ROWB>(base);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const unsigned base = sy + (((wo_ * 8 + b * 2 + (pc >> 1)) ^ rsw) << 4);
+            yf[b].h[0] = tr_read_lds<0>(base);
+            yf[b].h[1] = tr_read_lds<16 * ROWB>(base);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[a].v, yf[b].v, acc[a][b], 0, 0, 0);
+    };
+
+    // stages 0..2 in flight; step s: my pieces of stage s landed (8 younger instructions may be pending), barrier (everyone's have,
+    // and everyone is done with stage s-1), stage s+3 into the slot stage s-1 has left, compute stage s
+    stage(0);
+    stage(1);
+    stage(2);
+    for (int s = 0; s < nk; ++s) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        stage((s + 3) & (NSLOT4 - 1));
+        compute(s & (NSLOT4 - 1));
+    }
+    float* slab = p.slab + ((long)split * p.O) * p.I;
+    const int fcol = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int o = o0 + wo_ * 64 + b * 16 + fcol;
+        if (o >= p.O) continue;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int i = i0 + wi * 64 + a * 16 + fq * 4;
+            if (i >= p.I) continue;
+            *reinterpret_cast<f32x4*>(slab + (long)o * p.I + i) = acc[a][b];
+        }
+    }
+}
+
 // ---- 128 (o) x 256 (i) tile, 32 pixels per K step --------------------------------------------------------------------------
 // The 128 x 128 kernel above is bound by the bytes the L2 hands to the LDS (15.6 per kFLOP; the L2 -> LDS path sustains
 // ~43 GB/s per CU).  Widening the tile over the INPUT channels to 256 with a 32-pixel step keeps the MFMA
@@ -992,6 +1104,10 @@ extern "C" size_t mi_conv_wgrad_workspace(int B, int Ho, int Wo, int O, int I, i
         const size_t n2 = (size_t)S2 * T * O * I * sizeof(float);
         if (n2 > need) need = n2;
     }
+    if (ksize == 1) {          // the deep-stream 1x1 kernel: 32-pixel steps on the 128 x 128 tile
+        const size_t n4 = (size_t)pick_splits256(M, tiles) * O * I * sizeof(float);
+        if (n4 > need) need = n4;
+    }
     if (ksize == 3) {          // the fused-row kernel may be chosen for any dilation <= 8: budget for its largest split count
         P3Plan pl;
         for (int d = 1; d <= 8; d *= 2)
@@ -1142,7 +1258,23 @@ extern "C" int mi_conv_wgrad(const void* dy, const void* x, float* dw, int B, in
             hipLaunchKernelGGL(wgrad_tn256_kernel<1>, dim3(nb), dim3(256), LDS2_BYTES, (hipStream_t)stream, p);
         MI_CHECK_LAUNCH("mi_conv_wgrad (128 x 256 tile)");
     }
-    if (!wide) {
+    static int s4_mode = -1;                 // MI_WGRAD_S4=0: the 64-pixel double-buffer kernel for the 1x1 / stride-1 weight gradients too
+    if (s4_mode < 0) {
+        const char* e = getenv("MI_WGRAD_S4");
+        s4_mode = e ? atoi(e) : 1;
+    }
+    const bool deep = !wide && s4_mode && ksize == 1 && pad == 0 && stride == 1 && Ha == Ho && Wa == Wo && (long)M * (O > I ? O : I) * 2 < (1L << 31);
+    if (deep) {
+        p.i_tiles = (I + TI - 1) / TI;
+        p.S = pick_splits256(M, p.o_tiles * p.i_tiles);
+        const long steps4 = (M + KP4 - 1) / KP4;
+        p.rows_per_split = (int)(((steps4 + p.S - 1) / p.S) * KP4);
+        static std::atomic<uint64_t> attr4;
+        mi_allow_dynamic_lds((const void*)wgrad_s4_kernel, LDS4_BYTES, attr4);
+        hipLaunchKernelGGL(wgrad_s4_kernel, dim3((unsigned)(p.o_tiles * p.i_tiles * p.S)), dim3(256), LDS4_BYTES, (hipStream_t)stream, p);
+        MI_CHECK_LAUNCH("mi_conv_wgrad (1x1 deep stream)");
+    }
+    if (!wide && !deep) {
     p.i_tiles = (I + TI - 1) / TI;
     p.S = pick_splits(M, p.o_tiles * p.i_tiles * p.T);
     const long steps = (M + KP - 1) / KP;

@@ -30,6 +30,19 @@ for ci, co, k, d in ((256, 256, 3, 2), (512, 512, 3, 4), (256, 256, 3, 1), (128,
     f = lambda: K.conv_wgrad(dy, x, dw, k, 1, pad, d, scale=sc)
     f()
     t = min(timeit(f, 20) for _ in range(3))
+    # the same launch with cold operands, as in the training step: 1 GiB written between two calls pushes x / dy out of the
+    # 256 MB Infinity Cache; only the weight-gradient launches are timed (events around each call)
+    if os.environ.get("COLD"):
+        junk = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+        tc = []
+        for _ in range(12):
+            junk.add_(1)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); f(); e1.record(); torch.cuda.synchronize()
+            tc.append(e0.elapsed_time(e1) * 1e-3)
+        tcold = sorted(tc)[len(tc) // 2]
+        print("   cold operands: %7.1f us (median of 12)" % (tcold * 1e6))
+        del junk
     err = float("nan")
     if os.environ.get("CHECK"):
         ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).float(), dw.shape, dy.permute(0, 3, 1, 2).float(), padding=pad, dilation=d) * sc.view(-1, 1, 1, 1)
