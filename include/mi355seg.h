@@ -62,7 +62,7 @@ int mi_pack_weight_dgrad(const float* w_oihw, const float* scale_o, void* wp_bf1
 
 /* Every conv weight of a module in one launch.  table (device, int64[n_desc][8]) rows:
  * {w_off, scale_off or -1, wp_off, wpt_off or -1 (skip the dgrad pack), O, I, k*k, first_block}; offsets in elements
- * into wflat / sflat / wp / wpt; a block packs 256 (o,i) pairs, total_blocks = sum ceil(O*I/256). */
+ * into wflat / sflat / wp / wpt; a block packs 32 output x 128 input channels, total_blocks = sum ceil(O/32) * ceil(I/128); k*k <= 9. */
 int mi_pack_weights_multi(const float* wflat, const float* sflat, void* wp_bf16, void* wpt_bf16,
                           const int64_t* table_dev, int n_desc, int total_blocks, void* stream);
 
@@ -104,7 +104,8 @@ int mi_conv_gemm_pp(const void* a, const void* wp, void* out,
  * fails with MI_EINVAL instead of writing past it. */
 size_t mi_conv_wgrad_workspace(int B, int Ho, int Wo, int O, int I, int ksize);
 /* which kernel mi_conv_wgrad launches for a shape (measurement tools): 0 wgrad_tn_kernel (128 x 128 tile per tap), 1 wgrad_tn256_kernel
- * (opt-in), 2 wgrad_p3_kernel (opt-in), 3 wgrad_q3_kernel (3x3 stride 1: the three taps of a kernel row fused, 64 x 128 tile) */
+ * (opt-in), 2 wgrad_p3_kernel (opt-in), 3 wgrad_q3_kernel (3x3 stride 1: the three taps of a kernel row fused, 64 x 128 tile),
+ * 4 wgrad_s4_kernel (1x1 stride 1: 32-pixel stages, three in flight) */
 int mi_conv_wgrad_route(int B, int Ha, int Wa, int I, int Ho, int Wo, int O, int ksize, int stride, int pad, int dil, int out_map);
 int mi_conv_wgrad(const void* dy, const void* x, float* dw,
                   int B, int Ha, int Wa, int I, int Ho, int Wo, int O,

@@ -1152,7 +1152,7 @@ static int launch_p3(const void* dy, const void* x, float* ws, int H, int W, int
 }
 
 // which kernel mi_conv_wgrad launches for a shape: 0 wgrad_tn_kernel (128 x 128 per tap), 1 wgrad_tn256_kernel, 2 wgrad_p3_kernel,
-// 3 wgrad_q3_kernel (measurement tools; same rules as the dispatch below)
+// 3 wgrad_q3_kernel, 4 wgrad_s4_kernel (measurement tools; same rules as the dispatch below)
 extern "C" int mi_conv_wgrad_route(int B, int Ha, int Wa, int I, int Ho, int Wo, int O, int ksize, int stride, int pad, int dil, int out_map) {
     const char* e3 = getenv("MI_WGRAD_P3");
     const char* eq = getenv("MI_WGRAD_Q3");
@@ -1161,7 +1161,11 @@ extern "C" int mi_conv_wgrad_route(int B, int Ha, int Wa, int I, int Ho, int Wo,
     P3Plan pl;
     if (fused_ok && q3_mode && !p3_mode && p3_plan(B, Ho, Wo, O, I, dil, q3_mode == 2, pl, true)) return 3;
     if (fused_ok && p3_mode && p3_plan(B, Ho, Wo, O, I, dil, p3_mode == 2, pl)) return 2;
-    return use_tn256(I, stride, Ha, Ho, Wa, Wo) ? 1 : 0;
+    if (use_tn256(I, stride, Ha, Ho, Wa, Wo)) return 1;
+    const char* e4 = getenv("MI_WGRAD_S4");
+    const long M = (long)B * Ho * Wo;
+    if ((e4 ? atoi(e4) : 1) && ksize == 1 && pad == 0 && stride == 1 && Ha == Ho && Wa == Wo && M * (O > I ? O : I) * 2 < (1L << 31)) return 4;
+    return 0;
 }
 
 extern "C" int mi_conv_wgrad(const void* dy, const void* x, float* dw, int B, int Ha, int Wa, int I, int Ho, int Wo, int O,

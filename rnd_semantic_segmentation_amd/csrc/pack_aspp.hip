@@ -54,9 +54,14 @@ __global__ void aspp_pack_dgrad_kernel(const float* __restrict__ w4, __bf16* __r
 }
 
 // All conv weights of a module in ONE launch: table row = {w_off, scale_off(-1: none), wp_off, wpt_off(-1: skip), O, I, T,
-// first_block}; a block handles 256 (o,i) pairs of one tensor, reads the k*k taps once and writes both packs.
-__global__ void pack_multi_kernel(const float* __restrict__ wflat, const float* __restrict__ sflat, __bf16* __restrict__ wp,
-                                  __bf16* __restrict__ wpt, const long* __restrict__ table, int n_desc) {
+// first_block}; a block handles up to four 32 (o) x 32 (i) tiles (consecutive along i) of one tensor: the 32 * T floats of an o row are contiguous in OIHW and are
+// read as such into LDS; both packs then leave as 64-byte runs (32 consecutive i of the forward operand [t][o][i], 32 consecutive o
+// of the data-gradient operand [t][i][o]).  A thread per (o, i) pair writing its T taps scattered the data-gradient pack as
+// single bf16 stores O * 2 bytes apart: 303 us per step for 42 M weights, 4.4x the time of the bytes it moves.
+constexpr int PACK_TILES = 4;      // consecutive 32 x 32 tiles (along i) per block: one table search for 4-36 K weights
+__global__ __launch_bounds__(256) void pack_multi_kernel(const float* __restrict__ wflat, const float* __restrict__ sflat, __bf16* __restrict__ wp,
+                                                         __bf16* __restrict__ wpt, const long* __restrict__ table, int n_desc) {
+    __shared__ float tile[32][32 * 9 + 1];           // odd row stride: the transposed read (lanes over o) is conflict-free
     int lo = 0, hi = n_desc - 1;                     // last row whose first_block <= blockIdx.x
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -64,18 +69,44 @@ __global__ void pack_multi_kernel(const float* __restrict__ wflat, const float* 
     }
     const long* d = table + lo * 8;
     const int O = (int)d[4], I = (int)d[5], T = (int)d[6];
-    const long idx = ((long)blockIdx.x - d[7]) * 256 + threadIdx.x;
-    if (idx >= (long)O * I) return;
-    const int o = (int)(idx / I), i = (int)(idx - (long)o * I);
-    const float* src = wflat + d[0] + idx * T;
-    const float sc = d[1] >= 0 ? sflat[d[1] + o] : 1.f;
+    const int tiles_i = (I + 31) >> 5, groups_i = (tiles_i + PACK_TILES - 1) / PACK_TILES;
+    const int local = (int)((long)blockIdx.x - d[7]);
+    const int ot = local / groups_i;
+    const int o0 = ot * 32, it0 = (local - ot * groups_i) * PACK_TILES;
+    if (o0 >= O) return;
+    const int no = min(32, O - o0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long plane = (long)O * I;
-    __bf16* f = wp + d[2] + idx;
-    __bf16* b = d[3] >= 0 ? wpt + d[3] + (long)i * O + o : nullptr;
-    for (int t = 0; t < T; ++t) {
-        const float v = src[t];
-        f[t * plane] = (__bf16)v;
-        if (b) b[t * plane] = (__bf16)(v * sc);
+    const int c = tid & 31, r = tid >> 5;
+    const float sc = (d[3] >= 0 && d[1] >= 0 && c < no) ? sflat[d[1] + o0 + c] : 1.f;
+    for (int it = it0; it < it0 + PACK_TILES && it < tiles_i; ++it) {
+        const int i0 = it * 32;
+        const int ni = min(32, I - i0);
+        const int rowlen = ni * T;
+        if (it != it0) __syncthreads();
+        for (int o = wave; o < no; o += 4) {
+            const float* src = wflat + d[0] + ((long)(o0 + o) * I + i0) * T;
+            for (int e = lane; e < rowlen; e += 64) tile[o][e] = src[e];
+        }
+        __syncthreads();
+        // forward operand wp[t][o][i]: lanes over i
+        if (c < ni) {
+            for (int k = 0; k < 4; ++k) {
+                const int o = r + 8 * k;
+                if (o >= no) break;
+                __bf16* f = wp + d[2] + (long)(o0 + o) * I + i0 + c;
+                for (int t = 0; t < T; ++t) f[t * plane] = (__bf16)tile[o][c * T + t];
+            }
+        }
+        // data-gradient operand wpt[t][i][o] with the FrozenBN scale of output channel o folded in: lanes over o
+        if (d[3] >= 0 && c < no) {
+            for (int k = 0; k < 4; ++k) {
+                const int i = r + 8 * k;
+                if (i >= ni) break;
+                __bf16* b = wpt + d[3] + (long)(i0 + i) * O + o0 + c;
+                for (int t = 0; t < T; ++t) b[t * plane] = (__bf16)(tile[c][i * T + t] * sc);
+            }
+        }
     }
 }
 

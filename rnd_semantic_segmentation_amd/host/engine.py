@@ -197,6 +197,7 @@ class StageEngine:
         for rt in self.convs:
             c = rt.spec
             T = c.k * c.k
+            assert T <= 9, "mi_pack_weights_multi packs 1x1 and 3x3 convs"
             rows.append([rt.weight._mi_off, soff, off, off, c.cout, c.cin, T, blk])
             rt.wp = self._wp_flat[off:off + rt.weight.numel()].view(T, c.cout, c.cin)
             rt.wpt = self._wpt_flat[off:off + rt.weight.numel()].view(T, c.cin, c.cout)
@@ -204,7 +205,7 @@ class StageEngine:
             rt.shift = self._shift_flat[soff:soff + c.cout]
             off += rt.weight.numel()
             soff += c.cout
-            blk += -(-(c.cout * c.cin) // 256)
+            blk += -(-c.cout // 32) * -(-c.cin // 128)        # one block per 32 (o) x 128 (i) channels
         self._pack_blocks = blk
         self._table_train = torch.tensor(rows, dtype=torch.int64, device=dev)
         for r in rows:

@@ -178,7 +178,7 @@ def conv_wgrad(dy, x, dw, ksize=1, stride=1, pad=0, dil=1, scale=None, accumulat
     flops = 2.0 * B * Ho * Wo * o_real * I * ksize * ksize
     kern = "wgrad_tn_kernel+reduce"
     if PROFILE is not None:
-        kern = ("wgrad_tn_kernel", "wgrad_tn256_kernel", "wgrad_p3_kernel", "wgrad_q3_kernel")[
+        kern = ("wgrad_tn_kernel", "wgrad_tn256_kernel", "wgrad_p3_kernel", "wgrad_q3_kernel", "wgrad_s4_kernel")[
             L.mi_conv_wgrad_route(B, Ha, Wa, I, Ho, Wo, O, ksize, stride, pad, dil, out_map)] + "+reduce"
     check(_timed(kern, flops, lambda: L.mi_conv_wgrad(
         _p(dy), _p(x), _p(dw), B, Ha, Wa, I, Ho, Wo, O, ksize, stride, pad, dil, _p(scale),
