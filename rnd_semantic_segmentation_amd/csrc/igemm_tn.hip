@@ -361,8 +361,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_s4_kernel(WgradParams p) {
 }
 
 // ---- 128 (o) x 256 (i) tile, 32 pixels per K step --------------------------------------------------------------------------
-// The 128 x 128 kernel above is bound by the bytes the L2 hands to the LDS (15.6 per kFLOP; the L2 -> LDS path sustains
-// ~43 GB/s per CU).  Widening the tile over the INPUT channels to 256 with a 32-pixel step keeps the MFMA
+// The 128 x 128 kernel above was read as bound by the bytes the L2 hands to the LDS (15.6 per kFLOP at ~43 GB/s per CU; the later
+// microbenchmark tools/micro/l2lds.hip puts that path at 90-125 GB/s per CU for L2 hits and 28-30 for misses).  Widening the tile over the INPUT channels to 256 with a 32-pixel step keeps the MFMA
 // work per step (32 per wave) and the two-workgroups-per-CU structure (48 KiB of LDS, 128 accumulator registers) and moves
 // 24 KiB instead of 32 KiB per step: 11.4 bytes per kFLOP.  Used for stride-1 convs with I >= 256 (every layer3 / layer4 / ASPP
 // weight gradient).  Same slab layout, same reducer.
@@ -1192,8 +1192,8 @@ extern "C" int mi_conv_wgrad(const void* dy, const void* x, float* dw, int B, in
     // MI_WGRAD_P3: 0 = never (default), 1 = by the plan's own rule, 2 = whenever the geometry allows (tests: tiny shapes).
     // Opt-in because it does not win yet: at 256 -> 256, d = 2, M = 75 272 it takes 127 us against 131 us for the per-tap
     // kernel (512 -> 512: 404 vs 405).  Its parts, measured with the MI_P3_DBG toggles (tools/wgexp.py): MFMAs alone 42 us,
-    // LDS->register reads 25 us, DMA alone 49 us - the same with L2-hot rows, i.e. the L2 -> LDS path delivers ~43 GB/s per CU
-    // to this access pattern whatever the source (the 64-B-row slabs of igemm_pp.hip get half their lines from the L1) -,
+    // LDS->register reads 25 us, DMA alone 49 us - the same with L2-hot rows (~43 GB/s per CU; a bare stream of the same shape
+    // reaches 120 GB/s from the L2, tools/micro/l2lds.hip, so the DMA issue beside the partner's MFMAs is what was measured) -,
     // partial-plane stores 14 us, slab reducer 23 us.  With the DMA at 115 % of the MFMA time the ping-pong's read segments
     // (which carry the DMA issue) outlast the MFMA segments and the two hardly overlap (main loop 80 us).
     static int p3_mode = -1;
