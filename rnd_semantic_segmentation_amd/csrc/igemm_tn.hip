@@ -536,16 +536,22 @@ int pick_splits256(long M, int tiles) {
     return best;
 }
 
-inline bool use_tn256(int I, int stride, int Ha, int Ho, int Wa, int Wo) {
-    static int on = -1;
-    if (on < 0) {
-        // opt-in: measured SLOWER than the 128 x 128 kernel (B = 8, 97 x 97: 1x1 256 <-> 1024 71 us vs 58 us, 3x3 256 144 vs 129,
-        // 3x3 512 397 vs 406; with a drain + barrier per step instead of the ring: 81 / 139 us).  27 % fewer L2 bytes do not pay
-        // for twice the K steps: a step of these kernels costs one DMA round trip whatever it moves.
+inline bool use_tn256(int O, int I, int ksize, int pad, int stride, int Ha, int Ho, int Wa, int Wo) {
+    static int mode = -2;
+    if (mode == -2) {
+        // MI_WGRAD_TI256: unset = by rule, 0 = never, 1 = every stride-1 conv with I >= 256 (tests).
+        // Warm (operands in the Infinity Cache from the previous iteration of a timing loop) this kernel is SLOWER than the 128 x 128
+        // ones (B = 8, 97 x 97: 1x1 256 <-> 1024 71 us vs 58 us, 3x3 256 144 vs 129, 3x3 512 397 vs 406).  In the training step, with
+        // cold operands, the big 1x1 launches are HBM-latency-bound: the L2 -> LDS fill rate is (bytes in flight) / (HBM round trip),
+        // equal for both kernels, and this tile turns it into 1.33x the unique bytes (dy is read once instead of twice).  In-step:
+        // 512 -> 2048 172 vs 199 us, 2048 -> 512 162 vs 197, 1024 -> 2048 264 vs 374, 512 <-> 1024 98 vs 105; 256 <-> 1024 72 vs 70
+        // (the slab traffic of the larger split count eats the gain there), hence the size rule.
         const char* e = getenv("MI_WGRAD_TI256");
-        on = e ? atoi(e) : 0;
+        mode = e ? atoi(e) : -1;
     }
-    return on && I >= 256 && stride == 1 && Ha == Ho && Wa == Wo;
+    if (mode == 0 || I < 256 || stride != 1 || Ha != Ho || Wa != Wo) return false;
+    if (mode > 0) return true;
+    return ksize == 1 && pad == 0 && (long)O * I >= 512L * 1024;
 }
 
 // dw[o][i][t] = scale[o] * sum_s slab[s][t][o][i]   (fixed summation order -> reproducible).
@@ -1161,7 +1167,7 @@ extern "C" int mi_conv_wgrad_route(int B, int Ha, int Wa, int I, int Ho, int Wo,
     P3Plan pl;
     if (fused_ok && q3_mode && !p3_mode && p3_plan(B, Ho, Wo, O, I, dil, q3_mode == 2, pl, true)) return 3;
     if (fused_ok && p3_mode && p3_plan(B, Ho, Wo, O, I, dil, p3_mode == 2, pl)) return 2;
-    if (use_tn256(I, stride, Ha, Ho, Wa, Wo)) return 1;
+    if (use_tn256(O, I, ksize, pad, stride, Ha, Ho, Wa, Wo)) return 1;
     const char* e4 = getenv("MI_WGRAD_S4");
     const long M = (long)B * Ho * Wo;
     if ((e4 ? atoi(e4) : 1) && ksize == 1 && pad == 0 && stride == 1 && Ha == Ho && Wa == Wo && M * (O > I ? O : I) * 2 < (1L << 31)) return 4;
@@ -1246,7 +1252,7 @@ extern "C" int mi_conv_wgrad(const void* dy, const void* x, float* dw, int B, in
     p.pad = pad;
     p.dil = dil;
     p.o_tiles = (O + TO - 1) / TO;
-    const bool wide = use_tn256(I, stride, Ha, Ho, Wa, Wo);
+    const bool wide = use_tn256(O, I, ksize, pad, stride, Ha, Ho, Wa, Wo);
     if (wide) {
         p.i_tiles = (I + TI2 - 1) / TI2;
         p.S = pick_splits256(M, p.o_tiles * p.i_tiles * p.T);

@@ -87,6 +87,7 @@ def test_opt_in_kernel_variants_and_single_stream_schedule_stay_correct():
                      ({"MI_WGRAD_Q3": "2"}, ["tests/test_gpu_ops.py", "-k", "conv_fwd_dgrad or fused_epilogue or tiny_and_ragged or wgrad_full or full_size_vs"]),
                      ({"MI_WGRAD_Q3": "0"}, ["tests/test_gpu_ops.py", "-k", "wgrad_full or full_size_vs"]),
                      ({"MI_WGRAD_S4": "0"}, ["tests/test_gpu_ops.py", "-k", "tiny_and_ragged or wgrad_full or pointwise or aspp_head_2048"]),   # 1x1 weight gradients on the double-buffer kernel
+                     ({"MI_WGRAD_TI256": "0"}, ["tests/test_gpu_ops.py", "-k", "wgrad_full or aspp_head_2048 or aspp_head_upsample"]),   # the big 1x1 shapes on the 128 x 128 kernels
                      ({"MI_WGRAD_TI256": "1"}, ["tests/test_gpu_ops.py", "-k", "tiny_and_ragged or wgrad_full or full_size_vs or aspp_head_2048"]),
                      ({"MI_WGRAD_STREAM": "0", "MI_BATCH_LANES": "1"}, ["tests/test_gpu_model.py", "-k", "tinynet"])):
         r = run(["-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider"] + sel, env)
