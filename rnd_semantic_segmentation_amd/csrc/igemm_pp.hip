@@ -254,13 +254,19 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmParams p) {
     const bool tr_on = blockIdx.x == p.korder >> 8 && wq == 0;
     const unsigned long long tr_c0 = __builtin_readcyclecounter(), tr_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
+#if defined(PP_DBG) && (PP_DBG & 1)
+    read_frags(0);                                                  // timeline experiment: the loop below issues no LDS reads
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     for (int s = 0; s < ns; ++s) {
         // ---- read segment (G0: I_2s, G1: I_2s+1) ----
         PP_T(0)
         PP_T(1)
+#if !(defined(PP_DBG) && (PP_DBG & 1))
         read_frags(s);
+#endif
         piece_sources();
-#if !PP_DMA_SEG
+#if !PP_DMA_SEG && !(defined(PP_DBG) && (PP_DBG & 2))
         {
             char* dst = smem + (ld_s & 3) * SLAB + (grp == 0 ? wq * (NPA * 1024) : SLAB_A + wq * (NPW * 1024));
 #pragma unroll
@@ -273,7 +279,9 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmParams p) {
         PP_T(2)
         // end of an odd interval: group 1's pieces of slab s+1 must have landed (only slab s+2 may still be in flight: it stages
         // slab s+3 in the MFMA segment below)
+#if !(defined(PP_DBG) && (PP_DBG & 2))
         if (grp == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP_DMA_SEG ? NPW : 2 * NPW) : "memory");
+#endif
         __builtin_amdgcn_s_barrier();
         PP_T(3)
         // ---- MFMA segment (G0: I_2s+1, G1: I_2s+2) ----
