@@ -646,3 +646,40 @@ def test_conv_full_size_vs_pytorch_fp32_conv(cin, cout, k, d):
     dw = torch.empty_like(w)
     K.conv_wgrad(dy, x, dw, k, 1, pad, d)
     assert rel(dw, wr.grad) < 1e-3
+
+
+def test_table_driven_weight_pack_equals_the_per_tensor_packs_on_ragged_shapes():
+    """mi_pack_weights_multi (one launch for every conv of a module; 32 x 128 channel blocks through LDS) against exact
+    arithmetic and against mi_pack_weight_fwd / _dgrad: 1x1 and 3x3 tensors whose O and I are not multiples of the block
+    (tails in both directions, a tensor smaller than one block), with and without the data-gradient operand and the folded
+    FrozenBN scale.  bf16(x) and bf16(x * scale) are single roundings of fp32 values: bit exact."""
+    g = torch.Generator(device="cpu").manual_seed(11)
+    shapes = [(40, 24, 3), (8, 8, 1), (136, 264, 1), (72, 200, 3), (33, 129, 1), (256, 64, 3)]
+    ws = [torch.randn((o, i, k, k), generator=g) for o, i, k in shapes]
+    scales = [torch.rand(o, generator=g) + 0.5 for o, _, _ in shapes]
+    wflat = torch.cat([w.reshape(-1) for w in ws]).to(DEV)
+    sflat = torch.cat(scales).to(DEV)
+    for with_dgrad in (True, False):
+        rows, off, soff, blk = [], 0, 0, 0
+        for (o, i, k), w in zip(shapes, ws):
+            rows.append([off, soff if (o % 16) else -1, off, off if with_dgrad else -1, o, i, k * k, blk])   # some tensors without a scale
+            off += w.numel()
+            soff += o
+            blk += -(-o // 32) * -(-i // 128)
+        table = torch.tensor(rows, dtype=torch.int64, device=DEV)
+        wp = torch.full((off,), float("nan"), dtype=torch.bfloat16, device=DEV)
+        wpt = torch.full((off,), float("nan"), dtype=torch.bfloat16, device=DEV)
+        K.pack_weights_multi(wflat, sflat, wp, wpt, table, len(rows), blk)
+        for r, (o, i, k), w, sc in zip(rows, shapes, ws, scales):
+            n = w.numel()
+            wd = w.to(DEV)
+            want_f = wd.permute(2, 3, 0, 1).reshape(k * k, o, i).to(torch.bfloat16)
+            assert torch.equal(wp[r[2]:r[2] + n].view(k * k, o, i), want_f)
+            assert torch.equal(K.pack_weight_fwd(wd), want_f)
+            if with_dgrad:
+                s = sc.to(DEV) if r[1] >= 0 else torch.ones(o, device=DEV)
+                want_b = (wd * s.view(-1, 1, 1, 1)).permute(2, 3, 1, 0).reshape(k * k, i, o).to(torch.bfloat16)
+                assert torch.equal(wpt[r[3]:r[3] + n].view(k * k, i, o), want_b)
+                assert torch.equal(K.pack_weight_dgrad(wd, s), want_b)
+            else:
+                assert bool(torch.isnan(wpt[r[2]:r[2] + n].float()).all())          # untouched
