@@ -349,8 +349,13 @@ extern "C" int mi_conv_gemm_route(int B, int Ha, int Wa, int Ca, int Ho, int Wo,
         const char* e = getenv("MI_IGEMM_PP");
         pp_on = e ? atoi(e) : 1;
     }
+    static int min_k = -1;
+    if (min_k < 0) {
+        const char* e = getenv("MI_IGEMM_PP_MINK");
+        min_k = e ? atoi(e) : 512;         // in the step: 704 -> 2048 (ASPP data gradient) 246 vs 280 us, 512 -> 1024 101 vs 116; K = 256: no difference
+    }
     const long M = (long)B * Ho * Wo;
-    return pp_on && stride == 1 && Ha == Ho && Wa == Wo && !(flags & (MI_EPI_RESIDUAL | MI_EPI_MASK | MI_EPI_LEAKY)) && (long)ksize * ksize * Ca >= 1024 &&
+    return pp_on && stride == 1 && Ha == Ho && Wa == Wo && !(flags & (MI_EPI_RESIDUAL | MI_EPI_MASK | MI_EPI_LEAKY)) && (long)ksize * ksize * Ca >= min_k &&
            Ca % 32 == 0 && M >= 320 * 64 && N >= 256;
 }
 
@@ -381,7 +386,7 @@ extern "C" int mi_conv_gemm(const void* a, const void* wp, void* out, int B, int
     }
     // Long contractions without a residual tile go to the wide-tile ping-pong main loop (igemm_pp.hip): 7.0 instead of 13-14
     // L2 bytes per kFLOP.  Measured per shape against this kernel in one process (tools/ppexp.py, B = 8, 97 x 97): 3x3 256 +16 %,
-    // 3x3 512 +13 %, 1x1 2048->512 +18 %, 1x1 1024->256 / 1024->2048 / ASPP forward +6 %; the short contractions (K <= 704)
+    // 3x3 512 +13 %, 1x1 2048->512 +18 %, 1x1 1024->256 / 1024->2048 / ASPP forward +6 %; the short contractions (K < 512)
     // are epilogue-bound and stay here.  MI_IGEMM_PP=0 switches the dispatch off.
     if (mi_conv_gemm_route(B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, flags))
         return mi_conv_gemm_pp(a, wp, out, B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, pad, dil, gather_mode, scale, bias, res, msk, mask_out, flags, zgw,
