@@ -236,16 +236,19 @@ def main():
             tsec, fl, n = by[dom]
             # HBM bytes per launch of that kernel come from separate rocprofv3 --pmc passes (profiles/pmc.json, written by
             # profiles/make_pmc_json.py from the passes of tools/profile_round.sh): counters cannot be read inside this process.
-            traffic, traffic_src = None, None
+            traffic, traffic_src, l2 = None, None, None
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc.json")))
                 key = dom.split("+")[0]
                 traffic = pmc[key]["hbm_bytes_per_launch"]
+                if "l2_hit_frac" in pmc[key]:
+                    l2 = {"hit_frac": pmc[key]["l2_hit_frac"], "requests_per_launch": pmc[key]["l2_requests_per_launch"],
+                          "mfma_busy_frac": pmc[key]["mfma_busy_frac"]}
                 traffic_src = {"file": "profiles/pmc.json", "profiled_commit": pmc.get("_meta", {}).get("commit"), "round": pmc.get("_meta", {}).get("round")}
             except (OSError, KeyError, ValueError):
                 pass
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(fl / tsec / 1e12, 2), "peak": PEAK_BF16_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(fl / tsec / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                               "unit": "TFLOP/s", "frac": round(fl / tsec / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src, "l2": l2,
                                "launches_per_step": n // inst_steps, "avg_launch_us": round(1e6 * tsec / n, 2),
                                "alg_gflop_per_launch": round(fl / n / 1e9, 3), "ms_per_step_in_kernel": round(1e3 * tsec / inst_steps, 3),
                                "instrumented_steps": inst_steps,

@@ -7,14 +7,15 @@ cannot share a pass; never combine --pmc with sys/hip/hsa traces):
     rocprofv3 --kernel-trace --pmc WRITE_SIZE  --output-format csv -d <C> -- python3 bench.py ...
 gfx950 corrections (guide, section HBM): FETCH_SIZE is in KiB and reports HALF of a wide coalesced stream -> x 1024 x 2;
 WRITE_SIZE is in KiB and exact -> x 1024.
-Usage: python profiles/make_pmc_json.py <A> <B> <C> [out.json]"""
+A fourth pass (optional, sixth argument) adds the L2 picture: TCC_REQ_sum / TCC_HIT_sum / TCC_MISS_sum per launch.
+Usage: python profiles/make_pmc_json.py <A> <B> <C> [out.json [round [<D>]]]"""
 import csv
 import glob
 import json
 import sys
 from collections import defaultdict
 
-KERNELS = {"igemm_nt_kernel": "igemm_nt_kernel", "igemm_pp_kernel": "igemm_pp_kernel", "wgrad_tn_kernel": "wgrad_tn_kernel", "wgrad_q3_kernel": "wgrad_q3_kernel", "wgrad_s4_kernel": "wgrad_s4_kernel",
+KERNELS = {"igemm_nt_kernel": "igemm_nt_kernel", "igemm_pp_kernel": "igemm_pp_kernel", "wgrad_tn_kernel": "wgrad_tn_kernel", "wgrad_q3_kernel": "wgrad_q3_kernel", "wgrad_s4_kernel": "wgrad_s4_kernel", "wgrad_tn256_kernel": "wgrad_tn256_kernel",
            "wgrad_reduce_kernel": "wgrad_reduce_kernel", "upce_pass1_kernel": "upce_pass1_kernel"}
 
 
@@ -35,6 +36,9 @@ def main():
     a, na, da = load(sys.argv[1])
     b, nb, _ = load(sys.argv[2])
     c, nc, _ = load(sys.argv[3])
+    d4 = n4 = None
+    if len(sys.argv) > 6 and glob.glob(sys.argv[6] + "/**/*_counter_collection.csv", recursive=True):
+        d4, n4, _ = load(sys.argv[6])
     out = {}
     for k in KERNELS.values():
         L = na[(k, "GRBM_GUI_ACTIVE")]
@@ -47,6 +51,9 @@ def main():
                   "mfma_busy_frac": round(mf / (gui / 8 * 1024), 4), "clock_ghz": round(gui / 8 / da[(k, "GRBM_GUI_ACTIVE")], 3),
                   "hbm_read_bytes_per_launch": round(fetch), "hbm_write_bytes_per_launch": round(write),
                   "hbm_bytes_per_launch": round(fetch + write)}
+        if d4 is not None and n4[(k, "TCC_REQ_sum")]:
+            req, hit = d4[k]["TCC_REQ_sum"] / n4[(k, "TCC_REQ_sum")], d4[k]["TCC_HIT_sum"] / n4[(k, "TCC_HIT_sum")]
+            out[k].update({"l2_requests_per_launch": round(req), "l2_hit_frac": round(hit / req, 4) if req else None})
     import subprocess
     import os
     commit = None
