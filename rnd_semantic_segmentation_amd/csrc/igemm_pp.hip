@@ -1,15 +1,16 @@
 // Implicit-GEMM convolution, wide-tile "ping-pong" main loop for gfx950 (bf16 operands, fp32 MFMA accumulate).
 //
 //   out[m][n] = epi( sum_t sum_c A[src(m,t)][c] * Wp[t][n][c] )      same contract and epilogue as igemm_nt.hip, for the
-// stride-1 convs / plain GEMMs with a long contraction (K = taps * Ca >= 1024): the dilated 3x3 family of layer3 / layer4
+// stride-1 convs / plain GEMMs with a long contraction (K = taps * Ca >= 512): the dilated 3x3 family of layer3 / layer4
 // (reference core/components/resnet.py:22-25, 100) and the ASPP head's GEMMs (classifiers/aspp/classifier.py:26-29).
 //
-// Why a second main loop: every conv launch of the 128-wide kernel fits one model - time = bytes the L2 hands to the LDS /
-// ~13 TB/s - so the lever is bytes per FLOP, i.e. the tile.  This kernel computes a (2*16*MTG) x 256
+// Why a second main loop: the 128-wide kernel moves 13-14 bytes from the L2 into LDS per kFLOP, and with the step's cold operands
+// what fills the LDS is the scarce resource - the lever is bytes per FLOP, i.e. the tile.  This kernel computes a (2*16*MTG) x 256
 // tile per workgroup (320 x 256: 7.0 B/kFLOP against 13-14 for the 128-wide tiles) with ONE workgroup of 8 waves per CU, and
 // replaces the co-resident second workgroup (which used to hide the DMA drain and the barrier of every K-step) by structure:
-//   * K advances in 32-channel slabs through a 4-slot LDS ring; three slabs are always in flight (global_load_lds, counted
-//     s_waitcnt vmcnt, raw s_barrier - a __syncthreads() would drain the DMA queue);
+//   * K advances in 32-channel slabs through a 4-slot LDS ring; three slabs are always in flight (buffer_load ... lds, counted
+//     s_waitcnt vmcnt, raw s_barrier - a __syncthreads() would drain the DMA queue).  A 3x3 contraction runs channel-chunk-major
+//     (all nine taps of a 32-channel chunk, then the next chunk: the shifted re-reads of the input rows hit the L2);
 //   * the 8 waves are two groups of 4 (one wave of each group per SIMD).  Group 0 owns the upper half of the tile's rows,
 //     group 1 the lower half, each wave 16*MTG rows x 64 columns.  The groups run the same loop half a phase apart: while one
 //     group issues its MFMAs for slab p, the other reads its fragments of slab p (or p+1) from LDS and issues its share of
@@ -19,8 +20,7 @@
 //   every wave waits for ITS DMA pieces of slab p+1 (vmcnt, two younger slabs stay in flight) at the end of I_2p+1, so that
 //   after B_2p+2 the slab is visible to group 0 and after B_2p+3 to group 1;
 //   slab p+3 lands in the slot of slab p-1, whose last reader (G1 in I_2p-1) finished its ds_reads (lgkmcnt(0)) before B_2p.
-// (Tried and dropped: issuing half of a slab's DMA pieces at the head of the MFMA segment instead of the read segment - the
-// MFMA segments stretch more than the read segments shrink: 3x3 256 main loop 86 vs 73.5 us.)
+// (Tried and dropped: issuing a slab's DMA pieces inside the MFMA segment instead of the read segment - see PP_DMA_SEG below.)
 // LDS image of a slab: A rows then W rows, 64 B (32 channels) per row, lane-linear per 1-KiB DMA piece (16 rows); the 16-B chunk
 // c of row r sits at chunk c ^ s(r), applied to the per-lane SOURCE address and to the ds_read_b128 address, with
 // s_A(r) = (-(r >> 2)) & 3 and s_W(r) = ((r >> 3) & 1) << 1: both make every ds_read_b128 lane group hit 64 distinct banks
@@ -237,8 +237,6 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmParams p) {
     };
 
     // ---- prologue: three slabs in flight, slab 0 landed -------------------------------------------------------------------------
-    constexpr int NP = 0;   // (placeholder so that the waits below read as counts of PIECES per slab per wave)
-    (void)NP;
     for (int s = 0; s < 3 && s < ns; ++s) stage_next();
     if (ns >= 3) {
         if (grp == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPA) : "memory");
