@@ -247,8 +247,8 @@ def g_frozenbn(ref, out):
 
 
 # ------------------------------------------------------------------ G5 tiny net train steps (+G9 bf16 autocast)
-def build_ref_net(ref, arch):
-    fe = ref.fe(arch, pretrained_weights=None, aux=False, pretrained_backbone=False, freeze_bn=True)
+def build_ref_net(ref, arch, freeze_bn=True):
+    fe = ref.fe(arch, pretrained_weights=None, aux=False, pretrained_backbone=False, freeze_bn=freeze_bn)
     cls = ref.ASPP(2048, [6, 12, 18, 24], [6, 12, 18, 24], 19)
     synth.load_formula_weights(fe)
     synth.load_formula_weights(cls)
@@ -320,6 +320,50 @@ def g_tinynet(ref, out):
     fe, cls = build_ref_net(ref, "resnet_tiny")
     rec, first = train_steps(ref, fe, cls, x, lab, steps=1, base_lr=5e-4, max_iter=30, autocast=True)
     save(out, "g9_tinynet_bf16", loss=np.array(rec["loss"]), low=first["low"])
+
+
+def g_tinynet_bn(ref, out):
+    """G10: MODEL.FREEZE_BN=False (feature_extractor.py:37-39 -> nn.BatchNorm2d): three training steps with batch statistics
+    (aspp_trainer.py:77-97; fe.train()), then an eval-mode forward on the running statistics."""
+    B, S = 2, 65
+    x = synth.synth_image(B, S, S, seed=13)
+    lab = synth.synth_label(B, S, S, 19, seed=13)
+    fe, cls = build_ref_net(ref, "resnet_tiny", freeze_bn=False)
+    keys = list(fe.state_dict().keys())
+    rec, first = train_steps(ref, fe, cls, x, lab, steps=3, base_lr=5e-4, max_iter=30)
+    arrays = dict(x_seed=13, loss=np.array(rec["loss"]), lr=np.array(rec["lr"]), low=first["low"],
+                  feat_crop=first["feat"][:, :64, :, :].copy(), feat_absmax=np.abs(first["feat"]).max())
+    gn, gcrop, pn = {}, {}, {}
+    for k, g in first["grads"].items():
+        gn[k] = float(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        gcrop[k] = g.reshape(-1)[:16].copy()
+    for m in (fe, cls):
+        for k, p in m.named_parameters():
+            pn[k] = float(p.detach().double().norm())
+    names = sorted(gn)
+    arrays.update(param_names=np.array(names), grad_norm=np.array([gn[k] for k in names]),
+                  grad_crop=np.stack([gcrop[k] for k in names]), param_norm_after=np.array([pn[k] for k in names]))
+    sd = fe.state_dict()
+    stat_names = sorted(k for k in sd if k.endswith("running_mean") or k.endswith("running_var"))
+    arrays["stat_names"] = np.array(stat_names)
+    arrays["stat_norm_after"] = np.array([float(sd[k].double().norm()) for k in stat_names])
+    for k in ("backbone.bn1", "backbone.layer3.1.bn2", "backbone.layer4.1.bn3"):
+        arrays["after_" + k.replace(".", "_") + "_mean"] = sd[k + ".running_mean"].numpy().copy()
+        arrays["after_" + k.replace(".", "_") + "_var"] = sd[k + ".running_var"].numpy().copy()
+        arrays["after_" + k.replace(".", "_") + "_weight"] = sd[k + ".weight"].numpy().copy()
+    arrays["num_batches_tracked"] = int(sd["backbone.bn1.num_batches_tracked"])
+    fe.eval()
+    cls.eval()
+    with torch.no_grad():
+        arrays["low_eval"] = cls(fe(t(x))).numpy()
+    save(out, "g10_tinynet_bn_fp32", **arrays)
+    with open(os.path.join(out, "g8_tinynet_bn_keys.json"), "w") as f:
+        json.dump({"keys": keys, "n_fe_params": sum(p.numel() for p in fe.parameters())}, f)
+    # the full-size key / parameter counts of SURVEY 8a row A7 (312 tensors, 42 500 160 parameters, 624 state keys)
+    fe101 = ref.fe("resnet101", pretrained_weights=None, aux=False, pretrained_backbone=False, freeze_bn=False)
+    with open(os.path.join(out, "g8_r101_bn_keys.json"), "w") as f:
+        json.dump({"keys": list(fe101.state_dict().keys()), "n_fe_params": sum(p.numel() for p in fe101.parameters()),
+                   "n_fe_tensors": len(list(fe101.parameters()))}, f)
 
 
 def eval_record(ref, probs, pred, lab):
@@ -551,7 +595,7 @@ def main():
     torch.set_num_threads(8)
     ref = import_reference()
     jobs = dict(conv=lambda: g_conv(ref, args.out), aspp=lambda: g_aspp(ref, args.out),
-                frozenbn=lambda: g_frozenbn(ref, args.out), tinynet=lambda: g_tinynet(ref, args.out),
+                frozenbn=lambda: g_frozenbn(ref, args.out), tinynet=lambda: g_tinynet(ref, args.out), tinynet_bn=lambda: g_tinynet_bn(ref, args.out),
                 r101=lambda: g_r101(ref, args.out, not args.skip_big), metrics=lambda: g_metrics(ref, args.out),
                 fada=lambda: g_fada(ref, args.out))
     for name, fn in jobs.items():

@@ -62,8 +62,7 @@ def resnet_plan(layers=(3, 4, 23, 3), dilate=(False, True, True)):
 class RefFeatureExtractor(nn.Module):
     def __init__(self, layers=(3, 4, 23, 3), freeze_bn=True):
         super().__init__()
-        if not freeze_bn:
-            raise NotImplementedError("oracle covers MODEL.FREEZE_BN=True (configs/deeplabv2_r101_src.yaml:4)")
+        self.freeze_bn = freeze_bn            # False: nn.BatchNorm2d semantics (feature_extractor.py:37-39), batch statistics in train()
         self.plan = resnet_plan(layers)
         self.backbone = _Box()
         self._conv("conv1", 64, 3, 7)
@@ -88,16 +87,26 @@ class RefFeatureExtractor(nn.Module):
 
     def _bn(self, path, n):
         box = _box_path(self.backbone, path)
-        box.register_buffer("weight", torch.ones(n))
-        box.register_buffer("bias", torch.zeros(n))
+        if self.freeze_bn:
+            box.register_buffer("weight", torch.ones(n))
+            box.register_buffer("bias", torch.zeros(n))
+        else:                                  # torch.nn.BatchNorm2d(n): affine parameters, eps 1e-5, momentum 0.1
+            box.weight = nn.Parameter(torch.ones(n))
+            box.bias = nn.Parameter(torch.zeros(n))
         box.register_buffer("running_mean", torch.zeros(n))
         box.register_buffer("running_var", torch.ones(n))
+        if not self.freeze_bn:
+            box.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
     def _w(self, path):
         return _box_path(self.backbone, path).weight
 
     def _apply_bn(self, x, path):
         b = _box_path(self.backbone, path)
+        if not self.freeze_bn:
+            if self.training:
+                b.num_batches_tracked += 1
+            return F.batch_norm(x, b.running_mean, b.running_var, b.weight, b.bias, self.training, 0.1, 1e-5)
         scale = b.weight * b.running_var.rsqrt()            # layers.py:19 (no eps)
         shift = b.bias - b.running_mean * scale              # layers.py:20
         return x * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)

@@ -140,6 +140,63 @@ def test_tinynet_three_train_steps_fp32():
     assert rel(params["conv2d_list.0.bias"].detach().numpy(), g["after_aspp0_bias"]) < 1e-5
 
 
+def _tiny_bn():
+    fe = ref_model.RefFeatureExtractor(layers=(1, 1, 2, 2), freeze_bn=False)
+    cls = ref_model.RefASPP()
+    synth.load_formula_weights(fe)
+    synth.load_formula_weights(cls)
+    return fe, cls
+
+
+def test_trainable_batchnorm_state_dict_and_parameter_counts_match_reference(golden_dir):
+    """MODEL.FREEZE_BN=False (feature_extractor.py:37-39): nn.BatchNorm2d modules - 624 state keys, 312 parameter tensors,
+    42 500 160 parameters for resnet101."""
+    fe, _ = _tiny_bn()
+    keys = json.load(open(os.path.join(golden_dir, "g8_tinynet_bn_keys.json")))
+    assert list(fe.state_dict().keys()) == keys["keys"]
+    assert sum(p.numel() for p in fe.parameters()) == keys["n_fe_params"]
+    full = json.load(open(os.path.join(golden_dir, "g8_r101_bn_keys.json")))
+    fe = ref_model.RefFeatureExtractor(freeze_bn=False)
+    assert list(fe.state_dict().keys()) == full["keys"] and len(full["keys"]) == 624
+    assert sum(p.numel() for p in fe.parameters()) == full["n_fe_params"] == 42500160
+    assert len(list(fe.parameters())) == full["n_fe_tensors"] == 312
+
+
+def test_tinynet_trainable_batchnorm_three_train_steps_fp32():
+    """The oracle with batch statistics against the reference's own run (g10): losses, every gradient norm of step 0 (conv
+    weights and BatchNorm affine parameters), parameters and running statistics after three SGD steps, and the eval-mode
+    forward on those running statistics."""
+    g = _cases.load("g10_tinynet_bn_fp32")
+    x, lab = _cases.net_inputs(2, 65, 13)
+    fe, cls = _tiny_bn()
+    opt_f, opt_c = ref_model.make_optimizers(fe, cls, 5e-4)
+    xt, lt = torch.from_numpy(x), torch.from_numpy(lab)
+    losses = []
+    for it in range(3):
+        loss, lr = ref_model.ref_train_step(fe, cls, opt_f, opt_c, xt, lt, it, 30, 5e-4)
+        if it == 0:
+            grads = {k: p.grad.clone() for m in (fe, cls) for k, p in m.named_parameters()}
+        losses.append(loss.item())
+    assert np.allclose(losses, g["loss"], rtol=2e-5)
+    names = [str(n) for n in g["param_names"]]
+    gn = np.array([float(grads[k].double().norm()) for k in names])
+    assert np.allclose(gn, g["grad_norm"], rtol=5e-4, atol=1e-7)
+    params = dict(list(fe.named_parameters()) + list(cls.named_parameters()))
+    pn = np.array([float(params[k].detach().double().norm()) for k in names])
+    assert np.allclose(pn, g["param_norm_after"], rtol=1e-6)
+    sd = fe.state_dict()
+    sn = np.array([float(sd[str(k)].double().norm()) for k in g["stat_names"]])
+    assert np.allclose(sn, g["stat_norm_after"], rtol=1e-5)
+    assert rel(sd["backbone.layer3.1.bn2.running_var"].numpy(), g["after_backbone_layer3_1_bn2_var"]) < 1e-5
+    assert rel(sd["backbone.layer4.1.bn3.running_mean"].numpy(), g["after_backbone_layer4_1_bn3_mean"]) < 1e-4
+    assert int(sd["backbone.bn1.num_batches_tracked"]) == int(g["num_batches_tracked"]) == 3
+    fe.eval()
+    cls.eval()
+    with torch.no_grad():
+        low = cls(fe(xt))
+    assert rel(low.numpy(), g["low_eval"]) < 2e-5
+
+
 def test_r101_129_forward_loss_inference():
     g = _cases.load("g6_r101_129")
     x, lab = _cases.net_inputs(1, 129, 21)
