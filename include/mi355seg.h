@@ -243,6 +243,25 @@ int mi_relu_mask(const void* x_bf16, const void* msk, void* y_bf16, size_t n, in
 /* FrozenBN fold: scale = w*rsqrt(var) (no eps), shift = b - mean*scale (layers.py:18-20) */
 int mi_frozen_bn_fold(const float* w, const float* b, const float* mean, const float* var, float* scale, float* shift, int n, void* stream);
 
+/* ---- trainable BatchNorm2d (MODEL.FREEZE_BN=False: feature_extractor.py:37-39 builds the backbone on torch.nn.BatchNorm2d) over NHWC
+ * bf16 activations [M][C], C % 8 == 0, C <= 2048 for the reductions.  Reductions return RAW per-channel sums in a fixed order (bitwise
+ * reproducible); the caller divides by the pixel count, after an all-reduce over ranks when the statistics are synchronised
+ * (train_distill.py:53 converts to SyncBatchNorm).  workspace: mi_bn_workspace(M, C) bytes. */
+size_t mi_bn_workspace(long M, int C);
+/* out[c] = sum_m y[m][c] (mean == NULL) or sum_m (y[m][c] - mean[c])^2 (two-pass variance) */
+int mi_bn_colsum(const void* y_bf16, const float* mean, long M, int C, float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* out = relu?((y - mean[c]) * scale[c] + beta[c] (+ res)), scale = gamma * rsqrt(var + eps); mask_out (optional, C % 16 == 0): the
+ * packed sign bits of out in the layout of MI_EPI_WRITE_MASK */
+int mi_bn_apply(const void* y_bf16, const float* mean, const float* scale, const float* beta, const void* res_bf16, void* out_bf16,
+                void* mask_out, int relu, long M, int C, void* stream);
+/* dbeta[c] = sum_m g[m][c], dgamma[c] = sum_m g[m][c] * (y[m][c] - mean[c]) * invstd[c]   (raw sums) */
+int mi_bn_bwd_colsums(const void* g_bf16, const void* y_bf16, const float* mean, const float* invstd, long M, int C, float* dbeta,
+                      float* dgamma, void* workspace, size_t workspace_bytes, void* stream);
+/* dy = gamma * invstd * (g - dbeta * inv_count - xhat * dgamma * inv_count), xhat = (y - mean) * invstd; inv_count = 1 / (pixels over all
+ * ranks that shared the statistics) */
+int mi_bn_bwd_apply(const void* g_bf16, const void* y_bf16, const float* mean, const float* invstd, const float* gamma, const float* dbeta,
+                    const float* dgamma, float inv_count, void* dy_bf16, long M, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,13 +7,13 @@ import ctypes
 import os
 
 import torch  # noqa: F401  (first: the process must bind torch's bundled HIP runtime, not a second copy)
-from ctypes import c_char_p, c_float, c_int, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI355SEG_LIB") or os.path.join(_HERE, "libmi355seg.so")      # override: kernel experiments (tools/)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mi355seg.h")
 
-P, I, F, Z = c_void_p, c_int, c_float, c_size_t
+P, I, F, Z, L = c_void_p, c_int, c_float, c_size_t, c_long
 
 # name -> (restype, argtypes); mirrors include/mi355seg.h one to one (tests/test_cabi.py checks it)
 SIGNATURES = {
@@ -60,6 +60,11 @@ SIGNATURES = {
     "mi_allreduce_bucket": (I, [P, Z, I, I, P, P]),
     "mi_relu_mask": (I, [P, P, P, Z, I, P]),
     "mi_frozen_bn_fold": (I, [P, P, P, P, P, P, I, P]),
+    "mi_bn_workspace": (Z, [L, I]),
+    "mi_bn_colsum": (I, [P, P, L, I, P, P, Z, P]),
+    "mi_bn_apply": (I, [P, P, P, P, P, P, P, I, L, I, P]),
+    "mi_bn_bwd_colsums": (I, [P, P, P, P, L, I, P, P, P, Z, P]),
+    "mi_bn_bwd_apply": (I, [P, P, P, P, P, P, P, F, P, L, I, P]),
 }
 
 _lib = None

@@ -1,0 +1,239 @@
+// Trainable BatchNorm2d over NHWC bf16 activations [M][C] (M = B*H*W pixels): the kernels behind MODEL.FREEZE_BN=False
+// (reference core/models/feature_extractor.py:37-39 builds the backbone on torch.nn.BatchNorm2d then; core/components/resnet.py:84-113
+// applies it after every conv).  Per-channel reductions are deterministic two-level sums (up to 1024 workgroups each sum a
+// contiguous range of rows in a fixed lane order, one thread per channel then adds the partials in ascending order) and return RAW
+// sums: the host divides by the pixel count - after an all-reduce over ranks when the statistics are synchronised.
+//   mi_bn_colsum        s[c] = sum_m y[m][c]                         (mean == NULL)
+//                       s[c] = sum_m (y[m][c] - mean[c])^2           (two-pass variance: no cancellation)
+//   mi_bn_apply         out = relu?((y - mean) * scale + beta (+ res)), optional packed sign bits   scale = gamma * invstd
+//   mi_bn_bwd_colsums   dbeta[c] = sum_m g[m][c],   dgamma[c] = sum_m g[m][c] * (y[m][c] - mean[c]) * invstd[c]
+//   mi_bn_bwd_apply     dy = gamma * invstd * (g - dbeta * inv_count - xhat * dgamma * inv_count)
+// All arithmetic in fp32; bf16 only in memory.  Bound: HBM (each kernel is one or two streaming passes).
+#include "mi_common.h"
+
+namespace {
+
+constexpr int BN_MAX_BLOCKS = 1024;
+
+// MODE 0: sum y   1: sum (y - mean)^2   2: sum g and sum g * xhat.  A thread owns 8 consecutive channels (one 16-byte load per row).
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const bf16x8* __restrict__ y, const bf16x8* __restrict__ g, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, float* __restrict__ partial, long M, int slots, int cp,
+                                                         long rows_per_block) {
+    constexpr int NP = MODE == 2 ? 2 : 1;
+    __shared__ float red[256 * 8];
+    const int slot = threadIdx.x % cp, rl = threadIdx.x / cp, lanes = 256 / cp;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float a0[8], a1[8], mu[8], is[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a0[e] = a1[e] = mu[e] = 0.f, is[e] = 1.f;
+    if (slot < slots) {
+        if (MODE >= 1)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mu[e] = mean[slot * 8 + e];
+        if (MODE == 2)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) is[e] = invstd[slot * 8 + e];
+        for (long r = r0 + rl; r < r1; r += lanes) {
+            const bf16x8 v = y[r * slots + slot];
+            if (MODE == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a0[e] += (float)v[e];
+            } else if (MODE == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = (float)v[e] - mu[e];
+                    a0[e] += d * d;
+                }
+            } else {
+                const bf16x8 gv = g[r * slots + slot];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float ge = (float)gv[e];
+                    a0[e] += ge;
+                    a1[e] += ge * (((float)v[e] - mu[e]) * is[e]);
+                }
+            }
+        }
+    }
+    const int C = slots * 8;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        if (p) __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = p ? a1[e] : a0[e];
+        __syncthreads();
+        if (rl == 0 && slot < slots) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float s = 0.f;
+                for (int q = 0; q < lanes; ++q) s += red[(q * cp + slot) * 8 + e];
+                partial[((long)blockIdx.x * NP + p) * C + slot * 8 + e] = s;
+            }
+        }
+    }
+}
+
+// 8 channels per workgroup, 32 lanes per channel: lane q adds partials q, q+32, ... ascending; lane 0 adds the 32 lane sums ascending
+__global__ __launch_bounds__(256) void bn_final_kernel(const float* __restrict__ partial, int nblocks, int C, int nplanes, float* __restrict__ out0,
+                                                       float* __restrict__ out1) {
+    __shared__ float red[32][8];
+    const int c = threadIdx.x & 7, q = threadIdx.x >> 3;
+    const int n = blockIdx.x * 8 + c;
+    for (int p = 0; p < nplanes; ++p) {
+        float s = 0.f;
+        if (n < C)
+            for (int b = q; b < nblocks; b += 32) s += partial[((long)b * nplanes + p) * C + n];
+        if (p) __syncthreads();
+        red[q][c] = s;
+        __syncthreads();
+        if (q == 0 && n < C) {
+            float t = 0.f;
+            for (int k = 0; k < 32; ++k) t += red[k][c];
+            (p ? out1 : out0)[n] = t;
+        }
+    }
+}
+
+template <bool RELU, bool RES, bool BITS>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const bf16x8* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ scale,
+                                                       const float* __restrict__ beta, const bf16x8* __restrict__ res, bf16x8* __restrict__ out,
+                                                       uint8_t* __restrict__ bits, long n8, int slots) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n8) return;
+    const int slot = (int)(idx % slots);
+    const bf16x8 v = y[idx];
+    bf16x8 r;
+    if (RES) r = res[idx];
+    bf16x8 o;
+    unsigned m = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = slot * 8 + e;
+        float t = ((float)v[e] - mean[c]) * scale[c] + beta[c];
+        if (RES) t += (float)r[e];
+        if (RELU) t = fmaxf(t, 0.f);
+        o[e] = (__bf16)t;
+        m |= (unsigned)((float)o[e] > 0.f) << e;
+    }
+    out[idx] = o;
+    if (BITS) bits[idx] = (uint8_t)m;          // byte idx = channels 8*slot .. 8*slot+7 of the row: the uint16-per-16-channels layout of the convs
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16x8* __restrict__ g, const bf16x8* __restrict__ y, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ dbeta, const float* __restrict__ dgamma, float inv_count,
+                                                           bf16x8* __restrict__ dy, long n8, int slots) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n8) return;
+    const int slot = (int)(idx % slots);
+    const bf16x8 gv = g[idx], v = y[idx];
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = slot * 8 + e;
+        const float xhat = ((float)v[e] - mean[c]) * invstd[c];
+        o[e] = (__bf16)(gamma[c] * invstd[c] * ((float)gv[e] - dbeta[c] * inv_count - xhat * dgamma[c] * inv_count));
+    }
+    dy[idx] = o;
+}
+
+inline int pow2_at_least(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+struct Plan { int slots, cp, nblocks; long rows_per_block; };
+
+inline Plan bn_plan(long M, int C) {
+    Plan p;
+    p.slots = C / 8;
+    p.cp = pow2_at_least(p.slots);
+    const int lanes = 256 / p.cp;
+    long rpb = (M + BN_MAX_BLOCKS - 1) / BN_MAX_BLOCKS;
+    rpb = ((rpb + lanes - 1) / lanes) * lanes;
+    if (rpb < lanes) rpb = lanes;
+    p.rows_per_block = rpb;
+    p.nblocks = (int)((M + rpb - 1) / rpb);
+    return p;
+}
+
+}  // namespace
+
+extern "C" size_t mi_bn_workspace(long M, int C) {
+    (void)M;
+    return (size_t)BN_MAX_BLOCKS * 2 * (size_t)C * sizeof(float);
+}
+
+#define BN_COMMON_CHECKS(who)                                                                                      \
+    MI_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= 2048, who ": M=%ld, C=%d (C a multiple of 8, at most 2048)", M, C); \
+    MI_REQUIRE(workspace && workspace_bytes >= mi_bn_workspace(M, C), who ": workspace too small");
+
+extern "C" int mi_bn_colsum(const void* y_bf16, const float* mean, long M, int C, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    MI_REQUIRE(y_bf16 && out && mi_aligned16(y_bf16), "mi_bn_colsum: null or unaligned operand");
+    BN_COMMON_CHECKS("mi_bn_colsum")
+    const Plan p = bn_plan(M, C);
+    float* partial = (float*)workspace;
+    if (mean)
+        hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(p.nblocks), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)y_bf16, (const bf16x8*)nullptr, mean,
+                           (const float*)nullptr, partial, M, p.slots, p.cp, p.rows_per_block);
+    else
+        hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(p.nblocks), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)y_bf16, (const bf16x8*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, partial, M, p.slots, p.cp, p.rows_per_block);
+    hipLaunchKernelGGL(bn_final_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, partial, p.nblocks, C, 1, out, (float*)nullptr);
+    MI_CHECK_LAUNCH("mi_bn_colsum");
+    return MI_OK;
+}
+
+extern "C" int mi_bn_bwd_colsums(const void* g_bf16, const void* y_bf16, const float* mean, const float* invstd, long M, int C, float* dbeta,
+                                 float* dgamma, void* workspace, size_t workspace_bytes, void* stream) {
+    MI_REQUIRE(g_bf16 && y_bf16 && mean && invstd && dbeta && dgamma && mi_aligned16(g_bf16) && mi_aligned16(y_bf16), "mi_bn_bwd_colsums: null or unaligned operand");
+    BN_COMMON_CHECKS("mi_bn_bwd_colsums")
+    const Plan p = bn_plan(M, C);
+    float* partial = (float*)workspace;
+    hipLaunchKernelGGL(bn_partial_kernel<2>, dim3(p.nblocks), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)y_bf16, (const bf16x8*)g_bf16, mean, invstd,
+                       partial, M, p.slots, p.cp, p.rows_per_block);
+    hipLaunchKernelGGL(bn_final_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, partial, p.nblocks, C, 2, dbeta, dgamma);
+    MI_CHECK_LAUNCH("mi_bn_bwd_colsums");
+    return MI_OK;
+}
+
+extern "C" int mi_bn_apply(const void* y_bf16, const float* mean, const float* scale, const float* beta, const void* res_bf16, void* out_bf16,
+                           void* mask_out, int relu, long M, int C, void* stream) {
+    MI_REQUIRE(y_bf16 && mean && scale && beta && out_bf16 && mi_aligned16(y_bf16) && mi_aligned16(out_bf16), "mi_bn_apply: null or unaligned operand");
+    MI_REQUIRE(M > 0 && C > 0 && C % 8 == 0, "mi_bn_apply: M=%ld, C=%d (C a multiple of 8)", M, C);
+    MI_REQUIRE(!res_bf16 || mi_aligned16(res_bf16), "mi_bn_apply: residual alignment");
+    MI_REQUIRE(!mask_out || C % 16 == 0, "mi_bn_apply: sign bits need C %% 16 == 0");
+    const long n8 = M * (C / 8);
+    const dim3 grid((unsigned)((n8 + 255) / 256));
+#define BN_GO(R, S, B)                                                                                                                         \
+    hipLaunchKernelGGL((bn_apply_kernel<R, S, B>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16x8*)y_bf16, mean, scale, beta, (const bf16x8*)res_bf16, \
+                       (bf16x8*)out_bf16, (uint8_t*)mask_out, n8, C / 8)
+    const int sel = (relu ? 4 : 0) | (res_bf16 ? 2 : 0) | (mask_out ? 1 : 0);
+    switch (sel) {
+        case 0: BN_GO(false, false, false); break;
+        case 1: BN_GO(false, false, true); break;
+        case 2: BN_GO(false, true, false); break;
+        case 3: BN_GO(false, true, true); break;
+        case 4: BN_GO(true, false, false); break;
+        case 5: BN_GO(true, false, true); break;
+        case 6: BN_GO(true, true, false); break;
+        default: BN_GO(true, true, true); break;
+    }
+#undef BN_GO
+    MI_CHECK_LAUNCH("mi_bn_apply");
+    return MI_OK;
+}
+
+extern "C" int mi_bn_bwd_apply(const void* g_bf16, const void* y_bf16, const float* mean, const float* invstd, const float* gamma, const float* dbeta,
+                               const float* dgamma, float inv_count, void* dy_bf16, long M, int C, void* stream) {
+    MI_REQUIRE(g_bf16 && y_bf16 && mean && invstd && gamma && dbeta && dgamma && dy_bf16, "mi_bn_bwd_apply: null operand");
+    MI_REQUIRE(mi_aligned16(g_bf16) && mi_aligned16(y_bf16) && mi_aligned16(dy_bf16), "mi_bn_bwd_apply: alignment");
+    MI_REQUIRE(M > 0 && C > 0 && C % 8 == 0, "mi_bn_bwd_apply: M=%ld, C=%d (C a multiple of 8)", M, C);
+    const long n8 = M * (C / 8);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)g_bf16,
+                       (const bf16x8*)y_bf16, mean, invstd, gamma, dbeta, dgamma, inv_count, (bf16x8*)dy_bf16, n8, C / 8);
+    MI_CHECK_LAUNCH("mi_bn_bwd_apply");
+    return MI_OK;
+}

@@ -405,6 +405,68 @@ def frozen_bn_fold(w, b, mean, var):
     return scale, shift
 
 
+# ---------------------------------------------------------------------------------------------- trainable BatchNorm2d (NHWC bf16)
+_bn_ws = {}
+
+
+def _bn_workspace(dev, M, C):
+    need = int(_lib.lib().mi_bn_workspace(M, C))
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    w = _bn_ws.get(key)
+    if w is None or w.numel() < need:
+        w = _bn_ws[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+    return w
+
+
+def bn_colsum(y, mean=None):
+    """Raw per-channel sums over the pixels of a bf16 NHWC tensor: sum y, or sum (y - mean)^2 when `mean` is given."""
+    _chk(y, torch.bfloat16, "y")
+    C = y.shape[-1]
+    M = y.numel() // C
+    out = torch.empty(C, dtype=torch.float32, device=y.device)
+    ws = _bn_workspace(y.device, M, C)
+    _timed("bn_kernels", 0.0, lambda: check(_lib.lib().mi_bn_colsum(_p(y), _p(mean), M, C, _p(out), _p(ws), ws.numel(), _stream()), "mi_bn_colsum"),
+           ("bn", 0, C, C, M, 0, 0))
+    return out
+
+
+def bn_apply(y, mean, scale, beta, res=None, relu=False, want_mask=False):
+    """relu?((y - mean) * scale + beta (+ res)) as bf16 NHWC (+ packed sign bits)."""
+    _chk(y, torch.bfloat16, "y")
+    C = y.shape[-1]
+    M = y.numel() // C
+    out = torch.empty_like(y)
+    bits = torch.empty(y.shape[:-1] + (C // 16,), dtype=torch.int16, device=y.device) if want_mask else None
+    _timed("bn_kernels", 0.0, lambda: check(_lib.lib().mi_bn_apply(_p(y), _p(mean), _p(scale), _p(beta), _p(res), _p(out), _p(bits), int(relu), M, C,
+                                                                   _stream()), "mi_bn_apply"), ("bn", 1, C, C, M, 0, 0))
+    return (out, bits) if want_mask else out
+
+
+def bn_bwd_colsums(g, y, mean, invstd):
+    """Raw (sum g, sum g * xhat) per channel."""
+    _chk(g, torch.bfloat16, "g")
+    _chk(y, torch.bfloat16, "y")
+    C = y.shape[-1]
+    M = y.numel() // C
+    dbeta = torch.empty(C, dtype=torch.float32, device=y.device)
+    dgamma = torch.empty_like(dbeta)
+    ws = _bn_workspace(y.device, M, C)
+    _timed("bn_kernels", 0.0, lambda: check(_lib.lib().mi_bn_bwd_colsums(_p(g), _p(y), _p(mean), _p(invstd), M, C, _p(dbeta), _p(dgamma), _p(ws),
+                                                                         ws.numel(), _stream()), "mi_bn_bwd_colsums"), ("bn", 2, C, C, M, 0, 0))
+    return dbeta, dgamma
+
+
+def bn_bwd_apply(g, y, mean, invstd, gamma, dbeta, dgamma, count):
+    """dy of BatchNorm given the (possibly all-reduced) raw sums and the pixel count they were taken over."""
+    C = y.shape[-1]
+    M = y.numel() // C
+    dy = torch.empty_like(y)
+    _timed("bn_kernels", 0.0, lambda: check(_lib.lib().mi_bn_bwd_apply(_p(g), _p(y), _p(mean), _p(invstd), _p(gamma), _p(dbeta), _p(dgamma),
+                                                                       ctypes.c_float(1.0 / count), _p(dy), M, C, _stream()), "mi_bn_bwd_apply"),
+           ("bn", 3, C, C, M, 0, 0))
+    return dy
+
+
 # ---------------------------------------------------------------------------------------------- exact-fp32 evaluation path
 def pack_weight_f32(w, out=None):
     """fp32 OIHW -> fp32 [k*k][O][I] (a free view for 1x1)."""
