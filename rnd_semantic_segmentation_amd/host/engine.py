@@ -153,6 +153,18 @@ class _Lanes:
         return cls._by_device[key]
 
 
+def bn_fold(bn):
+    """(scale, shift) of a normalisation layer evaluated on its stored statistics: FrozenBatchNorm2d (layers.py:18-20, no eps) or an
+    nn.BatchNorm2d in eval mode (scale = gamma * rsqrt(running_var + eps))."""
+    eps = float(getattr(bn, "eps", 0.0) or 0.0)
+    var = bn.running_var if eps == 0.0 else bn.running_var + eps
+    return K.frozen_bn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, var)
+
+
+def bn_versions(bn):
+    return bn.weight._version + bn.bias._version + bn.running_mean._version + bn.running_var._version
+
+
 # ------------------------------------------------------------------------------------------------ backbone stages
 class _ConvRT:
     __slots__ = ("spec", "weight", "bn", "scale", "shift", "wp", "wpt")
@@ -178,6 +190,7 @@ class StageEngine:
         self._bn_sig = None
         self._pack_sig = None
         self._have_dgrad = False
+        self.batch_stats = False               # True: trainable BatchNorm2d in train(): no fold, unscaled data-gradient operands
 
     # -- preparation: FrozenBN folds and bf16 operand packs, redone only when their sources changed
     def _signature(self):
@@ -208,6 +221,7 @@ class StageEngine:
             blk += -(-c.cout // 32) * -(-c.cin // 128)        # one block per 32 (o) x 128 (i) channels
         self._pack_blocks = blk
         self._table_train = torch.tensor(rows, dtype=torch.int64, device=dev)
+        self._table_batch = torch.tensor([r[:1] + [-1] + r[2:] for r in rows], dtype=torch.int64, device=dev)     # no folded scale
         for r in rows:
             r[3] = -1
         self._table_eval = torch.tensor(rows, dtype=torch.int64, device=dev)
@@ -220,19 +234,20 @@ class StageEngine:
         if getattr(self, "_plan_store", None) is not store:
             self._build_pack_plan(store)
             self._bn_sig = self._pack_sig = None
-        bn_sig = sum(b._version for rt in self.convs for b in (rt.bn.weight, rt.bn.bias, rt.bn.running_mean, rt.bn.running_var))
-        bn_sig = (bn_sig, self.convs[0].bn.weight.data_ptr())
-        refold = bn_sig != self._bn_sig
-        if refold:
-            for rt in self.convs:
-                sc, sh = K.frozen_bn_fold(rt.bn.weight, rt.bn.bias, rt.bn.running_mean, rt.bn.running_var)
-                rt.scale.copy_(sc)
-                rt.shift.copy_(sh)
-            self._bn_sig = bn_sig
-        sig = self._signature()
+        refold = False
+        if not self.batch_stats:
+            bn_sig = (sum(bn_versions(rt.bn) for rt in self.convs), self.convs[0].bn.weight.data_ptr())
+            refold = bn_sig != self._bn_sig
+            if refold:
+                for rt in self.convs:
+                    sc, sh = bn_fold(rt.bn)
+                    rt.scale.copy_(sc)
+                    rt.shift.copy_(sh)
+                self._bn_sig = bn_sig
+        sig = self._signature() + (self.batch_stats,)
         if sig != self._pack_sig or refold or (train and not self._have_dgrad):
-            K.pack_weights_multi(store.data, self._scale_flat, self._wp_flat, self._wpt_flat,
-                                 self._table_train if train else self._table_eval, len(self.convs), self._pack_blocks)
+            table = self._table_batch if self.batch_stats else (self._table_train if train else self._table_eval)
+            K.pack_weights_multi(store.data, self._scale_flat, self._wp_flat, self._wpt_flat, table, len(self.convs), self._pack_blocks)
             self._pack_sig = sig
             self._have_dgrad = train
 
@@ -369,6 +384,120 @@ class StageEngine:
         return g
 
 
+
+# ------------------------------------------------------------------------------------------------ trainable BatchNorm2d (MODEL.FREEZE_BN=False)
+def _bn_allreduce(bn, *tensors):
+    """SyncBatchNorm semantics (train_distill.py:53): the raw per-channel sums of every rank are added; returns the number of ranks
+    that contributed (1 when the layer is not synchronised)."""
+    import torch.distributed as dist
+    if not getattr(bn, "_mi_sync", False) or not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return 1
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    dist.all_reduce(flat)
+    off = 0
+    for t in tensors:
+        t.copy_(flat[off:off + t.numel()].view_as(t))
+        off += t.numel()
+    return dist.get_world_size()
+
+
+class ConvFn(torch.autograd.Function):
+    """One conv of the backbone without an epilogue (its BatchNorm needs the raw output): NHWC bf16 in / out through the same
+    implicit-GEMM kernels as the FrozenBN schedule; the weight gradient is written into the parameter's gradient slot."""
+
+    @staticmethod
+    def forward(ctx, x, weight, rt):
+        c = rt.spec
+        y = K.conv_gemm(x, rt.wp, arch.out_hw(x.shape[1], x.shape[2], c), c.k, c.stride, c.pad, c.dil, K.GATHER_FWD)
+        ctx.rt = rt
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        rt = ctx.rt
+        c = rt.spec
+        dy = dy.contiguous()
+        dw, acc = grad_slot(rt.weight)
+        K.conv_wgrad(dy, x, dw, c.k, c.stride, c.pad, c.dil, accumulate=acc)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = K.conv_gemm(dy, rt.wpt, (x.shape[1], x.shape[2]), c.k, c.stride, c.pad, c.dil, K.GATHER_DGRAD)
+        return dx, None, None
+
+
+class BnActFn(torch.autograd.Function):
+    """relu?(BatchNorm2d(y) (+ res)) on batch statistics (torch.nn.BatchNorm2d in train(): biased variance for the normalisation,
+    unbiased for running_var, momentum 0.1, eps 1e-5 - resnet.py:84-113 with feature_extractor.py:37), NHWC bf16.  The affine
+    gradients go into the parameters' gradient slots."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, bn, res, relu):
+        C = y.shape[-1]
+        M = y.numel() // C
+        s = K.bn_colsum(y)
+        ranks = _bn_allreduce(bn, s)
+        count = M * ranks
+        mean = s / count
+        v = K.bn_colsum(y, mean)
+        _bn_allreduce(bn, v)
+        var = v / count
+        invstd = torch.rsqrt(var + bn.eps)
+        if relu:
+            out, bits = K.bn_apply(y, mean, gamma.detach() * invstd, beta.detach(), res=res, relu=True, want_mask=True)
+        else:
+            out, bits = K.bn_apply(y, mean, gamma.detach() * invstd, beta.detach(), res=res, relu=False), None
+        if bn.track_running_stats and bn.running_mean is not None:
+            if bn.momentum is None:
+                raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative average) is not used by the reference")
+            m = float(bn.momentum)
+            with torch.no_grad():
+                bn.running_mean.mul_(1.0 - m).add_(mean, alpha=m)
+                bn.running_var.mul_(1.0 - m).add_(var, alpha=m * count / max(count - 1, 1))
+                bn.num_batches_tracked += 1
+        ctx.bn, ctx.count, ctx.relu, ctx.has_res = bn, count, relu, res is not None
+        ctx.save_for_backward(y, mean, invstd, bits, gamma.detach())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        y, mean, invstd, bits, gamma = ctx.saved_tensors
+        bn = ctx.bn
+        g = g.contiguous()
+        if ctx.relu:
+            g = K.relu_mask(g, bits)
+        dbeta, dgamma = K.bn_bwd_colsums(g, y, mean, invstd)
+        for p, d in ((bn.weight, dgamma), (bn.bias, dbeta)):        # this rank's sums: what SyncBatchNorm hands DDP as well
+            slot, acc = grad_slot(p)
+            slot.add_(d) if acc else slot.copy_(d)
+        if getattr(bn, "_mi_sync", False):
+            dbeta, dgamma = dbeta.clone(), dgamma.clone()
+            _bn_allreduce(bn, dbeta, dgamma)
+        dy = K.bn_bwd_apply(g, y, mean, invstd, gamma, dbeta, dgamma, ctx.count)
+        return dy, None, None, None, (g if ctx.has_res else None), None
+
+
+def batchnorm_stages(x, eng):
+    """layer1..layer4 with trainable BatchNorm2d on batch statistics: the graph of resnet.py:93-113 composed from ConvFn / BnActFn
+    (torch autograd orders the backward; the FrozenBN schedule's fused epilogues and hand-written backward do not apply)."""
+    for blk, rts in eng.blocks:
+        def unit(inp, rt, res, relu):
+            return BnActFn.apply(ConvFn.apply(inp, rt.weight, rt), rt.bn.weight, rt.bn.bias, rt.bn, res, relu)
+        a1 = unit(x, rts[0], None, True)
+        a2 = unit(a1, rts[1], None, True)
+        idn = unit(x, rts[3], None, False) if blk.down else x
+        x = unit(a2, rts[2], idn, True)
+    return x
+
+
+def batchnorm_stem(x, conv_weight, bn):
+    """7x7/2 conv (PyTorch-ROCm library op) -> BatchNorm2d on batch statistics + ReLU (HIP) -> 3x3/2 max-pool."""
+    y = torch.nn.functional.conv2d(x, conv_weight.to(torch.bfloat16), None, 2, 3)
+    a = BnActFn.apply(y.permute(0, 2, 3, 1).contiguous(), bn.weight, bn.bias, bn, None, True)
+    p = torch.nn.functional.max_pool2d(a.permute(0, 3, 1, 2), 3, 2, 1)
+    return p.permute(0, 2, 3, 1).contiguous()
+
 # ------------------------------------------------------------------------------------------------ exact-fp32 evaluation
 class Fp32Backbone:
     """Forward-only fp32 schedule of stem + layer1..layer4 for evaluation (test.py / ASPPTester): fp32 NHWC activations,
@@ -393,8 +522,7 @@ class Fp32Backbone:
         bb = self.owner.backbone
         self._packs = {}
 
-        def fold(bn):
-            return K.frozen_bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        fold = bn_fold
 
         self._stem = (bb.conv1.weight.detach().contiguous(),) + fold(bb.bn1)
         for blk in self.plan:

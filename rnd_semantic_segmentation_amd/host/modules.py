@@ -55,10 +55,9 @@ class resnet_feature_extractor(nn.Module):
     def __init__(self, backbone_name, pretrained_weights=None, aux=False, pretrained_backbone=True, freeze_bn=False,
                  layers=None):
         super().__init__()
-        if not freeze_bn:
-            raise NotImplementedError(
-                "MODEL.FREEZE_BN=False (trainable BatchNorm2d / SyncBN) is outside the round-1 hot path; "
-                "configs/deeplabv2_r101_src.yaml uses FREEZE_BN: True")
+        # feature_extractor.py:37-39: FrozenBatchNorm2d when MODEL.FREEZE_BN, torch.nn.BatchNorm2d otherwise (624 state keys / 312
+        # parameter tensors for resnet101; batch statistics in train(), running statistics in eval())
+        self.freeze_bn = bool(freeze_bn)
         if aux:
             raise NotImplementedError("aux (layer3) output is not used by any DeepLab config")
         if layers is None:
@@ -94,7 +93,7 @@ class resnet_feature_extractor(nn.Module):
         node.weight = nn.Parameter(w)
         parent, leaf = c.bn.rsplit(".", 1) if "." in c.bn else ("", c.bn)
         holder = arch.node_at(self.backbone, parent) if parent else self.backbone
-        holder.add_module(leaf, FrozenBatchNorm2d(c.cout))
+        holder.add_module(leaf, FrozenBatchNorm2d(c.cout) if self.freeze_bn else nn.BatchNorm2d(c.cout))
 
     def _load_pretrained(self, src):
         """MODEL.WEIGHTS (resnet.py:211-215 uses mmcv.load_checkpoint on a URL).  There is no network here:
@@ -124,12 +123,19 @@ class resnet_feature_extractor(nn.Module):
 
     def _stem_fold(self):
         bn = self.backbone.bn1
-        sig = (bn.weight._version + bn.bias._version + bn.running_mean._version + bn.running_var._version, bn.weight.data_ptr())
+        sig = (engine.bn_versions(bn), bn.weight.data_ptr())
         if getattr(self, "_stem_sig", None) != sig:
-            from .. import kernels
-            self._stem_scale, self._stem_shift = kernels.frozen_bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var)
+            self._stem_scale, self._stem_shift = engine.bn_fold(bn)
             self._stem_sig = sig
         return self._stem_scale, self._stem_shift
+
+    def sync_batchnorm(self, on=True):
+        """train_distill.py:53 (SyncBatchNorm.convert_sync_batchnorm): with MODEL.FREEZE_BN=False every BatchNorm2d of the backbone
+        exchanges its raw batch sums over torch.distributed's default group."""
+        for m in self.backbone.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m._mi_sync = bool(on)
+        return self
 
     def forward(self, x):
         _require_gpu(x, "resnet_feature_extractor")
@@ -140,8 +146,14 @@ class resnet_feature_extractor(nn.Module):
             return self._fp32.forward(x.float()).permute(0, 3, 1, 2)        # NCHW-shaped view of NHWC fp32 memory
         self.ensure_flat()
         bb = self.backbone
-        # stem: 7x7/2 conv on the PyTorch-ROCm library (A6), then FrozenBN + ReLU + 3x3/2 max-pool in one HIP kernel
         xb = x.to(dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        self._engine.batch_stats = (not self.freeze_bn) and self.training
+        if self._engine.batch_stats:
+            # trainable BatchNorm2d in train(): batch statistics, composed from ConvFn / BnActFn (engine.batchnorm_stages)
+            self._engine.prepare(True)
+            y = engine.batchnorm_stem(xb, bb.conv1.weight, bb.bn1)
+            return engine.batchnorm_stages(y, self._engine).permute(0, 3, 1, 2)
+        # stem: 7x7/2 conv on the PyTorch-ROCm library (A6), then FrozenBN + ReLU + 3x3/2 max-pool in one HIP kernel
         scale, shift = self._stem_fold()
         y = engine.StemFn.apply(xb, bb.conv1.weight, scale, shift)                       # [B,Hp,Wp,64] bf16 NHWC
         weights = [rt.weight for rt in self._engine.convs]

@@ -56,6 +56,8 @@ class ASPPTrainer(BaseTrainer):
             stores = [m.ensure_flat() if hasattr(m, "ensure_flat") else _cpu_store(m) for m in (self.classifier, self.feature_extractor)]
             self.reducer = ddp.GradAllReducer(stores)
             self.reducer.broadcast_parameters(0)
+            if hasattr(self.feature_extractor, "sync_batchnorm") and not self.cfg.MODEL.FREEZE_BN:
+                self.feature_extractor.sync_batchnorm(True)          # train_distill.py:53 convert_sync_batchnorm
 
     @staticmethod
     def _ordered_params(module):
