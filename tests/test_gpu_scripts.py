@@ -56,6 +56,24 @@ def test_train_src_then_test_py_roundtrip(tmp_path):
     assert set(ck["optimizer_D"]["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
 
 
+def test_train_src_with_trainable_batchnorm_then_test_py(tmp_path):
+    """MODEL.FREEZE_BN False through the unchanged scripts: nn.BatchNorm2d backbone (624 state keys), batch statistics while training,
+    running statistics in test.py; the optimizer state covers the 312 backbone tensors."""
+    out = str(tmp_path / "run_bn")
+    r = run(["train_src.py", "-cfg", "configs/deeplabv2_r101_src.yaml", "OUTPUT_DIR", out, "SOLVER.EPOCHS", "1", "MODEL.FREEZE_BN", "False",
+             "SOLVER.BATCH_SIZE", "2", "INPUT.SOURCE_INPUT_SIZE_TRAIN", "(161, 129)"], {"MI_SYNTH_LEN": "6"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    chart = json.load(open(os.path.join(out, "aspp_chart_params.json")))
+    assert len(chart["loss"]) == 3 and all(0 < v < 10 for v in chart["loss"])
+    ck = torch.load(os.path.join(out, "Aspp-1.pth"), map_location="cpu")
+    assert len(ck["feature_extractor"]) == 624 and int(ck["feature_extractor"]["backbone.bn1.num_batches_tracked"]) == 3
+    assert len(ck["optimizer_fea"]["state"]) == 312
+    r = run(["test.py", "-cfg", "configs/deeplabv2_r101_src.yaml", "OUTPUT_DIR", out, "MODEL.FREEZE_BN", "False", "resume", os.path.join(out, "Aspp-1.pth"),
+             "INPUT.INPUT_SIZE_TEST", "(193, 97)"], {"MI_SYNTH_LEN": "2"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "Micro metric, val result: mIoU/mF1" in r.stderr + r.stdout
+
+
 def test_bench_under_torchrun_nccl_single_rank_exercises_the_reducer():
     """The data-parallel code path (RCCL process group, bucketed all-reduce on a side HIP stream behind events, barrier,
     max-over-ranks timing) on the one GPU available: a single-rank `nccl` job with MI_DDP_FORCE=1 issues every collective."""

@@ -96,8 +96,10 @@ def test_product_refuses_cpu_and_unbuilt_variants():
     cls = modules.ASPP_Classifier_V2(2048, [6, 12, 18, 24], [6, 12, 18, 24], 19)
     with pytest.raises(_lib.MiError, match="MI355X only"):
         cls(torch.zeros(1, 2048, 5, 5))
-    with pytest.raises(NotImplementedError, match="FREEZE_BN"):
-        modules.resnet_feature_extractor("resnet101", freeze_bn=False)
+    bn = modules.resnet_feature_extractor("resnet101", freeze_bn=False, pretrained_backbone=False, layers=(1, 1, 1, 1))     # MODEL.FREEZE_BN=False
+    assert isinstance(bn.backbone.bn1, torch.nn.BatchNorm2d) and "backbone.bn1.num_batches_tracked" in bn.state_dict()
+    with pytest.raises(_lib.MiError, match="MI355X only"):
+        bn(torch.zeros(2, 3, 33, 33))
     with pytest.raises(NotImplementedError):
         modules.ASPP_Classifier_V2(2048, [6, 12, 18, 24], [1, 1, 1, 1], 19)
     fe2 = modules.resnet_feature_extractor("resnet101", pretrained_weights="https://example.invalid/r101.pth", freeze_bn=True,
