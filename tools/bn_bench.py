@@ -1,0 +1,36 @@
+"""Training step with MODEL.FREEZE_BN False (trainable BatchNorm2d, batch statistics) at the BASELINE shape: ms/step and the share of
+the BatchNorm kernels.  usage: python tools/bn_bench.py [batch]"""
+import logging, os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from rnd_semantic_segmentation_amd import kernels
+from rnd_semantic_segmentation_amd.host import config as hc, synth
+from rnd_semantic_segmentation_amd.host.trainer import ASPPTrainer
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+cfg = hc.CfgNode(hc.default_tree()); cfg.merge_from_file(os.path.join(bench.ROOT, "configs", "deeplabv2_r101_src.yaml"))
+cfg.merge_from_list(["MODEL.FREEZE_BN", "False"]); cfg.freeze()
+tr = ASPPTrainer("aspp", cfg, [None] * 1000, 0, logger=logging.getLogger("x"))
+with torch.no_grad():
+    for m in (tr.feature_extractor, tr.classifier):
+        synth.load_formula_weights(m); m._store.generation += 1
+tr.feature_extractor.train(); tr.classifier.train()
+x, lab = bench.synthetic_batch(B, 769, 0, torch.device("cuda"))
+for i in range(4):
+    loss, _ = tr.train_step(x, lab, 100000); tr.iteration += 1
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+N = 10
+for i in range(N):
+    loss, _ = tr.train_step(x, lab, 100000); tr.iteration += 1
+torch.cuda.synchronize()
+ms = 1e3 * (time.perf_counter() - t0) / N
+events = []
+kernels.PROFILE = events
+tr.train_step(x, lab, 100000)
+kernels.PROFILE = None
+torch.cuda.synchronize()
+by = {}
+for name, e0, e1, fl, tag in events:
+    by[name] = by.get(name, 0.0) + e0.elapsed_time(e1)
+print("FREEZE_BN False, B=%d 769x769: %.1f ms/step = %.1f images/s, loss %.4f, reserved %.1f GB" % (B, ms, B * 1e3 / ms, float(loss), torch.cuda.memory_reserved() / 2**30))
+print("one instrumented step (single stream), ms per kernel group:", {k: round(v, 2) for k, v in sorted(by.items(), key=lambda kv: -kv[1])})
