@@ -250,17 +250,21 @@ int mi_frozen_bn_fold(const float* w, const float* b, const float* mean, const f
 size_t mi_bn_workspace(long M, int C);
 /* out[c] = sum_m y[m][c] (mean == NULL) or sum_m (y[m][c] - mean[c])^2 (two-pass variance) */
 int mi_bn_colsum(const void* y_bf16, const float* mean, long M, int C, float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* one pass: s1[c] = sum_m (y[m][c] - pilot[c]), s2[c] = sum_m (y[m][c] - pilot[c])^2; mean = pilot + s1/N, var = s2/N - (s1/N)^2.  The pilot
+ * must be the same on every rank that shares the statistics (the running mean is). */
+int mi_bn_colsum2(const void* y_bf16, const float* pilot, long M, int C, float* s1, float* s2, void* workspace, size_t workspace_bytes, void* stream);
 /* out = relu?((y - mean[c]) * scale[c] + beta[c] (+ res)), scale = gamma * rsqrt(var + eps); mask_out (optional, C % 16 == 0): the
  * packed sign bits of out in the layout of MI_EPI_WRITE_MASK */
 int mi_bn_apply(const void* y_bf16, const float* mean, const float* scale, const float* beta, const void* res_bf16, void* out_bf16,
                 void* mask_out, int relu, long M, int C, void* stream);
-/* dbeta[c] = sum_m g[m][c], dgamma[c] = sum_m g[m][c] * (y[m][c] - mean[c]) * invstd[c]   (raw sums) */
-int mi_bn_bwd_colsums(const void* g_bf16, const void* y_bf16, const float* mean, const float* invstd, long M, int C, float* dbeta,
-                      float* dgamma, void* workspace, size_t workspace_bytes, void* stream);
+/* dbeta[c] = sum_m g[m][c], dgamma[c] = sum_m g[m][c] * (y[m][c] - mean[c]) * invstd[c]   (raw sums); relu_bits (optional, C % 16 == 0):
+ * the packed sign bits of the layer's output - g counts only where the bit is set (ReLU backward without a separate pass) */
+int mi_bn_bwd_colsums(const void* g_bf16, const void* y_bf16, const float* mean, const float* invstd, const void* relu_bits, long M, int C,
+                      float* dbeta, float* dgamma, void* workspace, size_t workspace_bytes, void* stream);
 /* dy = gamma * invstd * (g - dbeta * inv_count - xhat * dgamma * inv_count), xhat = (y - mean) * invstd; inv_count = 1 / (pixels over all
  * ranks that shared the statistics) */
 int mi_bn_bwd_apply(const void* g_bf16, const void* y_bf16, const float* mean, const float* invstd, const float* gamma, const float* dbeta,
-                    const float* dgamma, float inv_count, void* dy_bf16, long M, int C, void* stream);
+                    const float* dgamma, float inv_count, const void* relu_bits, void* dy_bf16, long M, int C, void* stream);
 
 #ifdef __cplusplus
 }

@@ -63,8 +63,9 @@ SIGNATURES = {
     "mi_bn_workspace": (Z, [L, I]),
     "mi_bn_colsum": (I, [P, P, L, I, P, P, Z, P]),
     "mi_bn_apply": (I, [P, P, P, P, P, P, P, I, L, I, P]),
-    "mi_bn_bwd_colsums": (I, [P, P, P, P, L, I, P, P, P, Z, P]),
-    "mi_bn_bwd_apply": (I, [P, P, P, P, P, P, P, F, P, L, I, P]),
+    "mi_bn_colsum2": (I, [P, P, L, I, P, P, P, Z, P]),
+    "mi_bn_bwd_colsums": (I, [P, P, P, P, P, L, I, P, P, P, Z, P]),
+    "mi_bn_bwd_apply": (I, [P, P, P, P, P, P, P, F, P, P, L, I, P]),
 }
 
 _lib = None

@@ -5,22 +5,27 @@
 // sums: the host divides by the pixel count - after an all-reduce over ranks when the statistics are synchronised.
 //   mi_bn_colsum        s[c] = sum_m y[m][c]                         (mean == NULL)
 //                       s[c] = sum_m (y[m][c] - mean[c])^2           (two-pass variance: no cancellation)
+//   mi_bn_colsum2       s1[c] = sum_m (y - pilot[c]), s2[c] = sum_m (y - pilot[c])^2 in ONE pass: mean = pilot + s1/N,
+//                       var = s2/N - (s1/N)^2; with the pilot near the mean (the running mean) the subtraction loses 2-3 of 24 bits
 //   mi_bn_apply         out = relu?((y - mean) * scale + beta (+ res)), optional packed sign bits   scale = gamma * invstd
-//   mi_bn_bwd_colsums   dbeta[c] = sum_m g[m][c],   dgamma[c] = sum_m g[m][c] * (y[m][c] - mean[c]) * invstd[c]
+//   mi_bn_bwd_colsums   dbeta[c] = sum_m g[m][c],   dgamma[c] = sum_m g[m][c] * (y[m][c] - mean[c]) * invstd[c]   (g optionally masked by the
+//                       packed ReLU sign bits of the layer's output: no separate mask pass)
 //   mi_bn_bwd_apply     dy = gamma * invstd * (g - dbeta * inv_count - xhat * dgamma * inv_count)
 // All arithmetic in fp32; bf16 only in memory.  Bound: HBM (each kernel is one or two streaming passes).
 #include "mi_common.h"
 
 namespace {
 
-constexpr int BN_MAX_BLOCKS = 1024;
+constexpr int BN_MAX_BLOCKS = 256;
 
-// MODE 0: sum y   1: sum (y - mean)^2   2: sum g and sum g * xhat.  A thread owns 8 consecutive channels (one 16-byte load per row).
+// MODE 0: sum y   1: sum (y - mean)^2   2: sum g and sum g * xhat (g masked by the packed ReLU sign bits when given)
+// 3: sum (y - pilot) and sum (y - pilot)^2 in ONE pass (`mean` carries the pilot).  A thread owns 8 consecutive channels (one 16-byte
+// load per row).
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const bf16x8* __restrict__ y, const bf16x8* __restrict__ g, const float* __restrict__ mean,
-                                                         const float* __restrict__ invstd, float* __restrict__ partial, long M, int slots, int cp,
-                                                         long rows_per_block) {
-    constexpr int NP = MODE == 2 ? 2 : 1;
+                                                         const float* __restrict__ invstd, const uint8_t* __restrict__ bits,
+                                                         float* __restrict__ partial, long M, int slots, int cp, long rows_per_block) {
+    constexpr int NP = MODE >= 2 ? 2 : 1;
     __shared__ float red[256 * 8];
     const int slot = threadIdx.x % cp, rl = threadIdx.x / cp, lanes = 256 / cp;
     const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
@@ -34,8 +39,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const bf16x8* __restric
         if (MODE == 2)
 #pragma unroll
             for (int e = 0; e < 8; ++e) is[e] = invstd[slot * 8 + e];
-        for (long r = r0 + rl; r < r1; r += lanes) {
-            const bf16x8 v = y[r * slots + slot];
+        auto row = [&](const bf16x8 v, const bf16x8 gv, unsigned keep) {
             if (MODE == 0) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) a0[e] += (float)v[e];
@@ -45,15 +49,43 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const bf16x8* __restric
                     const float d = (float)v[e] - mu[e];
                     a0[e] += d * d;
                 }
-            } else {
-                const bf16x8 gv = g[r * slots + slot];
+            } else if (MODE == 3) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float ge = (float)gv[e];
+                    const float d = (float)v[e] - mu[e];
+                    a0[e] += d;
+                    a1[e] += d * d;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float ge = ((keep >> e) & 1u) ? (float)gv[e] : 0.f;
                     a0[e] += ge;
                     a1[e] += ge * (((float)v[e] - mu[e]) * is[e]);
                 }
             }
+        };
+        // four rows per trip: the loads are issued together (a lone 16-byte load per trip leaves the kernel latency-bound), the
+        // additions keep the row order, so the sums do not depend on the unrolling
+        long r = r0 + rl;
+        for (; r + 3 * lanes < r1; r += 4 * lanes) {
+            bf16x8 v[4], gv[4];
+            unsigned keep[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long at = (r + (long)u * lanes) * slots + slot;
+                v[u] = y[at];
+                if (MODE == 2) gv[u] = g[at];
+                keep[u] = (MODE == 2 && bits) ? bits[at] : 0xffu;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) row(v[u], gv[u], keep[u]);
+        }
+        for (; r < r1; r += lanes) {
+            const long at = r * slots + slot;
+            bf16x8 gv;
+            if (MODE == 2) gv = g[at];
+            row(y[at], gv, (MODE == 2 && bits) ? bits[at] : 0xffu);
         }
     }
     const int C = slots * 8;
@@ -74,7 +106,9 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const bf16x8* __restric
     }
 }
 
-// 8 channels per workgroup, 32 lanes per channel: lane q adds partials q, q+32, ... ascending; lane 0 adds the 32 lane sums ascending
+// 8 channels per workgroup, 32 lanes per channel: lane q adds partials q, q+32, ... ascending; lane 0 adds the 32 lane sums ascending.
+// (64 channels x 4 lanes with coalesced rows was tried: 3x slower - 256 dependent additions per lane; the chain length, not the
+// access pattern, sets this kernel's time)
 __global__ __launch_bounds__(256) void bn_final_kernel(const float* __restrict__ partial, int nblocks, int C, int nplanes, float* __restrict__ out0,
                                                        float* __restrict__ out1) {
     __shared__ float red[32][8];
@@ -105,12 +139,18 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16x8* __restrict_
     const bf16x8 v = y[idx];
     bf16x8 r;
     if (RES) r = res[idx];
+    float pm[8], ps[8], pb[8];                     // this thread's 8 channels of each parameter: two 16-byte loads each
+    *reinterpret_cast<f32x4*>(pm) = reinterpret_cast<const f32x4*>(mean)[slot * 2];
+    *reinterpret_cast<f32x4*>(pm + 4) = reinterpret_cast<const f32x4*>(mean)[slot * 2 + 1];
+    *reinterpret_cast<f32x4*>(ps) = reinterpret_cast<const f32x4*>(scale)[slot * 2];
+    *reinterpret_cast<f32x4*>(ps + 4) = reinterpret_cast<const f32x4*>(scale)[slot * 2 + 1];
+    *reinterpret_cast<f32x4*>(pb) = reinterpret_cast<const f32x4*>(beta)[slot * 2];
+    *reinterpret_cast<f32x4*>(pb + 4) = reinterpret_cast<const f32x4*>(beta)[slot * 2 + 1];
     bf16x8 o;
     unsigned m = 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const int c = slot * 8 + e;
-        float t = ((float)v[e] - mean[c]) * scale[c] + beta[c];
+        float t = ((float)v[e] - pm[e]) * ps[e] + pb[e];
         if (RES) t += (float)r[e];
         if (RELU) t = fmaxf(t, 0.f);
         o[e] = (__bf16)t;
@@ -123,17 +163,28 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16x8* __restrict_
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16x8* __restrict__ g, const bf16x8* __restrict__ y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ dbeta, const float* __restrict__ dgamma, float inv_count,
-                                                           bf16x8* __restrict__ dy, long n8, int slots) {
+                                                           const uint8_t* __restrict__ bits, bf16x8* __restrict__ dy, long n8, int slots) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n8) return;
     const int slot = (int)(idx % slots);
     const bf16x8 gv = g[idx], v = y[idx];
+    const unsigned keep = bits ? bits[idx] : 0xffu;
+    float pm[8], pi[8], pg[8], pdb[8], pdg[8];
+#define BN_LOAD8(dst, src)                                                                \
+    *reinterpret_cast<f32x4*>(dst) = reinterpret_cast<const f32x4*>(src)[slot * 2];       \
+    *reinterpret_cast<f32x4*>(dst + 4) = reinterpret_cast<const f32x4*>(src)[slot * 2 + 1];
+    BN_LOAD8(pm, mean)
+    BN_LOAD8(pi, invstd)
+    BN_LOAD8(pg, gamma)
+    BN_LOAD8(pdb, dbeta)
+    BN_LOAD8(pdg, dgamma)
+#undef BN_LOAD8
     bf16x8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const int c = slot * 8 + e;
-        const float xhat = ((float)v[e] - mean[c]) * invstd[c];
-        o[e] = (__bf16)(gamma[c] * invstd[c] * ((float)gv[e] - dbeta[c] * inv_count - xhat * dgamma[c] * inv_count));
+        const float xhat = ((float)v[e] - pm[e]) * pi[e];
+        const float ge = ((keep >> e) & 1u) ? (float)gv[e] : 0.f;
+        o[e] = (__bf16)(pg[e] * pi[e] * (ge - pdb[e] * inv_count - xhat * pdg[e] * inv_count));
     }
     dy[idx] = o;
 }
@@ -177,23 +228,36 @@ extern "C" int mi_bn_colsum(const void* y_bf16, const float* mean, long M, int C
     float* partial = (float*)workspace;
     if (mean)
         hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(p.nblocks), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)y_bf16, (const bf16x8*)nullptr, mean,
-                           (const float*)nullptr, partial, M, p.slots, p.cp, p.rows_per_block);
+                           (const float*)nullptr, (const uint8_t*)nullptr, partial, M, p.slots, p.cp, p.rows_per_block);
     else
         hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(p.nblocks), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)y_bf16, (const bf16x8*)nullptr,
-                           (const float*)nullptr, (const float*)nullptr, partial, M, p.slots, p.cp, p.rows_per_block);
+                           (const float*)nullptr, (const float*)nullptr, (const uint8_t*)nullptr, partial, M, p.slots, p.cp, p.rows_per_block);
     hipLaunchKernelGGL(bn_final_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, partial, p.nblocks, C, 1, out, (float*)nullptr);
     MI_CHECK_LAUNCH("mi_bn_colsum");
     return MI_OK;
 }
 
-extern "C" int mi_bn_bwd_colsums(const void* g_bf16, const void* y_bf16, const float* mean, const float* invstd, long M, int C, float* dbeta,
-                                 float* dgamma, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int mi_bn_colsum2(const void* y_bf16, const float* pilot, long M, int C, float* s1, float* s2, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+    MI_REQUIRE(y_bf16 && pilot && s1 && s2 && mi_aligned16(y_bf16), "mi_bn_colsum2: null or unaligned operand");
+    BN_COMMON_CHECKS("mi_bn_colsum2")
+    const Plan p = bn_plan(M, C);
+    float* partial = (float*)workspace;
+    hipLaunchKernelGGL(bn_partial_kernel<3>, dim3(p.nblocks), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)y_bf16, (const bf16x8*)nullptr, pilot,
+                       (const float*)nullptr, (const uint8_t*)nullptr, partial, M, p.slots, p.cp, p.rows_per_block);
+    hipLaunchKernelGGL(bn_final_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, partial, p.nblocks, C, 2, s1, s2);
+    MI_CHECK_LAUNCH("mi_bn_colsum2");
+    return MI_OK;
+}
+
+extern "C" int mi_bn_bwd_colsums(const void* g_bf16, const void* y_bf16, const float* mean, const float* invstd, const void* relu_bits, long M, int C,
+                                 float* dbeta, float* dgamma, void* workspace, size_t workspace_bytes, void* stream) {
     MI_REQUIRE(g_bf16 && y_bf16 && mean && invstd && dbeta && dgamma && mi_aligned16(g_bf16) && mi_aligned16(y_bf16), "mi_bn_bwd_colsums: null or unaligned operand");
     BN_COMMON_CHECKS("mi_bn_bwd_colsums")
     const Plan p = bn_plan(M, C);
     float* partial = (float*)workspace;
     hipLaunchKernelGGL(bn_partial_kernel<2>, dim3(p.nblocks), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)y_bf16, (const bf16x8*)g_bf16, mean, invstd,
-                       partial, M, p.slots, p.cp, p.rows_per_block);
+                       (const uint8_t*)relu_bits, partial, M, p.slots, p.cp, p.rows_per_block);
     hipLaunchKernelGGL(bn_final_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, partial, p.nblocks, C, 2, dbeta, dgamma);
     MI_CHECK_LAUNCH("mi_bn_bwd_colsums");
     return MI_OK;
@@ -204,6 +268,7 @@ extern "C" int mi_bn_apply(const void* y_bf16, const float* mean, const float* s
     MI_REQUIRE(y_bf16 && mean && scale && beta && out_bf16 && mi_aligned16(y_bf16) && mi_aligned16(out_bf16), "mi_bn_apply: null or unaligned operand");
     MI_REQUIRE(M > 0 && C > 0 && C % 8 == 0, "mi_bn_apply: M=%ld, C=%d (C a multiple of 8)", M, C);
     MI_REQUIRE(!res_bf16 || mi_aligned16(res_bf16), "mi_bn_apply: residual alignment");
+    MI_REQUIRE(mi_aligned16(mean) && mi_aligned16(scale) && mi_aligned16(beta), "mi_bn_apply: per-channel vectors must be 16-byte aligned");
     MI_REQUIRE(!mask_out || C % 16 == 0, "mi_bn_apply: sign bits need C %% 16 == 0");
     const long n8 = M * (C / 8);
     const dim3 grid((unsigned)((n8 + 255) / 256));
@@ -227,13 +292,15 @@ extern "C" int mi_bn_apply(const void* y_bf16, const float* mean, const float* s
 }
 
 extern "C" int mi_bn_bwd_apply(const void* g_bf16, const void* y_bf16, const float* mean, const float* invstd, const float* gamma, const float* dbeta,
-                               const float* dgamma, float inv_count, void* dy_bf16, long M, int C, void* stream) {
+                               const float* dgamma, float inv_count, const void* relu_bits, void* dy_bf16, long M, int C, void* stream) {
     MI_REQUIRE(g_bf16 && y_bf16 && mean && invstd && gamma && dbeta && dgamma && dy_bf16, "mi_bn_bwd_apply: null operand");
     MI_REQUIRE(mi_aligned16(g_bf16) && mi_aligned16(y_bf16) && mi_aligned16(dy_bf16), "mi_bn_bwd_apply: alignment");
-    MI_REQUIRE(M > 0 && C > 0 && C % 8 == 0, "mi_bn_bwd_apply: M=%ld, C=%d (C a multiple of 8)", M, C);
+    MI_REQUIRE(mi_aligned16(mean) && mi_aligned16(invstd) && mi_aligned16(gamma) && mi_aligned16(dbeta) && mi_aligned16(dgamma),
+               "mi_bn_bwd_apply: per-channel vectors must be 16-byte aligned");
+    MI_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && (!relu_bits || C % 16 == 0), "mi_bn_bwd_apply: M=%ld, C=%d (C a multiple of 8; 16 with sign bits)", M, C);
     const long n8 = M * (C / 8);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)g_bf16,
-                       (const bf16x8*)y_bf16, mean, invstd, gamma, dbeta, dgamma, inv_count, (bf16x8*)dy_bf16, n8, C / 8);
+                       (const bf16x8*)y_bf16, mean, invstd, gamma, dbeta, dgamma, inv_count, (const uint8_t*)relu_bits, (bf16x8*)dy_bf16, n8, C / 8);
     MI_CHECK_LAUNCH("mi_bn_bwd_apply");
     return MI_OK;
 }

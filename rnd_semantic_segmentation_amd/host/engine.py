@@ -436,13 +436,25 @@ class BnActFn(torch.autograd.Function):
     def forward(ctx, y, gamma, beta, bn, res, relu):
         C = y.shape[-1]
         M = y.numel() // C
-        s = K.bn_colsum(y)
-        ranks = _bn_allreduce(bn, s)
-        count = M * ranks
-        mean = s / count
-        v = K.bn_colsum(y, mean)
-        _bn_allreduce(bn, v)
-        var = v / count
+        # one pass over y: sums of (y - pilot) and (y - pilot)^2 with the running mean as the pilot (identical on every rank, and
+        # close enough to the batch mean that var = E[d^2] - E[d]^2 loses 2-3 of fp32's 24 bits); MI_BN_TWO_PASS=1: mean first, then
+        # sum (y - mean)^2 - a second read of y
+        if os.environ.get("MI_BN_TWO_PASS") == "1" or bn.running_mean is None:
+            s = K.bn_colsum(y)
+            ranks = _bn_allreduce(bn, s)
+            count = M * ranks
+            mean = s / count
+            v = K.bn_colsum(y, mean)
+            _bn_allreduce(bn, v)
+            var = v / count
+        else:
+            pilot = bn.running_mean.detach().clone()
+            s1, s2 = K.bn_colsum2(y, pilot)
+            ranks = _bn_allreduce(bn, s1, s2)
+            count = M * ranks
+            d = s1 / count
+            mean = pilot + d
+            var = (s2 / count - d * d).clamp_min_(0.0)
         invstd = torch.rsqrt(var + bn.eps)
         if relu:
             out, bits = K.bn_apply(y, mean, gamma.detach() * invstd, beta.detach(), res=res, relu=True, want_mask=True)
@@ -465,16 +477,19 @@ class BnActFn(torch.autograd.Function):
         y, mean, invstd, bits, gamma = ctx.saved_tensors
         bn = ctx.bn
         g = g.contiguous()
-        if ctx.relu:
-            g = K.relu_mask(g, bits)
-        dbeta, dgamma = K.bn_bwd_colsums(g, y, mean, invstd)
+        fused_mask = None
+        if ctx.relu and ctx.has_res:
+            g = K.relu_mask(g, bits)                # the skip connection needs the masked gradient as a tensor
+        elif ctx.relu:
+            fused_mask = bits                       # otherwise both backward kernels apply the sign bits on the fly
+        dbeta, dgamma = K.bn_bwd_colsums(g, y, mean, invstd, fused_mask)
         for p, d in ((bn.weight, dgamma), (bn.bias, dbeta)):        # this rank's sums: what SyncBatchNorm hands DDP as well
             slot, acc = grad_slot(p)
             slot.add_(d) if acc else slot.copy_(d)
         if getattr(bn, "_mi_sync", False):
             dbeta, dgamma = dbeta.clone(), dgamma.clone()
             _bn_allreduce(bn, dbeta, dgamma)
-        dy = K.bn_bwd_apply(g, y, mean, invstd, gamma, dbeta, dgamma, ctx.count)
+        dy = K.bn_bwd_apply(g, y, mean, invstd, gamma, dbeta, dgamma, ctx.count, fused_mask)
         return dy, None, None, None, (g if ctx.has_res else None), None
 
 

@@ -430,6 +430,19 @@ def bn_colsum(y, mean=None):
     return out
 
 
+def bn_colsum2(y, pilot):
+    """One pass: raw (sum (y - pilot), sum (y - pilot)^2) per channel."""
+    _chk(y, torch.bfloat16, "y")
+    C = y.shape[-1]
+    M = y.numel() // C
+    s1 = torch.empty(C, dtype=torch.float32, device=y.device)
+    s2 = torch.empty_like(s1)
+    ws = _bn_workspace(y.device, M, C)
+    _timed("bn_kernels", 0.0, lambda: check(_lib.lib().mi_bn_colsum2(_p(y), _p(pilot), M, C, _p(s1), _p(s2), _p(ws), ws.numel(), _stream()), "mi_bn_colsum2"),
+           ("bn", 4, C, C, M, 0, 0))
+    return s1, s2
+
+
 def bn_apply(y, mean, scale, beta, res=None, relu=False, want_mask=False):
     """relu?((y - mean) * scale + beta (+ res)) as bf16 NHWC (+ packed sign bits)."""
     _chk(y, torch.bfloat16, "y")
@@ -442,8 +455,8 @@ def bn_apply(y, mean, scale, beta, res=None, relu=False, want_mask=False):
     return (out, bits) if want_mask else out
 
 
-def bn_bwd_colsums(g, y, mean, invstd):
-    """Raw (sum g, sum g * xhat) per channel."""
+def bn_bwd_colsums(g, y, mean, invstd, relu_bits=None):
+    """Raw (sum g, sum g * xhat) per channel; with relu_bits g counts only where the layer's output was positive."""
     _chk(g, torch.bfloat16, "g")
     _chk(y, torch.bfloat16, "y")
     C = y.shape[-1]
@@ -451,18 +464,18 @@ def bn_bwd_colsums(g, y, mean, invstd):
     dbeta = torch.empty(C, dtype=torch.float32, device=y.device)
     dgamma = torch.empty_like(dbeta)
     ws = _bn_workspace(y.device, M, C)
-    _timed("bn_kernels", 0.0, lambda: check(_lib.lib().mi_bn_bwd_colsums(_p(g), _p(y), _p(mean), _p(invstd), M, C, _p(dbeta), _p(dgamma), _p(ws),
-                                                                         ws.numel(), _stream()), "mi_bn_bwd_colsums"), ("bn", 2, C, C, M, 0, 0))
+    _timed("bn_kernels", 0.0, lambda: check(_lib.lib().mi_bn_bwd_colsums(_p(g), _p(y), _p(mean), _p(invstd), _p(relu_bits), M, C, _p(dbeta), _p(dgamma),
+                                                                         _p(ws), ws.numel(), _stream()), "mi_bn_bwd_colsums"), ("bn", 2, C, C, M, 0, 0))
     return dbeta, dgamma
 
 
-def bn_bwd_apply(g, y, mean, invstd, gamma, dbeta, dgamma, count):
+def bn_bwd_apply(g, y, mean, invstd, gamma, dbeta, dgamma, count, relu_bits=None):
     """dy of BatchNorm given the (possibly all-reduced) raw sums and the pixel count they were taken over."""
     C = y.shape[-1]
     M = y.numel() // C
     dy = torch.empty_like(y)
     _timed("bn_kernels", 0.0, lambda: check(_lib.lib().mi_bn_bwd_apply(_p(g), _p(y), _p(mean), _p(invstd), _p(gamma), _p(dbeta), _p(dgamma),
-                                                                       ctypes.c_float(1.0 / count), _p(dy), M, C, _stream()), "mi_bn_bwd_apply"),
+                                                                       ctypes.c_float(1.0 / count), _p(relu_bits), _p(dy), M, C, _stream()), "mi_bn_bwd_apply"),
            ("bn", 3, C, C, M, 0, 0))
     return dy
 

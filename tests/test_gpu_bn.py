@@ -35,6 +35,12 @@ def test_batchnorm_forward_backward_kernels_vs_torch_fp32(B, H, W, C):
     assert relmax(mean.double(), y32.double().mean(0)) < 1e-5
     assert relmax(var.double(), y32.double().var(0, unbiased=False)) < 1e-5
     assert torch.equal(K.bn_colsum(yd), K.bn_colsum(yd)) and torch.equal(K.bn_colsum(yd, mean), K.bn_colsum(yd, mean))     # fixed order
+    # one-pass form with a pilot that is NOT the mean (zeros, i.e. a fresh running_mean, and a pilot 0.5 sigma off): same statistics
+    for pilot in (torch.zeros(C, device=DEV), mean + 0.8):
+        s1, s2 = K.bn_colsum2(yd, pilot)
+        d = s1 / M
+        assert relmax((pilot + d).double(), y32.double().mean(0)) < 1e-5
+        assert relmax((s2 / M - d * d).double(), y32.double().var(0, unbiased=False)) < 2e-5
     # --- normalise (+ residual, ReLU, sign bits) against torch's training-mode batch_norm in fp32
     invstd = torch.rsqrt(var + eps)
     # (float64 restatement of torch.nn.functional.batch_norm(training=True): MIOpen's fp32 kernel is itself ~1e-3 off at
@@ -66,6 +72,15 @@ def test_batchnorm_forward_backward_kernels_vs_torch_fp32(B, H, W, C):
     assert torch.equal(dbeta, d2[0]) and torch.equal(dgamma, d2[1])
     dy = K.bn_bwd_apply(gd, yd, mean, invstd, gam, dbeta, dgamma, M)
     assert relmax(dy.double().permute(0, 3, 1, 2), x.grad) < 2.0 ** -8
+    # ReLU backward fused into both kernels (packed sign bits) == masking first
+    if C % 16 == 0:
+        keep = torch.rand(B, H, W, C, generator=g).to(DEV) > 0.4
+        packed = (keep.view(B, H, W, C // 16, 16).int() << torch.arange(16, device=DEV).int()).sum(-1).to(torch.int16)
+        gm = (gd.float() * keep).to(torch.bfloat16)
+        a = K.bn_bwd_colsums(gd, yd, mean, invstd, packed)
+        b = K.bn_bwd_colsums(gm, yd, mean, invstd)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        assert torch.equal(K.bn_bwd_apply(gd, yd, mean, invstd, gam, a[0], a[1], M, packed), K.bn_bwd_apply(gm, yd, mean, invstd, gam, b[0], b[1], M))
 
 
 # ------------------------------------------------------------------------------------------------ model level (tinynet, g10)

@@ -32,5 +32,14 @@ torch.cuda.synchronize()
 by = {}
 for name, e0, e1, fl, tag in events:
     by[name] = by.get(name, 0.0) + e0.elapsed_time(e1)
+ops = {}
+names = {0: "colsum (1 read)", 1: "apply (read + write [+ residual])", 2: "bwd colsums (2 reads)", 3: "bwd apply (2 reads + write)", 4: "colsum2 (1 read)"}
+passes = {0: 1, 1: 2, 2: 2, 3: 3, 4: 1}
+for name, e0, e1, fl, tag in events:
+    if name == "bn_kernels":
+        o = ops.setdefault(tag[1], [0.0, 0.0, 0])
+        o[0] += e0.elapsed_time(e1); o[1] += passes[tag[1]] * tag[4] * tag[2] * 2.0; o[2] += 1
+for k, (ms_, by_, n) in sorted(ops.items()):
+    print("   bn op %-36s %3d launches %7.2f ms  %5.2f TB/s (tensor passes only)" % (names[k], n, ms_, by_ / ms_ / 1e9))
 print("FREEZE_BN False, B=%d 769x769: %.1f ms/step = %.1f images/s, loss %.4f, reserved %.1f GB" % (B, ms, B * 1e3 / ms, float(loss), torch.cuda.memory_reserved() / 2**30))
 print("one instrumented step (single stream), ms per kernel group:", {k: round(v, 2) for k, v in sorted(by.items(), key=lambda kv: -kv[1])})
