@@ -508,8 +508,7 @@ def batchnorm_stages(x, eng):
 
 def batchnorm_stem(x, conv_weight, bn):
     """7x7/2 conv (PyTorch-ROCm library op) -> BatchNorm2d on batch statistics + ReLU (HIP) -> 3x3/2 max-pool."""
-    y = torch.nn.functional.conv2d(x, conv_weight.to(torch.bfloat16), None, 2, 3)
-    a = BnActFn.apply(y.permute(0, 2, 3, 1).contiguous(), bn.weight, bn.bias, bn, None, True)
+    a = BnActFn.apply(StemConvFn.apply(x, conv_weight), bn.weight, bn.bias, bn, None, True)
     p = torch.nn.functional.max_pool2d(a.permute(0, 3, 1, 2), 3, 2, 1)
     return p.permute(0, 2, 3, 1).contiguous()
 
@@ -591,6 +590,32 @@ class Fp32Aspp:
         return out
 
 
+def stem_conv_wgrad(dy_nhwc, x, w16):
+    """d loss / d conv1.weight.  Default: patch matrix + the fixed-order 1x1 weight-gradient kernel (bit-reproducible; the library's
+    weight gradient uses atomics and was the one nondeterministic launch of the step).  MI_STEM_WGRAD=miopen: the library op."""
+    if os.environ.get("MI_STEM_WGRAD", "hip") == "miopen":
+        dy = dy_nhwc.permute(0, 3, 1, 2)                                                  # NCHW-shaped, channels_last
+        return torch.ops.aten.convolution_backward(dy, x, w16, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1, [False, True, False])[1].float()
+    return K.stem_wgrad(dy_nhwc, x)
+
+
+class StemConvFn(torch.autograd.Function):
+    """The 7x7/2 stem conv on the library (forward) with the deterministic weight gradient; the input image needs no
+    gradient.  x [B,3,H,W] bf16 channels_last, weight fp32 -> [B,Hc,Wc,64] bf16 NHWC."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        w16 = weight.detach().to(torch.bfloat16)
+        y = torch.nn.functional.conv2d(x, w16, None, 2, 3).permute(0, 2, 3, 1).contiguous()
+        ctx.save_for_backward(x, w16)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w16 = ctx.saved_tensors
+        return None, stem_conv_wgrad(dy.contiguous(), x, w16)
+
+
 class StemFn(torch.autograd.Function):
     """Stem: 7x7/2 conv on the PyTorch-ROCm library + fused FrozenBN/ReLU/max-pool HIP kernel.
     x [B,3,H,W] bf16 channels_last, weight fp32 [64,3,7,7] -> pooled [B,Hp,Wp,64] bf16 NHWC."""
@@ -608,9 +633,8 @@ class StemFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dpool):
         x, w16, idx, scale = ctx.saved_tensors
-        dy = K.stem_pool_bwd(dpool.contiguous(), idx, scale, ctx.conv_hw).permute(0, 3, 1, 2)   # NCHW-shaped, channels_last
-        dw = torch.ops.aten.convolution_backward(dy, x, w16, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1, [False, True, False])[1]
-        return None, dw.float(), None, None
+        dy = K.stem_pool_bwd(dpool.contiguous(), idx, scale, ctx.conv_hw)                      # [B,Hc,Wc,64] bf16 NHWC
+        return None, stem_conv_wgrad(dy, x, w16), None, None
 
 
 class StagesFn(torch.autograd.Function):

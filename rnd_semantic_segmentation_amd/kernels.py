@@ -336,6 +336,22 @@ def stem_pool_bwd(dpool, idx, scale, conv_hw):
     return dy
 
 
+def stem_wgrad(dy, x):
+    """Weight gradient of the 7x7 / stride 2 / pad 3 stem conv, deterministic: dy [B,Ho,Wo,64] bf16 NHWC, x [B,3,H,W] bf16 channels_last
+    -> fp32 [64,3,7,7].  Patch matrix (mi_stem_im2col) + the 1x1 weight-gradient kernel with its fixed-order slab reduction."""
+    _chk(dy, torch.bfloat16, "dy")
+    B, Ho, Wo, O = dy.shape
+    H, W = x.shape[2], x.shape[3]
+    xn = x.permute(0, 2, 3, 1)
+    if not xn.is_contiguous():
+        xn = xn.contiguous()
+    col = torch.empty((B, Ho, Wo, 160), dtype=torch.bfloat16, device=dy.device)
+    check(_lib.lib().mi_stem_im2col(_p(xn), _p(col), B, H, W, Ho, Wo, _stream()), "mi_stem_im2col")
+    dw = torch.empty((O, 160, 1, 1), dtype=torch.float32, device=dy.device)
+    conv_wgrad(dy, col, dw, 1, 1, 0, 1)
+    return dw.view(O, 160)[:, :147].reshape(O, 3, 7, 7)
+
+
 def bias_grad_bf16(dy, db, accumulate=False):
     """db[n] (+)= sum over pixels of dy[..., n];  dy bf16 [B,H,W,N]"""
     _chk(dy, torch.bfloat16, "dy")

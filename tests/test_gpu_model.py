@@ -315,3 +315,35 @@ def test_hip_graph_replay_of_the_training_step_is_bit_equal_to_eager(tmp_path, m
     assert not cap0 and cap1
     assert eager == graph and torch.equal(w0, w1)
     assert eager[-1] < eager[0]
+
+
+def test_training_is_bit_reproducible_run_to_run():
+    """Every launch of the step has a fixed summation order (split-K slabs and BatchNorm / bias sums are reduced in a fixed order, no
+    float atomics), including the stem conv's weight gradient, which runs as patch matrix + 1x1 weight gradient instead of the
+    library op (MIOpen's atomics made 160-step trainings end in different parameters): two trainings from the same state end in
+    bit-identical parameters and optimizer state."""
+    from rnd_semantic_segmentation_amd.host import sgd
+
+    def train():
+        _, _, fe, cls = make_pair((1, 1, 2, 2))
+        fe.train()
+        cls.train()
+        fe.ensure_flat()
+        cls.ensure_flat()
+        of = sgd.FusedSGD(list(fe.parameters()), lr=4e-3, momentum=0.9, weight_decay=5e-4)
+        oc = sgd.FusedSGD(list(cls.parameters()), lr=4e-2, momentum=0.9, weight_decay=5e-4)
+        x, lab = _cases.net_inputs(2, 97, 23)
+        xt, lt = torch.from_numpy(x).cuda(), torch.from_numpy(lab).cuda().long()
+        losses = []
+        for _ in range(30):
+            of.zero_grad()
+            oc.zero_grad()
+            loss = cls.loss(fe(xt), lt)
+            loss.backward()
+            of.step()
+            oc.step()
+            losses.append(loss)
+        return torch.stack(losses).cpu(), fe._store.data.clone(), cls._store.data.clone()
+
+    a, b = train(), train()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])

@@ -683,3 +683,19 @@ def test_table_driven_weight_pack_equals_the_per_tensor_packs_on_ragged_shapes()
                 assert torch.equal(K.pack_weight_dgrad(wd, s), want_b)
             else:
                 assert bool(torch.isnan(wpt[r[2]:r[2] + n].float()).all())          # untouched
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 33, 35), (1, 65, 65), (3, 16, 23)])
+def test_stem_weight_gradient_patch_matrix_plus_1x1_wgrad_vs_torch(B, H, W):
+    """mi_stem_im2col + mi_conv_wgrad (the deterministic replacement of the library's weight gradient for the 7x7/2/3 stem conv,
+    resnet.py:137) against torch's conv2d weight gradient in fp32 on the same bf16-rounded operands; bit-reproducible run to run."""
+    g = torch.Generator(device="cpu").manual_seed(H * 7 + W)
+    x = torch.randn(B, 3, H, W, generator=g).to(torch.bfloat16)
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    dy = torch.randn(B, Ho, Wo, 64, generator=g).to(torch.bfloat16)
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    dyd = dy.to(DEV)
+    dw = K.stem_wgrad(dyd, xd)
+    ref = torch.nn.grad.conv2d_weight(x.float(), (64, 3, 7, 7), dy.float().permute(0, 3, 1, 2), stride=2, padding=3)
+    assert relmax(dw.cpu().numpy(), ref.numpy()) < 2e-5
+    assert torch.equal(dw, K.stem_wgrad(dyd, xd))
