@@ -355,6 +355,9 @@ extern "C" int mi_conv_gemm_route(int B, int Ha, int Wa, int Ca, int Ho, int Wo,
         min_k = e ? atoi(e) : 512;         // in the step: 704 -> 2048 (ASPP data gradient) 246 vs 280 us, 512 -> 1024 101 vs 116; K = 256: no difference
     }
     const long M = (long)B * Ho * Wo;
+    // igemm_pp_kernel addresses its operands with 32-bit buffer offsets: 2 GiB tensors stay on the pointer-arithmetic kernel
+    const long a_bytes = (long)B * Ha * Wa * Ca * 2 + 64L * (Wa + 1) * Ca * 2, w_bytes = (long)ksize * ksize * N * Ca * 2;
+    if (a_bytes >= (1L << 31) - (1L << 20) || w_bytes >= (1L << 31) - (1L << 20)) return 0;
     return pp_on && stride == 1 && Ha == Ho && Wa == Wo && !(flags & (MI_EPI_RESIDUAL | MI_EPI_MASK | MI_EPI_LEAKY)) && (long)ksize * ksize * Ca >= min_k &&
            Ca % 32 == 0 && M >= 320 * 64 && N >= 256;
 }
@@ -388,7 +391,8 @@ extern "C" int mi_conv_gemm(const void* a, const void* wp, void* out, int B, int
     // L2 bytes per kFLOP.  Measured per shape against this kernel in one process (tools/ppexp.py, B = 8, 97 x 97): 3x3 256 +16 %,
     // 3x3 512 +13 %, 1x1 2048->512 +18 %, 1x1 1024->256 / 1024->2048 / ASPP forward +6 %; the short contractions (K < 512)
     // are epilogue-bound and stay here.  MI_IGEMM_PP=0 switches the dispatch off.
-    if (mi_conv_gemm_route(B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, flags))
+    if (mi_conv_gemm_route(B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, flags) &&
+        (long)B * Ha * Wa * Ca * 2 + 2L * ((long)(ksize - 1) * dil + pad) * (Wa + 1) * Ca * 2 < (1L << 31) - (1L << 20))     // its exact 32-bit offset bound
         return mi_conv_gemm_pp(a, wp, out, B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, pad, dil, gather_mode, scale, bias, res, msk, mask_out, flags, zgw,
                                alpha, 0, stream);
     IgemmParams p;

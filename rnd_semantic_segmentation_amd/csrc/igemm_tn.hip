@@ -1295,7 +1295,9 @@ extern "C" int mi_conv_wgrad(const void* dy, const void* x, float* dw, int B, in
     mi_allow_dynamic_lds((const void*)wgrad_tn_kernel<2>, LDS_BYTES, attr_set[2]);
     const unsigned nblocks = (unsigned)(p.o_tiles * p.i_tiles * p.T * p.S);
     const bool unit = stride == 1 && Ha == Ho && Wa == Wo;
-    if (unit && ksize == 1 && pad == 0)
+    // MODE 2 addresses a split's rows through 32-bit buffer offsets: operands of 2 GiB or more take the pointer-arithmetic kernel
+    const bool small32 = (long)M * (O > I ? O : I) * 2 < (1L << 31);
+    if (unit && ksize == 1 && pad == 0 && small32)
         hipLaunchKernelGGL(wgrad_tn_kernel<2>, dim3(nblocks), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
     else if (unit)
         hipLaunchKernelGGL(wgrad_tn_kernel<1>, dim3(nblocks), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
