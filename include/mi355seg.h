@@ -269,6 +269,14 @@ int mi_bn_bwd_colsums(const void* g_bf16, const void* y_bf16, const float* mean,
 int mi_bn_bwd_apply(const void* g_bf16, const void* y_bf16, const float* mean, const float* invstd, const float* gamma, const float* dbeta,
                     const float* dgamma, float inv_count, const void* relu_bits, void* dy_bf16, long M, int C, void* stream);
 
+/* ---- PraNet path, first kernel: the structure loss of pranet_trainer.py:22-31 on one-channel maps pred / mask fp32
+ * [B][H][W]: weit = 1 + 5 |avg_pool31(mask) - mask|, BCE-with-logits averaged over the whole batch (the reference's reduce='none' is read by
+ * torch as the legacy reduce=True), weighted IoU per image.  out: float[1 + 2B] = {loss, N_0, D_0, ...} (N = inter + 1, D = union - inter + 1);
+ * grad (optional) = grad_scale * d loss / d pred.  Fixed-order sums. */
+size_t mi_structure_loss_workspace(int B, int H, int W);
+int mi_structure_loss(const float* pred, const float* mask, int B, int H, int W, float* out, float* grad, float grad_scale,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

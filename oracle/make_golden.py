@@ -9,6 +9,7 @@ Unavailable third-party packages are replaced by in-memory stubs (ours, below):
   torchvision.models.utils.load_state_dict_from_url  (resnet.py:3, never reached)
   mmcv.runner.load_checkpoint                        (resnet.py:2, never reached: pretrained=False)
   torchvision.transforms                              (utility.py:14, unused on this path)
+  thop.profile / clever_format                        (core/utils/utils.py:3, pulled in by pranet_trainer.py:9, unused)
 Network-fetching loaders (MODEL.WEIGHTS URL) are never called: models are built
 with pretrained_backbone=False and filled with formula weights
 (rnd_semantic_segmentation_amd/host/synth.py), which the tests regenerate.
@@ -82,6 +83,7 @@ def install_stubs():
     tv.transforms = mod("torchvision.transforms")
     mm = mod("mmcv")
     mm.runner = mod("mmcv.runner", load_checkpoint=_offline)
+    mod("thop", profile=_offline, clever_format=_offline)          # core/utils/utils.py:3 (FLOP counter, unused on these paths)
 
 
 def import_reference():
@@ -366,6 +368,34 @@ def g_tinynet_bn(ref, out):
                    "n_fe_tensors": len(list(fe101.parameters()))}, f)
 
 
+def g_structure_loss(ref, out):
+    """G11 (first piece): PraNetTrainer.structure_loss (pranet_trainer.py:22-31) called as the reference defines it -
+    including its `reduce='none'` argument, which torch reads as the legacy reduce=True, i.e. the BCE term is the MEAN over the batch -
+    on soft masks (the trainer bilinearly rescales the ground truth), hard masks, an empty and a full mask; loss and d loss / d pred."""
+    from core.trainers.pranet_trainer import PraNetTrainer
+    import warnings
+    cases = {}
+    for name, (B, H, W, kind) in dict(soft=(2, 44, 44, "soft"), ragged=(3, 37, 52, "hard"), tiny=(1, 9, 13, "soft"), empty=(2, 20, 24, "zero"),
+                                      full=(1, 33, 33, "one")).items():
+        pred = (synth.uniform("sl.pred." + name, (B, 1, H, W)) * 6).astype(np.float32)
+        blob = synth.uniform("sl.mask." + name, (B, 1, (H + 7) // 8, (W + 7) // 8))
+        m = np.kron((blob > 0).astype(np.float32), np.ones((8, 8), np.float32))[:, :, :H, :W]
+        if kind == "soft":
+            m = F.avg_pool2d(t(m), 5, 1, 2).numpy()
+        elif kind == "zero":
+            m = np.zeros_like(m)
+        elif kind == "one":
+            m = np.ones_like(m)
+        p = t(pred).requires_grad_(True)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            loss = PraNetTrainer.structure_loss(None, p, t(np.ascontiguousarray(m)))
+        loss.backward()
+        cases[name + "_pred"], cases[name + "_mask"] = pred, np.ascontiguousarray(m)
+        cases[name + "_loss"], cases[name + "_grad"] = np.float64(loss.item()), p.grad.numpy()
+    save(out, "g11_structure_loss", **cases)
+
+
 def eval_record(ref, probs, pred, lab):
     """What ASPPTester.test (aspp_tester.py:47-83) accumulates for one image, by the reference's own functions: the
     per-class intersection / union / target / prediction areas (utility.py:133-145, the numpy twin of :148-161), the
@@ -595,7 +625,7 @@ def main():
     torch.set_num_threads(8)
     ref = import_reference()
     jobs = dict(conv=lambda: g_conv(ref, args.out), aspp=lambda: g_aspp(ref, args.out),
-                frozenbn=lambda: g_frozenbn(ref, args.out), tinynet=lambda: g_tinynet(ref, args.out), tinynet_bn=lambda: g_tinynet_bn(ref, args.out),
+                frozenbn=lambda: g_frozenbn(ref, args.out), tinynet=lambda: g_tinynet(ref, args.out), tinynet_bn=lambda: g_tinynet_bn(ref, args.out), structure_loss=lambda: g_structure_loss(ref, args.out),
                 r101=lambda: g_r101(ref, args.out, not args.skip_big), metrics=lambda: g_metrics(ref, args.out),
                 fada=lambda: g_fada(ref, args.out))
     for name, fn in jobs.items():

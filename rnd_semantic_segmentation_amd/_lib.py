@@ -61,6 +61,8 @@ SIGNATURES = {
     "mi_allreduce_bucket": (I, [P, Z, I, I, P, P]),
     "mi_relu_mask": (I, [P, P, P, Z, I, P]),
     "mi_frozen_bn_fold": (I, [P, P, P, P, P, P, I, P]),
+    "mi_structure_loss_workspace": (Z, [I, I, I]),
+    "mi_structure_loss": (I, [P, P, I, I, I, P, P, F, P, Z, P]),
     "mi_bn_workspace": (Z, [L, I]),
     "mi_bn_colsum": (I, [P, P, L, I, P, P, Z, P]),
     "mi_bn_apply": (I, [P, P, P, P, P, P, P, I, L, I, P]),

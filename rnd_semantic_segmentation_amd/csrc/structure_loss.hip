@@ -1,0 +1,131 @@
+// PraNet structure loss (first kernel of that path): reference core/trainers/pranet_trainer.py:22-31
+//   weit = 1 + 5 * |avg_pool2d(mask, 31, stride 1, pad 15) - mask|               (zero padding counted: every window divides by 961)
+//   wbce = binary_cross_entropy_with_logits(pred, mask, reduce='none')           -> torch reads the string as the legacy reduce=True:
+//          the MEAN over the whole batch, a scalar; (weit * wbce).sum / weit.sum is then that scalar again for every image
+//   p = sigmoid(pred); inter = sum(p * mask * weit), union = sum((p + mask) * weit) per image; wiou = 1 - (inter + 1) / (union - inter + 1)
+//   loss = mean_i(wbce + wiou_i)
+// and its gradient with respect to pred:
+//   d loss / d x = (p - z) / (B*H*W)  -  (1/B) * w * (z * D_i - N_i * (1 - z)) / D_i^2 * p * (1 - p),   N_i = inter_i + 1, D_i = union_i - inter_i + 1
+// pred / mask fp32 [B][H][W] (the maps have one channel).  Sums are two-level with a fixed order (bitwise reproducible); the box filter is
+// separable (31 + 31 taps).  Bound: launch latency (the maps are 352 x 352 x B).
+#include "mi_common.h"
+
+namespace {
+
+constexpr int SL_BLOCKS = 64;      // partial-sum workgroups per image
+
+__global__ __launch_bounds__(256) void sl_hbox_kernel(const float* __restrict__ mask, float* __restrict__ tmp, int B, int H, int W) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * H * W) return;
+    const int w = (int)(idx % W);
+    const float* row = mask + (idx - w);
+    float s = 0.f;
+    for (int dx = -15; dx <= 15; ++dx) {
+        const int ww = w + dx;
+        if ((unsigned)ww < (unsigned)W) s += row[ww];
+    }
+    tmp[idx] = s;
+}
+
+// weit, and per-workgroup partial sums {bce, inter, union} over a contiguous pixel range of ONE image
+__global__ __launch_bounds__(256) void sl_terms_kernel(const float* __restrict__ pred, const float* __restrict__ mask, const float* __restrict__ tmp,
+                                                       float* __restrict__ weit, float* __restrict__ partial, int H, int W, int per_block) {
+    __shared__ float red[3][256];
+    const int b = blockIdx.y;
+    const int HW = H * W;
+    const int p0 = blockIdx.x * per_block, p1 = min(HW, p0 + per_block);
+    const long base = (long)b * HW;
+    float a_bce = 0.f, a_int = 0.f, a_uni = 0.f;
+    for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+        const int h = p / W, w = p - h * W;
+        float box = 0.f;
+        for (int dy = -15; dy <= 15; ++dy) {
+            const int hh = h + dy;
+            if ((unsigned)hh < (unsigned)H) box += tmp[base + (long)hh * W + w];
+        }
+        box *= (1.0f / 961.0f);
+        const float z = mask[base + p], x = pred[base + p];
+        const float wt = 1.0f + 5.0f * fabsf(box - z);
+        weit[base + p] = wt;
+        // max(x, 0) - x z + log(1 + exp(-|x|)): torch's stable form of the logistic loss
+        a_bce += fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x)));
+        const float s = 1.0f / (1.0f + expf(-x));
+        a_int += s * z * wt;
+        a_uni += (s + z) * wt;
+    }
+    red[0][threadIdx.x] = a_bce;
+    red[1][threadIdx.x] = a_int;
+    red[2][threadIdx.x] = a_uni;
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float s = 0.f;
+        for (int k = 0; k < 256; ++k) s += red[threadIdx.x][k];              // fixed order
+        partial[((long)b * gridDim.x + blockIdx.x) * 3 + threadIdx.x] = s;
+    }
+}
+
+// one workgroup: per image the partials in ascending order, then the images in ascending order.  out = {loss, N_0, D_0, N_1, D_1, ...}
+__global__ __launch_bounds__(64) void sl_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int B, int nblk, float inv_pixels) {
+    if (threadIdx.x != 0) return;
+    float bce = 0.f, iou = 0.f;
+    for (int b = 0; b < B; ++b) {
+        float sb = 0.f, si = 0.f, su = 0.f;
+        for (int k = 0; k < nblk; ++k) {
+            const float* q = partial + ((long)b * nblk + k) * 3;
+            sb += q[0];
+            si += q[1];
+            su += q[2];
+        }
+        bce += sb;
+        const float N = si + 1.0f, D = su - si + 1.0f;
+        out[1 + 2 * b] = N;
+        out[2 + 2 * b] = D;
+        iou += 1.0f - N / D;
+    }
+    out[0] = bce * inv_pixels + iou / (float)B;
+}
+
+__global__ __launch_bounds__(256) void sl_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ mask, const float* __restrict__ weit,
+                                                     const float* __restrict__ nd, float* __restrict__ grad, int B, int HW, float inv_pixels,
+                                                     float inv_b, float gscale) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * HW) return;
+    const int b = (int)(idx / HW);
+    const float N = nd[1 + 2 * b], D = nd[2 + 2 * b];
+    const float x = pred[idx], z = mask[idx], w = weit[idx];
+    const float s = 1.0f / (1.0f + expf(-x));
+    const float diou = -w * (z * D - N * (1.0f - z)) / (D * D);
+    grad[idx] = gscale * ((s - z) * inv_pixels + inv_b * diou * s * (1.0f - s));
+}
+
+}  // namespace
+
+extern "C" size_t mi_structure_loss_workspace(int B, int H, int W) {
+    return ((size_t)2 * B * H * W + (size_t)B * SL_BLOCKS * 3) * sizeof(float);
+}
+
+extern "C" int mi_structure_loss(const float* pred, const float* mask, int B, int H, int W, float* out, float* grad, float grad_scale,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    MI_REQUIRE(pred && mask && out && workspace, "mi_structure_loss: null operand");
+    MI_REQUIRE(B > 0 && H > 0 && W > 0 && (long)B * H * W < (1L << 31), "mi_structure_loss: bad shape");
+    MI_REQUIRE(workspace_bytes >= mi_structure_loss_workspace(B, H, W), "mi_structure_loss: workspace too small");
+    const long n = (long)B * H * W;
+    float* tmp = (float*)workspace;
+    float* weit = tmp + n;
+    float* partial = weit + n;
+    const int HW = H * W;
+    int nblk = (HW + 1023) / 1024;                       // at least 1024 pixels per partial workgroup
+    if (nblk > SL_BLOCKS) nblk = SL_BLOCKS;
+    const int per_block = (HW + nblk - 1) / nblk;
+    nblk = (HW + per_block - 1) / per_block;
+    const float inv_pixels = 1.0f / (float)n;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sl_hbox_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mask, tmp, B, H, W);
+    hipLaunchKernelGGL(sl_terms_kernel, dim3(nblk, B), dim3(256), 0, st, pred, mask, tmp, weit, partial, H, W, per_block);
+    hipLaunchKernelGGL(sl_final_kernel, dim3(1), dim3(64), 0, st, partial, out, B, nblk, inv_pixels);
+    if (grad)
+        hipLaunchKernelGGL(sl_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pred, mask, weit, out, grad, B, HW, inv_pixels,
+                           1.0f / (float)B, grad_scale);
+    MI_CHECK_LAUNCH("mi_structure_loss");
+    return MI_OK;
+}

@@ -421,6 +421,23 @@ def frozen_bn_fold(w, b, mean, var):
     return scale, shift
 
 
+# ---------------------------------------------------------------------------------------------- PraNet structure loss
+def structure_loss(pred, mask, want_grad=True, grad_scale=1.0):
+    """pranet_trainer.py:22-31 on fp32 maps [B,1,H,W] (or [B,H,W]): returns (loss scalar tensor, d loss / d pred * grad_scale or None)."""
+    _chk(pred, torch.float32, "pred")
+    _chk(mask, torch.float32, "mask")
+    if pred.shape != mask.shape or (pred.dim() == 4 and pred.shape[1] != 1):
+        raise _lib.MiError("structure_loss: pred / mask must be [B,1,H,W] of the same shape, got %s / %s" % (tuple(pred.shape), tuple(mask.shape)))
+    B, H, W = pred.shape[0], pred.shape[-2], pred.shape[-1]
+    L = _lib.lib()
+    ws = torch.empty(int(L.mi_structure_loss_workspace(B, H, W)), dtype=torch.uint8, device=pred.device)
+    out = torch.empty(1 + 2 * B, dtype=torch.float32, device=pred.device)
+    grad = torch.empty_like(pred) if want_grad else None
+    check(L.mi_structure_loss(_p(pred), _p(mask), B, H, W, _p(out), _p(grad), ctypes.c_float(grad_scale), _p(ws), ws.numel(), _stream()),
+          "mi_structure_loss")
+    return out[0], grad
+
+
 # ---------------------------------------------------------------------------------------------- trainable BatchNorm2d (NHWC bf16)
 _bn_ws = {}
 

@@ -311,3 +311,22 @@ def test_new_op_fixtures_2048ch_aspp_13x21_upsample_large_logits_autocast():
     with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
         low = cls(fe(torch.from_numpy(x))).float()
     assert rel(low.numpy(), g["low"]) < 2e-2            # same rounding regime, different op fusion: bf16-level agreement
+
+
+def test_pranet_structure_loss_restatement_vs_reference_golden():
+    """oracle/ref_pranet.py::structure_loss against the reference's own function (pranet_trainer.py:22-31, g11): soft, hard, ragged, empty
+    and full masks - loss and d loss / d pred.  Pins the quirk that the BCE term is the batch MEAN (torch reads reduce='none' as
+    the legacy reduce=True): a per-pixel-weighted BCE would give different numbers on every case."""
+    from oracle import ref_pranet
+    g = _cases.load("g11_structure_loss")
+    for name in ("soft", "ragged", "tiny", "empty", "full"):
+        pred = torch.from_numpy(g[name + "_pred"]).requires_grad_(True)
+        mask = torch.from_numpy(g[name + "_mask"])
+        loss = ref_pranet.structure_loss(pred, mask)
+        loss.backward()
+        assert abs(loss.item() - float(g[name + "_loss"])) < 2e-6 * abs(float(g[name + "_loss"])), name
+        assert rel(pred.grad.numpy(), g[name + "_grad"]) < 2e-5, name
+    # the box filter alone, against torch's avg_pool2d
+    m = torch.from_numpy(g["ragged_mask"])
+    assert np.abs(ref_pranet.box31(m.numpy()) - torch.nn.functional.avg_pool2d(m, 31, 1, 15).numpy()).max() < 1e-6
+
