@@ -396,6 +396,101 @@ def g_structure_loss(ref, out):
     save(out, "g11_structure_loss", **cases)
 
 
+def import_pranet():
+    """The reference's PraNet modules (core/models/classifiers/pranet/PraNet_Res2Net.py, Res2Net_v1b.py).  PraNet.__init__ asks for
+    res2net50_v1b_26w_4s(pretrained=True), which torch.load()s a weight file this image does not have: the constructor name is
+    re-bound at run time to the same architecture without the load (no reference file is modified)."""
+    from core.models.classifiers.pranet import PraNet_Res2Net as P
+    from core.models.classifiers.pranet import Res2Net_v1b as R
+    P.res2net50_v1b_26w_4s = lambda pretrained=False, **kw: R.Res2Net(R.Bottle2neck, [3, 4, 6, 3], baseWidth=26, scale=4, **kw)
+    return P, R
+
+
+def _grad_norms(module):
+    return {k: float(p.grad.double().norm()) for k, p in module.named_parameters() if p.grad is not None}
+
+
+def g_pranet(ref, out):
+    """G12: module-level and whole-net fixtures of the PraNet path with formula weights - a Res2Net bottleneck of
+    each kind ('normal', 'stage' with the avg-pool downsample), RFB_modified, the partial decoder (aggregation), and PraNet at
+    2 x 3 x 96 x 96: eval-mode lateral maps, train-mode (batch statistics) structure-loss sum of pranet_trainer.py:50-56 and the
+    gradient norm of every parameter; state_dict keys and parameter count of the full model."""
+    from core.trainers.pranet_trainer import PraNetTrainer
+    import warnings
+    P, R = import_pranet()
+    arrays = {}
+
+    def run(tag, mod, inputs):
+        synth.load_formula_weights(mod, prefix=tag + ".")
+        mod.train()
+        xs = [t(a).requires_grad_(True) for a in inputs]
+        y = mod(*xs)
+        (y.square().mean() + y.mean()).backward()
+        arrays[tag + "_out"] = y.detach().numpy()
+        for i, x in enumerate(xs):
+            arrays["%s_dx%d" % (tag, i)] = x.grad.numpy()
+        gn = _grad_norms(mod)
+        arrays[tag + "_pnames"] = np.array(sorted(gn))
+        arrays[tag + "_pgrad"] = np.array([gn[k] for k in sorted(gn)])
+        mod.eval()
+        with torch.no_grad():
+            arrays[tag + "_out_eval"] = mod(*[t(a) for a in inputs]).numpy()
+
+    u = lambda name, shape, s=1.0: (synth.uniform("pn." + name, shape) * s).astype(np.float32)
+    run("b2n_normal", R.Bottle2neck(64, 16, baseWidth=26, scale=4), [u("b2n_normal.x", (2, 64, 12, 12), 2)])
+    ds = nn.Sequential(nn.AvgPool2d(kernel_size=2, stride=2, ceil_mode=True, count_include_pad=False), nn.Conv2d(64, 128, 1, 1, bias=False),
+                       nn.BatchNorm2d(128))
+    run("b2n_stage", R.Bottle2neck(64, 32, stride=2, downsample=ds, baseWidth=26, scale=4, stype="stage"), [u("b2n_stage.x", (2, 64, 13, 13), 2)])
+    run("rfb", P.RFB_modified(64, 32), [u("rfb.x", (2, 64, 11, 11), 2)])
+    run("agg", P.aggregation(32), [u("agg.x1", (2, 32, 3, 3)), u("agg.x2", (2, 32, 6, 6)), u("agg.x3", (2, 32, 12, 12))])
+    save(out, "g12_pranet_modules", **arrays)
+
+    # ---- the whole net
+    torch.manual_seed(0)
+    net = P.PraNet(channel=32)
+    synth.load_formula_weights(net, prefix="pranet.")
+    keys = list(net.state_dict().keys())
+    with open(os.path.join(out, "g8_pranet_keys.json"), "w") as f:
+        json.dump({"keys": keys, "n_params": sum(p.numel() for p in net.parameters()), "n_tensors": len(list(net.parameters()))}, f)
+    B, S = 2, 96
+    x = synth.synth_image(B, S, S, seed=31)
+    blob = synth.uniform("pn.gt", (B, 1, S // 8, S // 8))
+    gt = F.avg_pool2d(t(np.kron((blob > 0.1).astype(np.float32), np.ones((8, 8), np.float32))), 5, 1, 2).numpy()
+    full = dict(x_seed=31, gt=gt)
+    net.train()
+    outs = net(t(x))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        losses = [PraNetTrainer.structure_loss(None, o, t(gt)) for o in outs]          # lateral_map_5, 4, 3, 2
+    loss = losses[3] + losses[2] + losses[1] + losses[0]                               # pranet_trainer.py:56
+    loss.backward()
+    full["train_losses"] = np.array([l.item() for l in losses])
+    full["train_loss"] = np.float64(loss.item())
+    for i, m in enumerate(outs):
+        full["train_map%d_crop" % i] = m.detach().numpy()[:, :, ::4, ::4].copy()
+    gn = _grad_norms(net)
+    names = sorted(gn)
+    full["pnames"] = np.array(names)
+    full["pgrad"] = np.array([gn[k] for k in names])
+    # eval(): with the formula running statistics a 50-layer eval forward overflows, so the running statistics are first driven to the
+    # batch statistics the way training does it - 120 more train-mode forwards (momentum 0.1: 0.9^121 = 3e-6 of the initial values left)
+    with torch.no_grad():
+        for _ in range(120):
+            net(t(x))
+    sd = net.state_dict()
+    full["num_batches_tracked"] = int(sd["resnet.bn1.num_batches_tracked"])
+    for k in ("resnet.bn1", "resnet.layer2.0.bns.1", "rfb3_1.conv_cat.bn", "ra2_conv3.bn"):
+        full["stat_" + k.replace(".", "_") + "_mean"] = sd[k + ".running_mean"].numpy().copy()
+        full["stat_" + k.replace(".", "_") + "_var"] = sd[k + ".running_var"].numpy().copy()
+    net.eval()
+    with torch.no_grad():
+        maps = [m.numpy() for m in net(t(x))]
+    for i, m in enumerate(maps):
+        full["eval_map%d_crop" % i] = m[:, :, ::4, ::4].copy()
+        full["eval_map%d_norm" % i] = np.float64(np.sqrt((m.astype(np.float64) ** 2).sum()))
+    save(out, "g12_pranet_96", **full)
+
+
 def eval_record(ref, probs, pred, lab):
     """What ASPPTester.test (aspp_tester.py:47-83) accumulates for one image, by the reference's own functions: the
     per-class intersection / union / target / prediction areas (utility.py:133-145, the numpy twin of :148-161), the
@@ -625,7 +720,7 @@ def main():
     torch.set_num_threads(8)
     ref = import_reference()
     jobs = dict(conv=lambda: g_conv(ref, args.out), aspp=lambda: g_aspp(ref, args.out),
-                frozenbn=lambda: g_frozenbn(ref, args.out), tinynet=lambda: g_tinynet(ref, args.out), tinynet_bn=lambda: g_tinynet_bn(ref, args.out), structure_loss=lambda: g_structure_loss(ref, args.out),
+                frozenbn=lambda: g_frozenbn(ref, args.out), tinynet=lambda: g_tinynet(ref, args.out), tinynet_bn=lambda: g_tinynet_bn(ref, args.out), structure_loss=lambda: g_structure_loss(ref, args.out), pranet=lambda: g_pranet(ref, args.out),
                 r101=lambda: g_r101(ref, args.out, not args.skip_big), metrics=lambda: g_metrics(ref, args.out),
                 fada=lambda: g_fada(ref, args.out))
     for name, fn in jobs.items():

@@ -330,3 +330,81 @@ def test_pranet_structure_loss_restatement_vs_reference_golden():
     m = torch.from_numpy(g["ragged_mask"])
     assert np.abs(ref_pranet.box31(m.numpy()) - torch.nn.functional.avg_pool2d(m, 31, 1, 15).numpy()).max() < 1e-6
 
+
+def _pn_uniform(name, shape, scale=1.0):
+    return (synth.uniform("pn." + name, shape) * scale).astype(np.float32)
+
+
+def test_pranet_modules_restatement_vs_reference_golden():
+    """oracle/ref_pranet.py building blocks against the reference's own modules (g12): a Res2Net bottleneck of each kind, the RFB, the
+    partial decoder - train-mode output, input gradients, every parameter-gradient norm, eval-mode output."""
+    from oracle import ref_pranet as rp
+    g = _cases.load("g12_pranet_modules")
+    ds = torch.nn.Sequential(torch.nn.AvgPool2d(2, 2, ceil_mode=True, count_include_pad=False), torch.nn.Conv2d(64, 128, 1, 1, bias=False),
+                             torch.nn.BatchNorm2d(128))
+    cases = [("b2n_normal", rp.Bottle2neck(64, 16), [_pn_uniform("b2n_normal.x", (2, 64, 12, 12), 2)]),
+             ("b2n_stage", rp.Bottle2neck(64, 32, stride=2, downsample=ds, stype="stage"), [_pn_uniform("b2n_stage.x", (2, 64, 13, 13), 2)]),
+             ("rfb", rp.RFB(64, 32), [_pn_uniform("rfb.x", (2, 64, 11, 11), 2)]),
+             ("agg", rp.PartialDecoder(32), [_pn_uniform("agg.x1", (2, 32, 3, 3)), _pn_uniform("agg.x2", (2, 32, 6, 6)), _pn_uniform("agg.x3", (2, 32, 12, 12))])]
+    for tag, mod, inputs in cases:
+        synth.load_formula_weights(mod, prefix=tag + ".")
+        mod.train()
+        xs = [torch.from_numpy(a).requires_grad_(True) for a in inputs]
+        y = mod(*xs)
+        (y.square().mean() + y.mean()).backward()
+        assert rel(y.detach().numpy(), g[tag + "_out"]) < 2e-5, tag
+        for i, x in enumerate(xs):
+            assert rel(x.grad.numpy(), g["%s_dx%d" % (tag, i)]) < 2e-4, (tag, i)
+        gn = {k: float(p.grad.double().norm()) for k, p in mod.named_parameters()}
+        names = [str(n) for n in g[tag + "_pnames"]]
+        assert sorted(gn) == names
+        assert np.allclose([gn[k] for k in names], g[tag + "_pgrad"], rtol=2e-3, atol=1e-7), tag
+        if np.isfinite(g[tag + "_out_eval"]).all():      # the formula gives `bns.N.running_var` (not recognised as BatchNorm by name) negative entries:
+            mod.eval()                                   # the reference's own eval output of the two bottlenecks is NaN, nothing to compare
+            with torch.no_grad():
+                assert rel(mod(*[torch.from_numpy(a) for a in inputs]).numpy(), g[tag + "_out_eval"]) < 2e-5, tag
+
+
+def test_pranet_whole_net_restatement_vs_reference_golden(golden_dir):
+    """oracle PraNet (Res2Net-50 v1b 26w x 4s + RFB + partial decoder + reverse attention) against the reference's own run at 2 x 3 x 96 x 96
+    (g12): state_dict keys / parameter count, the four train-mode side outputs, the structure-loss sum of pranet_trainer.py:50-56, every
+    parameter-gradient norm, running statistics after 121 train-mode forwards and the eval-mode outputs on them."""
+    from oracle import ref_pranet as rp
+    keys = json.load(open(os.path.join(golden_dir, "g8_pranet_keys.json")))
+    net = rp.PraNet()
+    assert list(net.state_dict().keys()) == keys["keys"] and len(keys["keys"]) == 922
+    assert sum(p.numel() for p in net.parameters()) == keys["n_params"] == 32547319 and len(list(net.parameters())) == keys["n_tensors"]
+    g = _cases.load("g12_pranet_96")
+    synth.load_formula_weights(net, prefix="pranet.")
+    x = torch.from_numpy(synth.synth_image(2, 96, 96, seed=31))
+    gt = torch.from_numpy(g["gt"])
+    net.train()
+    outs = net(x)
+    losses = [rp.structure_loss(o, gt) for o in outs]
+    loss = losses[3] + losses[2] + losses[1] + losses[0]
+    loss.backward()
+    assert np.allclose([l.item() for l in losses], g["train_losses"], rtol=2e-5)
+    assert abs(loss.item() - float(g["train_loss"])) < 2e-5 * float(g["train_loss"])
+    for i, o in enumerate(outs):
+        assert rel(o.detach().numpy()[:, :, ::4, ::4], g["train_map%d_crop" % i]) < 1e-4, i
+    gn = {k: float(p.grad.double().norm()) for k, p in net.named_parameters() if p.grad is not None}
+    names = [str(n) for n in g["pnames"]]
+    assert sorted(gn) == names                                        # resnet.fc.* get no gradient in either implementation
+    ours = np.array([gn[k] for k in names])
+    big = g["pgrad"] > 1e-6 * g["pgrad"].max()
+    assert np.abs(ours[big] / g["pgrad"][big] - 1).max() < 5e-3
+    with torch.no_grad():
+        for _ in range(120):
+            net(x)
+    sd = net.state_dict()
+    assert int(sd["resnet.bn1.num_batches_tracked"]) == int(g["num_batches_tracked"]) == 121
+    for k in ("resnet.bn1", "resnet.layer2.0.bns.1", "rfb3_1.conv_cat.bn", "ra2_conv3.bn"):
+        tag = k.replace(".", "_")
+        assert rel(sd[k + ".running_mean"].numpy(), g["stat_" + tag + "_mean"]) < 1e-4, k
+        assert rel(sd[k + ".running_var"].numpy(), g["stat_" + tag + "_var"]) < 1e-4, k
+    net.eval()
+    with torch.no_grad():
+        maps = net(x)
+    for i, m in enumerate(maps):
+        assert rel(m.numpy()[:, :, ::4, ::4], g["eval_map%d_crop" % i]) < 1e-3, i
+
