@@ -206,6 +206,9 @@ int mi_upsample_softce(const float* seg_low, float inv_temperature, float clip, 
 /* torch.optim.Adam (no amsgrad, weight_decay 0; fada_adapter.py:24) on flat fp32 buffers; step >= 1 is this update's index */
 int mi_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2,
                  float eps, int step, void* stream);
+/* the same after clamping g to [-grad_clamp, grad_clamp] in place: clip_gradient (core/utils/utils.py:6-16) + Adam.step of pranet_trainer.py:59-60 */
+int mi_adam_step_clamped(float* p, float* g, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2,
+                         float eps, int step, float grad_clamp, void* stream);
 
 /* ---- exact-fp32 evaluation path (test.py / ASPPTester; csrc/igemm_f32.hip) ---------------------------------------
  * The reference computes in fp32; BASELINE.json asks for argmax masks identical to it.  These entry points run the same

@@ -215,12 +215,18 @@ __global__ void softce_pass2_kernel(const float* __restrict__ tmp, float* __rest
     dd[(((long)b * h + i) * w + j) * ldD + k] = s * scale;
 }
 
-// torch.optim.Adam single-tensor update
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
-                            float step_size, float beta1, float beta2, float inv_sqrt_bc2, float eps) {
+// torch.optim.Adam single-tensor update; CLAMP: the gradient is first clamped to [-clamp, clamp] IN PLACE (core/utils/utils.py:6-16
+// clip_gradient, called before optimizer.step() at pranet_trainer.py:59)
+template <bool CLAMP>
+__global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                            float step_size, float beta1, float beta2, float inv_sqrt_bc2, float eps, float clamp) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float gi = g[i];
+        float gi = g[i];
+        if (CLAMP) {
+            gi = fminf(fmaxf(gi, -clamp), clamp);
+            g[i] = gi;
+        }
         const float mi = beta1 * m[i] + (1.f - beta1) * gi;
         const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
         m[i] = mi;
@@ -292,8 +298,20 @@ extern "C" int mi_adam_step(float* p, const float* g, float* exp_avg, float* exp
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     size_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, exp_avg, exp_avg_sq, n, (float)(lr / bc1),
-                       beta1, beta2, (float)(1.0 / sqrt(bc2)), eps);
+    hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, const_cast<float*>(g), exp_avg, exp_avg_sq, n,
+                       (float)(lr / bc1), beta1, beta2, (float)(1.0 / sqrt(bc2)), eps, 0.f);
     MI_CHECK_LAUNCH("mi_adam_step");
+    return MI_OK;
+}
+
+extern "C" int mi_adam_step_clamped(float* p, float* g, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2,
+                                    float eps, int step, float grad_clamp, void* stream) {
+    MI_REQUIRE(p && g && exp_avg && exp_avg_sq && n > 0 && step >= 1 && grad_clamp > 0.f, "mi_adam_step_clamped: bad argument");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, exp_avg, exp_avg_sq, n, (float)(lr / bc1),
+                       beta1, beta2, (float)(1.0 / sqrt(bc2)), eps, grad_clamp);
+    MI_CHECK_LAUNCH("mi_adam_step_clamped");
     return MI_OK;
 }

@@ -218,7 +218,10 @@ def build_adversarial_discriminator(cfg, num_features=None, mid_nc=256):
 
 
 class FusedAdam(torch.optim.Adam):
-    """torch.optim.Adam(betas, eps; no amsgrad / weight decay) with the update on a HIP kernel; torch's state_dict format."""
+    """torch.optim.Adam(betas, eps; no amsgrad / weight decay) with the update on a HIP kernel; torch's state_dict format.
+    `grad_clamp` (attribute, default None): clamp every gradient to [-c, c] in place before the update - core/utils/utils.py:6-16
+    clip_gradient(optimizer, 0.5) followed by optimizer.step() in pranet_trainer.py:59-60, as one launch per tensor."""
+    grad_clamp = None
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -237,7 +240,10 @@ class FusedAdam(torch.optim.Adam):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] += 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                K.adam_step(p.data, g, st["exp_avg"], st["exp_avg_sq"], group["lr"], b1, b2, group["eps"], int(st["step"].item()))
+                K.adam_step(p.data, g, st["exp_avg"], st["exp_avg_sq"], group["lr"], b1, b2, group["eps"], int(st["step"].item()),
+                            grad_clamp=self.grad_clamp)
+                if self.grad_clamp is not None and g is not p.grad:
+                    p.grad.copy_(g)
                 ps = getattr(p, "_mi_store", None)
                 if ps is not None:
                     ps.generation += 1

@@ -380,9 +380,13 @@ def upsample_softce(seg_low, d_low, size, domain, temperature=1.8, clip=0.9, wan
     return out, dd
 
 
-def adam_step(p, g, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
+def adam_step(p, g, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_clamp=None):
     for t, n in ((p, "p"), (g, "g"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
         _chk(t, torch.float32, n)
+    if grad_clamp is not None:          # clip_gradient(optimizer, c) + Adam.step (pranet_trainer.py:59-60): g is clamped in place
+        check(_lib.lib().mi_adam_step_clamped(_p(p), _p(g), _p(exp_avg), _p(exp_avg_sq), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+                                              int(step), float(grad_clamp), _stream()), "mi_adam_step_clamped")
+        return
     check(_lib.lib().mi_adam_step(_p(p), _p(g), _p(exp_avg), _p(exp_avg_sq), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
                                   int(step), _stream()), "mi_adam_step")
 
