@@ -185,9 +185,10 @@ int mi_stem_pool_fwd(const void* y, const float* scale, const float* shift, void
                      int B, int Hc, int Wc, int C, int Hp, int Wp, void* stream);
 int mi_stem_pool_bwd(const void* dpool, const uint8_t* idx, const float* scale, void* dy,
                      int B, int Hc, int Wc, int C, int Hp, int Wp, void* stream);
-/* Patch matrix of the stem conv (7x7, stride 2, pad 3, 3 input channels; resnet.py:137): col[m][k] bf16 [B*Ho*Wo][160], k = (c*7+ky)*7+kx for
- * k < 147, zero above.  With it the stem's weight gradient is a 1x1 mi_conv_wgrad (deterministic), not the library's atomics. */
-int mi_stem_im2col(const void* x_bf16_nhwc, void* col_bf16, int B, int H, int W, int Ho, int Wo, void* stream);
+/* Patch matrix of the stem conv (7x7, stride 2, pad 3, 3 input channels; resnet.py:137): col[m][k] bf16 [B*Ho*Wo][ncols], k = (c*7+ky)*7+kx for
+ * k < 147, zero above (ncols a multiple of 8; 192 when the matrix also feeds the forward as a 1x1 mi_conv_gemm, 160 for the weight gradient
+ * alone).  With it the stem conv is a plain GEMM and its weight gradient a 1x1 mi_conv_wgrad (deterministic), not the library's atomics. */
+int mi_stem_im2col(const void* x_bf16_nhwc, void* col_bf16, int B, int H, int W, int Ho, int Wo, int ncols, void* stream);
 
 /* ---- FADA adversarial step (reference core/combos/aspp_fada.py:80-127) ---------------------------
  * db[n] (+)= sum_m dy[m][n]  (conv bias gradient; dy bf16 [M][N], N % 8 == 0; fixed summation order) */

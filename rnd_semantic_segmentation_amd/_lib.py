@@ -44,7 +44,7 @@ SIGNATURES = {
     "mi_upsample_softmax": (I, [P, P, P] + [I] * 6 + [P]),
     "mi_stem_pool_fwd": (I, [P, P, P, P, P] + [I] * 6 + [P]),
     "mi_stem_pool_bwd": (I, [P, P, P, P] + [I] * 6 + [P]),
-    "mi_stem_im2col": (I, [P, P] + [I] * 5 + [P]),
+    "mi_stem_im2col": (I, [P, P] + [I] * 6 + [P]),
     "mi_bias_grad_bf16": (I, [P, P, I, I, I, P, Z, P]),
     "mi_upsample_softce_workspace": (Z, [I] * 6),
     "mi_upsample_softce": (I, [P, F, F, P, I, I, P, P] + [I] * 6 + [F, P, Z, P]),

@@ -113,15 +113,16 @@ extern "C" int mi_stem_pool_bwd(const void* dpool, const uint8_t* idx, const flo
 // MIOpen's weight gradient of the stem conv (torch convolution_backward) is not run-to-run reproducible - its atomics are the only
 // source of nondeterminism in the training step (tools/determinism_check.py: with the stem frozen, or with this path, 160 steps end in
 // bit-identical parameters).  col[m][k] = x[b][2*ho - 3 + ky][2*wo - 3 + kx][c] for k = (c * 7 + ky) * 7 + kx < 147 (the order of the
-// OIHW weight tensor), zero for 147 <= k < 160; dW[o][k] = sum_m dy[m][o] * col[m][k] is then a 1x1 weight gradient (mi_conv_wgrad,
+// OIHW weight tensor), zero for 147 <= k < ncols (160 for the weight gradient alone, 192 when the same matrix also feeds the forward GEMM, whose K is a multiple of 64); dW[o][k] = sum_m dy[m][o] * col[m][k] is then a 1x1 weight gradient (mi_conv_wgrad,
 // fixed-order slabs).  x is the bf16 channels_last input [B][H][W][3]; a thread writes 8 consecutive k of one output pixel.
 namespace {
-__global__ __launch_bounds__(256) void stem_im2col_kernel(const __bf16* __restrict__ x, bf16x8* __restrict__ col, int B, int H, int W, int Ho, int Wo) {
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const __bf16* __restrict__ x, bf16x8* __restrict__ col, int B, int H, int W, int Ho, int Wo,
+                                                          int groups) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const long total = (long)B * Ho * Wo * 20;
+    const long total = (long)B * Ho * Wo * groups;
     if (idx >= total) return;
-    const int kg = (int)(idx % 20);
-    const long m = idx / 20;
+    const int kg = (int)(idx % groups);
+    const long m = idx / groups;
     const int wo = (int)(m % Wo);
     const int ho = (int)((m / Wo) % Ho);
     const int b = (int)(m / ((long)Wo * Ho));
@@ -141,13 +142,14 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const __bf16* __restri
 }
 }  // namespace
 
-extern "C" int mi_stem_im2col(const void* x_bf16_nhwc, void* col_bf16, int B, int H, int W, int Ho, int Wo, void* stream) {
+extern "C" int mi_stem_im2col(const void* x_bf16_nhwc, void* col_bf16, int B, int H, int W, int Ho, int Wo, int ncols, void* stream) {
     MI_REQUIRE(x_bf16_nhwc && col_bf16 && B > 0 && H > 0 && W > 0, "mi_stem_im2col: bad argument");
+    MI_REQUIRE(ncols >= 152 && ncols % 8 == 0 && ncols <= 256, "mi_stem_im2col: ncols=%d (a multiple of 8 in [152, 256])", ncols);
     MI_REQUIRE(Ho == (H + 6 - 7) / 2 + 1 && Wo == (W + 6 - 7) / 2 + 1, "mi_stem_im2col: output size must be that of a 7x7/2/3 conv");
     MI_REQUIRE(mi_aligned16(col_bf16), "mi_stem_im2col: alignment");
-    const long total = (long)B * Ho * Wo * 20;
+    const long total = (long)B * Ho * Wo * (ncols / 8);
     hipLaunchKernelGGL(stem_im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x_bf16_nhwc,
-                       (bf16x8*)col_bf16, B, H, W, Ho, Wo);
+                       (bf16x8*)col_bf16, B, H, W, Ho, Wo, ncols / 8);
     MI_CHECK_LAUNCH("mi_stem_im2col");
     return MI_OK;
 }

@@ -590,51 +590,66 @@ class Fp32Aspp:
         return out
 
 
-def stem_conv_wgrad(dy_nhwc, x, w16):
-    """d loss / d conv1.weight.  Default: patch matrix + the fixed-order 1x1 weight-gradient kernel (bit-reproducible; the library's
-    weight gradient uses atomics and was the one nondeterministic launch of the step).  MI_STEM_WGRAD=miopen: the library op."""
+def _stem_on_library():
+    """MI_STEM_CONV=miopen: the 7x7/2 stem conv forward on the PyTorch-ROCm library (round 1: SURVEY 8a row A6).  Default (hip): patch matrix +
+    plain GEMM on the implicit-GEMM kernel, so that no library convolution is left in the training step."""
+    return os.environ.get("MI_STEM_CONV", "hip") == "miopen"
+
+
+def stem_conv_forward(x, weight):
+    """x [B,3,H,W] bf16 channels_last, weight fp32 [64,3,7,7] -> (y [B,Hc,Wc,64] bf16 NHWC, what the weight gradient needs)."""
+    if _stem_on_library():
+        w16 = weight.detach().to(torch.bfloat16)
+        return torch.nn.functional.conv2d(x, w16, None, 2, 3).permute(0, 2, 3, 1).contiguous(), (x, w16)
+    y, col = K.stem_conv_fwd(x, weight)
+    return y, (col,)
+
+
+def stem_conv_wgrad(dy_nhwc, saved):
+    """d loss / d conv1.weight.  Default: the 1x1 weight-gradient kernel on the forward's patch matrix (bit-reproducible).  With the library
+    forward: patch matrix built here, or (MI_STEM_WGRAD=miopen) the library's weight gradient, whose atomics were the one
+    nondeterministic launch of the step."""
+    if len(saved) == 1:
+        return K.stem_wgrad(dy_nhwc, col=saved[0])
+    x, w16 = saved
     if os.environ.get("MI_STEM_WGRAD", "hip") == "miopen":
         dy = dy_nhwc.permute(0, 3, 1, 2)                                                  # NCHW-shaped, channels_last
         return torch.ops.aten.convolution_backward(dy, x, w16, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1, [False, True, False])[1].float()
-    return K.stem_wgrad(dy_nhwc, x)
+    return K.stem_wgrad(dy_nhwc, x=x)
 
 
 class StemConvFn(torch.autograd.Function):
-    """The 7x7/2 stem conv on the library (forward) with the deterministic weight gradient; the input image needs no
-    gradient.  x [B,3,H,W] bf16 channels_last, weight fp32 -> [B,Hc,Wc,64] bf16 NHWC."""
+    """The 7x7/2 stem conv alone (the trainable-BatchNorm stem); the input image needs no gradient.
+    x [B,3,H,W] bf16 channels_last, weight fp32 -> [B,Hc,Wc,64] bf16 NHWC."""
 
     @staticmethod
     def forward(ctx, x, weight):
-        w16 = weight.detach().to(torch.bfloat16)
-        y = torch.nn.functional.conv2d(x, w16, None, 2, 3).permute(0, 2, 3, 1).contiguous()
-        ctx.save_for_backward(x, w16)
+        y, saved = stem_conv_forward(x, weight)
+        ctx.save_for_backward(*saved)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w16 = ctx.saved_tensors
-        return None, stem_conv_wgrad(dy.contiguous(), x, w16)
+        return None, stem_conv_wgrad(dy.contiguous(), ctx.saved_tensors)
 
 
 class StemFn(torch.autograd.Function):
-    """Stem: 7x7/2 conv on the PyTorch-ROCm library + fused FrozenBN/ReLU/max-pool HIP kernel.
+    """Stem: 7x7/2 conv (patch matrix + GEMM) + fused FrozenBN/ReLU/max-pool HIP kernel.
     x [B,3,H,W] bf16 channels_last, weight fp32 [64,3,7,7] -> pooled [B,Hp,Wp,64] bf16 NHWC."""
 
     @staticmethod
     def forward(ctx, x, weight, scale, shift):
-        w16 = weight.detach().to(torch.bfloat16)
-        y = torch.nn.functional.conv2d(x, w16, None, 2, 3)                    # [B,64,Hc,Wc] channels_last
-        y = y.permute(0, 2, 3, 1).contiguous()                               # NHWC view (no copy when channels_last)
+        y, saved = stem_conv_forward(x, weight)
         pool, idx = K.stem_pool_fwd(y, scale, shift)
-        ctx.save_for_backward(x, w16, idx, scale)
+        ctx.save_for_backward(idx, scale, *saved)
         ctx.conv_hw = (y.shape[1], y.shape[2])
         return pool
 
     @staticmethod
     def backward(ctx, dpool):
-        x, w16, idx, scale = ctx.saved_tensors
+        idx, scale = ctx.saved_tensors[:2]
         dy = K.stem_pool_bwd(dpool.contiguous(), idx, scale, ctx.conv_hw)                      # [B,Hc,Wc,64] bf16 NHWC
-        return None, stem_conv_wgrad(dy, x, w16), None, None
+        return None, stem_conv_wgrad(dy, ctx.saved_tensors[2:]), None, None
 
 
 class StagesFn(torch.autograd.Function):

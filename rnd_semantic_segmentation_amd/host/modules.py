@@ -6,7 +6,7 @@ the reference, computing through the MI355X engine (engine.py -> C-ABI kernels).
   ASPP_Classifier_V2         reference core/models/classifiers/aspp/classifier.py:6-32
 
 These modules run on the GPU only: their forward raises if given CPU tensors (the CPU restatement lives in
-oracle/, as test infrastructure).  What stays on PyTorch-ROCm library ops: the 7x7/s2 stem
+oracle/, as test infrastructure).  Round 1 left on PyTorch-ROCm library ops the 7x7/s2 stem
 conv, its FrozenBN+ReLU and the 3x3/s2 max-pool.
 """
 import logging
@@ -153,7 +153,7 @@ class resnet_feature_extractor(nn.Module):
             self._engine.prepare(True)
             y = engine.batchnorm_stem(xb, bb.conv1.weight, bb.bn1)
             return engine.batchnorm_stages(y, self._engine).permute(0, 3, 1, 2)
-        # stem: 7x7/2 conv on the PyTorch-ROCm library (A6), then FrozenBN + ReLU + 3x3/2 max-pool in one HIP kernel
+        # stem: 7x7/2 conv as patch matrix + GEMM (engine.stem_conv_forward), then FrozenBN + ReLU + 3x3/2 max-pool in one HIP kernel
         scale, shift = self._stem_fold()
         y = engine.StemFn.apply(xb, bb.conv1.weight, scale, shift)                       # [B,Hp,Wp,64] bf16 NHWC
         weights = [rt.weight for rt in self._engine.convs]

@@ -336,20 +336,42 @@ def stem_pool_bwd(dpool, idx, scale, conv_hw):
     return dy
 
 
-def stem_wgrad(dy, x):
-    """Weight gradient of the 7x7 / stride 2 / pad 3 stem conv, deterministic: dy [B,Ho,Wo,64] bf16 NHWC, x [B,3,H,W] bf16 channels_last
-    -> fp32 [64,3,7,7].  Patch matrix (mi_stem_im2col) + the 1x1 weight-gradient kernel with its fixed-order slab reduction."""
-    _chk(dy, torch.bfloat16, "dy")
-    B, Ho, Wo, O = dy.shape
-    H, W = x.shape[2], x.shape[3]
+def stem_im2col(x, ncols):
+    """Patch matrix of the 7x7 / stride 2 / pad 3 stem conv: x [B,3,H,W] bf16 channels_last -> [B,Ho,Wo,ncols] bf16 (147 live columns)."""
+    _chk_dtype = x.dtype
+    if _chk_dtype != torch.bfloat16 or not x.is_cuda:
+        raise _lib.MiError("stem_im2col: x must be a bf16 GPU tensor")
+    B, _, H, W = x.shape
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
     xn = x.permute(0, 2, 3, 1)
     if not xn.is_contiguous():
         xn = xn.contiguous()
-    col = torch.empty((B, Ho, Wo, 160), dtype=torch.bfloat16, device=dy.device)
-    check(_lib.lib().mi_stem_im2col(_p(xn), _p(col), B, H, W, Ho, Wo, _stream()), "mi_stem_im2col")
-    dw = torch.empty((O, 160, 1, 1), dtype=torch.float32, device=dy.device)
+    col = torch.empty((B, Ho, Wo, ncols), dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().mi_stem_im2col(_p(xn), _p(col), B, H, W, Ho, Wo, ncols, _stream()), "mi_stem_im2col")
+    return col
+
+
+def stem_conv_fwd(x, weight):
+    """The stem conv as patch matrix + plain GEMM on the implicit-GEMM kernel: returns (y [B,Ho,Wo,64] bf16 NHWC, the patch matrix, which the
+    weight gradient reuses)."""
+    col = stem_im2col(x, 192)
+    O = weight.shape[0]
+    wp = torch.zeros((1, O, 192), dtype=torch.bfloat16, device=x.device)
+    wp[0, :, :147] = weight.detach().reshape(O, 147).to(torch.bfloat16)
+    return conv_gemm(col, wp, (col.shape[1], col.shape[2]), 1, 1, 0, 1, GATHER_FWD), col
+
+
+def stem_wgrad(dy, x=None, col=None):
+    """Weight gradient of the stem conv, deterministic: dy [B,Ho,Wo,64] bf16 NHWC and either the forward's patch matrix `col` or the input
+    x [B,3,H,W] bf16 channels_last (a 160-column matrix is built then) -> fp32 [64,3,7,7], by the 1x1 weight-gradient kernel with its
+    fixed-order slab reduction."""
+    _chk(dy, torch.bfloat16, "dy")
+    if col is None:
+        col = stem_im2col(x, 160)
+    O, n = dy.shape[-1], col.shape[-1]
+    dw = torch.empty((O, n, 1, 1), dtype=torch.float32, device=dy.device)
     conv_wgrad(dy, col, dw, 1, 1, 0, 1)
-    return dw.view(O, 160)[:, :147].reshape(O, 3, 7, 7)
+    return dw.view(O, n)[:, :147].reshape(O, 3, 7, 7)
 
 
 def bias_grad_bf16(dy, db, accumulate=False):

@@ -695,7 +695,13 @@ def test_stem_weight_gradient_patch_matrix_plus_1x1_wgrad_vs_torch(B, H, W):
     dy = torch.randn(B, Ho, Wo, 64, generator=g).to(torch.bfloat16)
     xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
     dyd = dy.to(DEV)
-    dw = K.stem_wgrad(dyd, xd)
+    dw = K.stem_wgrad(dyd, x=xd)
     ref = torch.nn.grad.conv2d_weight(x.float(), (64, 3, 7, 7), dy.float().permute(0, 3, 1, 2), stride=2, padding=3)
     assert relmax(dw.cpu().numpy(), ref.numpy()) < 2e-5
-    assert torch.equal(dw, K.stem_wgrad(dyd, xd))
+    assert torch.equal(dw, K.stem_wgrad(dyd, x=xd))
+    # the forward as patch matrix + GEMM, and the weight gradient from that same (192-column) matrix
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    y, col = K.stem_conv_fwd(xd, w.to(DEV))
+    want = torch.nn.functional.conv2d(x.float(), w.to(torch.bfloat16).float(), None, 2, 3).permute(0, 2, 3, 1)
+    assert relmax(y.float().cpu().numpy(), want.numpy()) < 2.0 ** -8
+    assert torch.equal(K.stem_wgrad(dyd, col=col), dw)

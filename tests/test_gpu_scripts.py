@@ -107,7 +107,8 @@ def test_opt_in_kernel_variants_and_single_stream_schedule_stay_correct():
                      ({"MI_WGRAD_S4": "0"}, ["tests/test_gpu_ops.py", "-k", "tiny_and_ragged or wgrad_full or pointwise or aspp_head_2048"]),   # 1x1 weight gradients on the double-buffer kernel
                      ({"MI_WGRAD_TI256": "0"}, ["tests/test_gpu_ops.py", "-k", "wgrad_full or aspp_head_2048 or aspp_head_upsample"]),   # the big 1x1 shapes on the 128 x 128 kernels
                      ({"MI_WGRAD_TI256": "1"}, ["tests/test_gpu_ops.py", "-k", "tiny_and_ragged or wgrad_full or full_size_vs or aspp_head_2048"]),
-                     ({"MI_STEM_WGRAD": "miopen"}, ["tests/test_gpu_model.py", "-k", "tinynet_three_sgd or tinynet_forward_backward"]),   # the library's stem weight gradient
+                     ({"MI_STEM_CONV": "miopen"}, ["tests/test_gpu_model.py", "-k", "tinynet_three_sgd or tinynet_forward_backward or bit_reproducible"]),   # library stem forward, HIP weight gradient
+                     ({"MI_STEM_CONV": "miopen", "MI_STEM_WGRAD": "miopen"}, ["tests/test_gpu_model.py", "-k", "tinynet_three_sgd or tinynet_forward_backward"]),   # the library's stem conv both ways
                      ({"MI_BN_TWO_PASS": "1"}, ["tests/test_gpu_bn.py", "-k", "tinynet_trainable"]),             # BatchNorm statistics as two passes
                      ({"MI_WGRAD_STREAM": "0", "MI_BATCH_LANES": "1"}, ["tests/test_gpu_model.py", "-k", "tinynet"])):
         r = run(["-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider"] + sel, env)
