@@ -6,8 +6,8 @@ the reference, computing through the MI355X engine (engine.py -> C-ABI kernels).
   ASPP_Classifier_V2         reference core/models/classifiers/aspp/classifier.py:6-32
 
 These modules run on the GPU only: their forward raises if given CPU tensors (the CPU restatement lives in
-oracle/, as test infrastructure).  Round 1 left on PyTorch-ROCm library ops the 7x7/s2 stem
-conv, its FrozenBN+ReLU and the 3x3/s2 max-pool.
+oracle/, as test infrastructure).  Every convolution of the training step, the 7x7/s2 stem included (patch matrix +
+GEMM), runs on the library behind the C-ABI; the trainable-BatchNorm stem uses torch's max_pool2d.
 """
 import logging
 import os
