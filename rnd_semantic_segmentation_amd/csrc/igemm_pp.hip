@@ -41,6 +41,9 @@ template <int MTG> struct PPGeo {
     static_assert(PA % 4 == 0, "the A pieces must split evenly over the four waves of group 0");
 };
 
+#ifndef PP_PRIO
+#define PP_PRIO 0         // 0: no priority changes (default: 1 and 2 measure the same within 1 %, the 256-row tile 3 % slower with 1); 1: s_setprio 1 around every MFMA segment; 2: static priority 1 for the younger group (waves 4-7)
+#endif
 #ifndef PP_DMA_SEG
 #define PP_DMA_SEG 0      // 0: the DMA pieces of the slab three ahead are issued in the read segment, after the fragment reads; 1: between the MFMAs
 #endif
@@ -252,6 +255,9 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmParams p) {
     const bool tr_on = blockIdx.x == p.korder >> 8 && wq == 0;
     const unsigned long long tr_c0 = __builtin_readcyclecounter(), tr_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
+#if PP_PRIO == 2
+    if (grp == 1) __builtin_amdgcn_s_setprio(1);
+#endif
 #if defined(PP_DBG) && (PP_DBG & 1)
     read_frags(0);                                                  // timeline experiment: the loop below issues no LDS reads
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -283,9 +289,13 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmParams p) {
         __builtin_amdgcn_s_barrier();
         PP_T(3)
         // ---- MFMA segment (G0: I_2s+1, G1: I_2s+2) ----
+#if PP_PRIO == 1
         __builtin_amdgcn_s_setprio(1);
+#endif
         mfma_and_stage();                                           // + slab s+3 -> the slot slab s-1 has left
+#if PP_PRIO == 1
         __builtin_amdgcn_s_setprio(0);
+#endif
         PP_T(4)
         if (grp == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPA) : "memory");     // slab s+1 landed (s+2, s+3 in flight)
         __builtin_amdgcn_s_barrier();
