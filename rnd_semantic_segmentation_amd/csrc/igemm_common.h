@@ -29,6 +29,11 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// the same with the non-temporal cache policy (aux bit 1 = nt on gfx94x / gfx950): for tensors a launch reads exactly once
+__device__ __forceinline__ void glds16_nt(const char* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
+}
 
 // Buffer form of the same DMA: per-lane 32-bit byte offset + scalar offset against a buffer resource; a lane whose offset is out
 // of range for the resource (bit 31 set, num_records < 2^31) writes zeros.
@@ -240,7 +245,7 @@ __device__ __forceinline__ void igemm_residual_to_lds(const IgemmParams& p, int 
         const int row = 4 * q + prow, m = m0 + row;
         const int n = n0 + ((pch ^ (row & 15)) << 3);
         const char* src = (m < p.M && n < p.N) ? reinterpret_cast<const char*>(p.res + (long)m * p.N + n) : zero;
-        glds16(src, stage + q * 1024);
+        glds16(src, stage + q * 1024);          // (glds16_nt here: 8.09 -> 8.03 ms for the class, inside the noise; not used)
     }
 }
 
@@ -295,9 +300,14 @@ __device__ __forceinline__ void igemm_store_staged(const IgemmParams& p, int m0,
 #pragma unroll
     for (int it = 0; it < 2 * MT; ++it) {
         const int row = it * 16 + r_in, m = m0 + row;
-        if (m < p.M)
-            *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.out) + (long)m * p.N + n) =
-                *reinterpret_cast<const bf16x8*>(stage + row * 256 + ((c ^ (row & 15)) << 4));
+        if (m < p.M) {
+            // non-temporal: the 154-308 MB outputs of the residual launches are not read again before they have left every cache, and
+            // written through the normal policy they evict the operands the neighbouring workgroups still share (K = 256 <-> N = 1024
+            // class 3.70 -> 3.97 TB/s, +0.6 % images/s).  The direct-store epilogues (38-77 MB outputs, read by the very next launch)
+            // keep the default policy: with nt there the next launch misses (igemm_pp +2 %, step -1 %).
+            __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(stage + row * 256 + ((c ^ (row & 15)) << 4)),
+                                        reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(p.out) + (long)m * p.N + n));
+        }
     }
 }
 
