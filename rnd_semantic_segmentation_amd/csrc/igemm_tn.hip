@@ -536,6 +536,33 @@ int pick_splits256(long M, int tiles) {
     return best;
 }
 
+// Splits of the deep-stream 1x1 kernel.  MI_WGRAD_S4_SLOTS (default 512 = two workgroups per CU): workgroup slots the cost model fills.
+// With 256 (one workgroup per CU, twice the K steps, half the partial planes) the launches themselves are 7 % faster when timed alone
+// (256 <-> 1024: 64.7 vs 70.0 us; the class 3.72 vs 4.02 ms single-stream), but the two-stream step is not (278.9 vs 280.0 images/s): a
+// launch that fills every CU's slot leaves the data-gradient chain beside it nothing to overlap with.
+int pick_splits_s4(long M, int tiles) {
+    static int slots = -1;
+    if (slots < 0) {
+        const char* e = getenv("MI_WGRAD_S4_SLOTS");
+        slots = e ? atoi(e) : 512;
+        if (slots < 64) slots = 512;
+    }
+    const long steps = (M + 31) / 32;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= 128; ++s) {
+        const long per = (steps + s - 1) / s;
+        if (s > 1 && per < 16) break;
+        const long rounds = ((long)tiles * s + slots - 1) / slots;
+        const double cost = (double)rounds * (double)(per + 12);
+        if (cost < best_cost - 1e-9) {
+            best_cost = cost;
+            best = s;
+        }
+    }
+    return best;
+}
+
 inline bool use_tn256(int O, int I, int ksize, int pad, int stride, int Ha, int Ho, int Wa, int Wo) {
     static int mode = -2;
     if (mode == -2) {
@@ -1111,7 +1138,7 @@ extern "C" size_t mi_conv_wgrad_workspace(int B, int Ho, int Wo, int O, int I, i
         if (n2 > need) need = n2;
     }
     if (ksize == 1) {          // the deep-stream 1x1 kernel: 32-pixel steps on the 128 x 128 tile
-        const size_t n4 = (size_t)pick_splits256(M, tiles) * O * I * sizeof(float);
+        const size_t n4 = (size_t)(pick_splits256(M, tiles) > pick_splits_s4(M, tiles) ? pick_splits256(M, tiles) : pick_splits_s4(M, tiles)) * O * I * sizeof(float);
         if (n4 > need) need = n4;
     }
     if (ksize == 3) {          // the fused-row kernel may be chosen for any dilation <= 8: budget for its largest split count
@@ -1276,7 +1303,7 @@ extern "C" int mi_conv_wgrad(const void* dy, const void* x, float* dw, int B, in
     const bool deep = !wide && s4_mode && ksize == 1 && pad == 0 && stride == 1 && Ha == Ho && Wa == Wo && (long)M * (O > I ? O : I) * 2 < (1L << 31);
     if (deep) {
         p.i_tiles = (I + TI - 1) / TI;
-        p.S = pick_splits256(M, p.o_tiles * p.i_tiles);
+        p.S = pick_splits_s4(M, p.o_tiles * p.i_tiles);
         const long steps4 = (M + KP4 - 1) / KP4;
         p.rows_per_split = (int)(((steps4 + p.S - 1) / p.S) * KP4);
         static std::atomic<uint64_t> attr4;
