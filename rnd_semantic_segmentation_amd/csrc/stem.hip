@@ -118,27 +118,34 @@ extern "C" int mi_stem_pool_bwd(const void* dpool, const uint8_t* idx, const flo
 namespace {
 __global__ __launch_bounds__(256) void stem_im2col_kernel(const __bf16* __restrict__ x, bf16x8* __restrict__ col, int B, int H, int W, int Ho, int Wo,
                                                           int groups) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const long total = (long)B * Ho * Wo * groups;
-    if (idx >= total) return;
-    const int kg = (int)(idx % groups);
-    const long m = idx / groups;
-    const int wo = (int)(m % Wo);
-    const int ho = (int)((m / Wo) % Ho);
-    const int b = (int)(m / ((long)Wo * Ho));
+    // grid: x = 256-thread chunks of one output row's (wo, column group) pairs, y = (b, ho): no runtime divisions per thread
+    const int in_row = blockIdx.x * 256 + threadIdx.x;
+    if (in_row >= Wo * groups) return;
+    const int wo = in_row / groups, kg = in_row - wo * groups;
+    const int ho = blockIdx.y % Ho, b = blockIdx.y / Ho;
+    // first column of this thread's eight, then (c, ky, kx) advance like an odometer
+    int k = kg * 8;
+    int c = k / 49, r = k - c * 49, ky = r / 7, kx = r - ky * 7;
+    const __bf16* img = x + (long)b * H * W * 3;
+    // (eight unconditional loads with the out-of-image taps zeroed afterwards measured slower: 244 vs 203 us)
     bf16x8 v;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const int k = kg * 8 + e;
         __bf16 val = (__bf16)0.f;
-        if (k < 147) {
-            const int c = k / 49, r = k - c * 49, ky = r / 7, kx = r - ky * 7;
+        if (k + e < 147) {
             const int h = 2 * ho - 3 + ky, w = 2 * wo - 3 + kx;
-            if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) val = x[(((long)b * H + h) * W + w) * 3 + c];
+            if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) val = img[((long)h * W + w) * 3 + c];
         }
         v[e] = val;
+        if (++kx == 7) {
+            kx = 0;
+            if (++ky == 7) {
+                ky = 0;
+                ++c;
+            }
+        }
     }
-    col[idx] = v;
+    col[((long)blockIdx.y * Wo + wo) * groups + kg] = v;
 }
 }  // namespace
 
@@ -147,9 +154,9 @@ extern "C" int mi_stem_im2col(const void* x_bf16_nhwc, void* col_bf16, int B, in
     MI_REQUIRE(ncols >= 152 && ncols % 8 == 0 && ncols <= 256, "mi_stem_im2col: ncols=%d (a multiple of 8 in [152, 256])", ncols);
     MI_REQUIRE(Ho == (H + 6 - 7) / 2 + 1 && Wo == (W + 6 - 7) / 2 + 1, "mi_stem_im2col: output size must be that of a 7x7/2/3 conv");
     MI_REQUIRE(mi_aligned16(col_bf16), "mi_stem_im2col: alignment");
-    const long total = (long)B * Ho * Wo * (ncols / 8);
-    hipLaunchKernelGGL(stem_im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x_bf16_nhwc,
-                       (bf16x8*)col_bf16, B, H, W, Ho, Wo, ncols / 8);
+    MI_REQUIRE((long)B * Ho < 65536, "mi_stem_im2col: B * Ho = %ld exceeds the grid", (long)B * Ho);
+    hipLaunchKernelGGL(stem_im2col_kernel, dim3((unsigned)((Wo * (ncols / 8) + 255) / 256), (unsigned)(B * Ho)), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16*)x_bf16_nhwc, (bf16x8*)col_bf16, B, H, W, Ho, Wo, ncols / 8);
     MI_CHECK_LAUNCH("mi_stem_im2col");
     return MI_OK;
 }
