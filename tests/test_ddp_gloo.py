@@ -284,3 +284,103 @@ def test_two_rank_gloo_overlapped_bucket_exchange_and_bf16_payload(tmp_path):
         assert torch.equal(r0["bf16"][tag], exp) and torch.equal(r1["bf16"][tag], exp)
         err = (r0["bf16"][tag] - want).abs().max() / want.abs().max()
         assert err < 2.0 ** -7, err                                         # two bf16 roundings of an fp32 average
+
+
+# ------------------------------------------------------------------------------------------------ synchronised BatchNorm (host logic)
+class _TorchBnKernels:
+    """Stand-ins for the BatchNorm entry points of kernels.py on CPU tensors (test infrastructure: the product path has no CPU
+    kernels) - the same contracts: RAW per-channel sums over NHWC tensors, packed sign bits, fp32 arithmetic."""
+
+    @staticmethod
+    def bn_colsum2(y, pilot):
+        d = y.float().reshape(-1, y.shape[-1]) - pilot
+        return d.sum(0), (d * d).sum(0)
+
+    @staticmethod
+    def bn_apply(y, mean, scale, beta, res=None, relu=False, want_mask=False):
+        out = (y.float() - mean) * scale + beta
+        if res is not None:
+            out = out + res.float()
+        if relu:
+            out = out.relu()
+        out = out.to(y.dtype)
+        return (out, (out.float() > 0)) if want_mask else out
+
+    @staticmethod
+    def relu_mask(g, bits):
+        return (g.float() * bits).to(g.dtype)
+
+    @staticmethod
+    def bn_bwd_colsums(g, y, mean, invstd, relu_bits=None):
+        gf = g.float() * relu_bits if relu_bits is not None else g.float()
+        xhat = (y.float() - mean) * invstd
+        C = y.shape[-1]
+        return gf.reshape(-1, C).sum(0), (gf * xhat).reshape(-1, C).sum(0)
+
+    @staticmethod
+    def bn_bwd_apply(g, y, mean, invstd, gamma, dbeta, dgamma, count, relu_bits=None):
+        gf = g.float() * relu_bits if relu_bits is not None else g.float()
+        xhat = (y.float() - mean) * invstd
+        return (gamma * invstd * (gf - dbeta / count - xhat * dgamma / count)).to(g.dtype)
+
+
+def _syncbn_worker(rank, world, port, tmpdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    try:
+        for name in ("bn_colsum2", "bn_apply", "relu_mask", "bn_bwd_colsums", "bn_bwd_apply"):
+            setattr(engine.K, name, getattr(_TorchBnKernels, name))
+        g = torch.Generator().manual_seed(5)
+        B, H, W, C = 4, 6, 5, 16
+        y_all = torch.randn(B, H, W, C, generator=g) * 1.5 + torch.randn(C, generator=g)
+        res_all = torch.randn(B, H, W, C, generator=g)
+        gout_all = torch.randn(B, H, W, C, generator=g)
+
+        def run(sl, sync):
+            bn = torch.nn.BatchNorm2d(C)
+            with torch.no_grad():
+                bn.weight.copy_(torch.linspace(0.5, 1.5, C))
+                bn.bias.copy_(torch.linspace(-0.2, 0.2, C))
+            bn._mi_sync = sync
+            y = y_all[sl].clone().requires_grad_(True)
+            res = res_all[sl].clone().requires_grad_(True)
+            out = engine.BnActFn.apply(y, bn.weight, bn.bias, bn, res, True)
+            out.backward(gout_all[sl])
+            return out.detach(), y.grad, res.grad, bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_mean.clone(), bn.running_var.clone()
+
+        half = slice(rank * 2, rank * 2 + 2)
+        out_s, dy_s, dres_s, dg_s, db_s, rm_s, rv_s = run(half, True)
+        dist.all_reduce(dg_s)
+        dist.all_reduce(db_s)
+        out_f, dy_f, dres_f, dg_f, db_f, rm_f, rv_f = run(slice(0, B), False)
+        # torch's own BatchNorm2d on the full batch as the third witness
+        bn = torch.nn.BatchNorm2d(C)
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, C))
+            bn.bias.copy_(torch.linspace(-0.2, 0.2, C))
+        yt = y_all.permute(0, 3, 1, 2).clone().requires_grad_(True)
+        ot = (bn(yt) + res_all.permute(0, 3, 1, 2)).relu()
+        ot.backward(gout_all.permute(0, 3, 1, 2))
+        close = lambda a, b, tol=2e-5: float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))
+        assert close(out_f, ot.detach().permute(0, 2, 3, 1)) and close(dy_f, yt.grad.permute(0, 2, 3, 1)), "single-process BnActFn vs torch"
+        assert close(dg_f, bn.weight.grad) and close(db_f, bn.bias.grad) and close(rm_f, bn.running_mean) and close(rv_f, bn.running_var)
+        # synchronised halves == the full batch: outputs, input / residual gradients of this rank's samples, summed affine gradients,
+        # running statistics (global mean, unbiased global variance)
+        assert close(out_s, out_f[half]) and close(dy_s, dy_f[half]) and close(dres_s, dres_f[half])
+        assert close(dg_s, dg_f) and close(db_s, db_f) and close(rm_s, rm_f) and close(rv_s, rv_f)
+        # without the exchange the halves differ from the full batch
+        out_l = run(half, False)[0]
+        assert not close(out_l, out_f[half], 1e-3)
+        open(os.path.join(tmpdir, "syncbn_ok_%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_synchronised_batchnorm_equals_full_batch(tmp_path):
+    """engine.BnActFn with `_mi_sync` (train_distill.py:53 SyncBatchNorm semantics) in a 2-rank gloo job, the BatchNorm kernels replaced
+    by torch stand-ins with the same contracts: the exchange of RAW sums, the global pixel count, the per-rank affine gradients and
+    the running-statistics update reproduce one process on the full batch - and torch.nn.BatchNorm2d itself."""
+    port = _free_port()
+    mp.spawn(_syncbn_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert all(os.path.exists(os.path.join(str(tmp_path), "syncbn_ok_%d" % r)) for r in range(2))
