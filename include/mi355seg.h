@@ -281,6 +281,69 @@ size_t mi_structure_loss_workspace(int B, int H, int W);
 int mi_structure_loss(const float* pred, const float* mask, int B, int H, int W, float* out, float* grad, float grad_scale,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- PraNet path, the network (csrc/gconv.hip, csrc/gnet.hip) ---------------------------------------------------
+ * Operands are channel-slice VIEWS of NHWC tensors: a pointer to channel 0 of the slice in pixel 0 and `ld`, the elements per pixel
+ * row of the tensor the slice lives in (ld >= channels).  torch.split / torch.cat of the Res2Net bottleneck (Res2Net_v1b.py:68-84),
+ * of RFB_modified (PraNet_Res2Net.py:50-54) and of the partial decoder (:84-91) therefore never copy.  Any channel count; alignment
+ * only selects the access width (16 / 4 / 2 bytes).  bf16 unless a parameter says fp32.
+ *
+ * mi_gconv: nn.Conv2d of every shape the path has (kh x kw taps, per-axis stride / padding / dilation, optional bias) and, with
+ *   MI_GATHER_DGRAD on the transposed pack, its data gradient.  a [B][Ha][Wa][Ca], out [B][Ho][Wo][N] (the OUTPUT of the launch:
+ *   in DGRAD mode that is the forward conv's input shape and a is the forward conv's output gradient).
+ *   wp: [kh*kw][roundup(N,32)][roundup(Ca,32)] bf16 from mi_gconv_pack_multi (zero padded).
+ *   stats (optional): float[ceil(M/128)][2][N], per 128-pixel tile the column sums and sums of squares of the bf16-rounded outputs -
+ *   the first level of nn.BatchNorm2d's batch statistics (PraNet_Res2Net.py:13), finished by mi_gbn_finalize.
+ *   out_f32: store fp32 (the one-channel side maps; N <= 32). */
+size_t mi_gconv_pack_elems(int O, int I, int kh, int kw);
+/* table (device, int64[n_desc][8]) rows: {w_off, wp_off, wpt_off or -1, O, I, kh*kw, first_block, 0}; w_off indexes wflat (fp32 OIHW
+ * masters), wp_off / wpt_off the packed forward [t][Opad][Ipad] and data-gradient [t][Ipad][Opad] operands; a block packs 1024 elements,
+ * total_blocks = sum ceil(kh*kw*Opad*Ipad / 1024). */
+int mi_gconv_pack_multi(const float* wflat, void* wp_bf16, void* wpt_bf16, const int64_t* table_dev, int n_desc, int total_blocks, void* stream);
+size_t mi_gconv_stats_elems(int B, int Ho, int Wo, int N);
+int mi_gconv(const void* a, long lda, const void* wp, void* out, long ldo, int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N,
+             int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int mode, const float* bias, float* stats, int out_f32,
+             void* stream);
+/* dw[o][i][ky][kx] (+)= sum_m dy[m][o] * x[src(m,ky,kx)][i], fp32 OIHW; split-K slabs summed in a fixed order. */
+size_t mi_gconv_wgrad_workspace(int B, int Ho, int Wo, int O, int I, int kh, int kw);
+int mi_gconv_wgrad(const void* dy, long ldy, const void* x, long ldx, float* dw, int B, int Ha, int Wa, int I, int Ho, int Wo, int O,
+                   int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw_, int accumulate, void* workspace, size_t workspace_bytes,
+                   void* stream);
+/* nn.BatchNorm2d in train() from the conv's tile statistics: mean, invstd = rsqrt(biased var + eps), scale = gamma * invstd,
+ * shift = beta - mean * scale, and the running-statistics update (momentum; unbiased variance), all per channel.  count = pixels. */
+int mi_gbn_finalize(const float* partials, int tiles, int C, long count, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                    float momentum, float eps, float* mean_out, float* invstd_out, float* scale_out, float* shift_out, void* stream);
+/* eval(): scale = gamma * rsqrt(running_var + eps), shift = beta - running_mean * scale */
+int mi_gbn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, float* scale, float* shift, int C,
+                void* stream);
+/* out = relu?(y * scale[c] + shift[c] (+ add)); out bf16, or fp32 when out_f32 */
+int mi_gbn_apply(const void* y, long ldy, const float* scale, const float* shift, const void* add, long ldadd, void* out, long ldo, int out_f32, long M, int C,
+                 int relu, void* stream);
+/* dbeta[c] (+)= sum_m g'[m][c], dgamma[c] (+)= sum_m g'[m][c] * (y[m][c] - mean[c]) * invstd[c]; g' = g where mask > 0 (mask: the layer's
+ * ReLU output, or NULL); y NULL: dbeta only (a conv bias gradient).  g / mask fp32 when the flags say so. */
+size_t mi_gcolsum_workspace(long M, int C);
+int mi_gbn_bwd_sums(const void* g, long ldg, int g_f32, const void* y, long ldy, const void* mask, long ldm, int mask_f32, const float* mean,
+                    const float* invstd, long M, int C, float* dbeta, float* dgamma, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* dy = gamma * invstd * (g' - dbeta * inv_count - xhat * dgamma * inv_count) */
+int mi_gbn_bwd_apply(const void* g, long ldg, int g_f32, const void* y, long ldy, const void* mask, long ldm, int mask_f32, const float* mean,
+                     const float* invstd, const float* gamma, const float* dbeta, const float* dgamma, float inv_count, void* dy, long lddy, long M, int C,
+                     void* stream);
+/* out = a op b on views.  op: 0 add (sp + spx[i], Res2Net_v1b.py:72; x + crop, PraNet_Res2Net.py:140), 1 mul (partial decoder, :81-83),
+ * 2 copy, 3 a where b > 0 else 0 (ReLU backward).  dtype: 0 bf16, 1 fp32, 2 copy fp32 -> bf16, 3 copy bf16 -> fp32. */
+int mi_gbinary(int op, int dtype, const void* a, long lda, const void* b, long ldb, void* out, long ldo, long M, int C, void* stream);
+/* AvgPool2d(k, stride, pad) with count_include_pad=True (include_pad != 0; Res2Net_v1b.py:40) or AvgPool2d(stride, stride, ceil_mode=True,
+ * count_include_pad=False) (include_pad == 0; Res2Net_v1b.py:122-123).  backward != 0: x is d loss / d input (written), out is d loss / d output. */
+int mi_gavgpool(const void* x, long ldx, void* out, long ldo, int B, int H, int W, int C, int Ho, int Wo, int k, int stride, int pad, int include_pad,
+                int backward, void* stream);
+/* F.interpolate / nn.Upsample, mode='bilinear' (PraNet_Res2Net.py:67,127-177): src = align_corners ? scale * dst : max(scale * (dst + 0.5) - 0.5, 0).
+ * scale_h / scale_w as ATen computes them: align_corners: (in - 1) / (out - 1); otherwise 1 / scale_factor when the caller gave a
+ * scale_factor, in / out when it gave a size.  backward != 0: x is d loss / d input (written), out is d loss / d output (gather form,
+ * fixed summation order). */
+int mi_gresize(const void* x, long ldx, void* out, long ldo, int f32, int B, int H, int W, int C, int Ho, int Wo, int align_corners, float scale_h, float scale_w,
+               int backward, void* stream);
+/* reverse attention (PraNet_Res2Net.py:131-133): out[m][c] = (1 - sigmoid(gate[m])) * feat[m][c], gate fp32 [M]; backward: dfeat and dgate */
+int mi_gra_fwd(const float* gate, const void* feat, long ldfeat, void* out, long ldo, long M, int C, void* stream);
+int mi_gra_bwd(const float* gate, const void* feat, long ldfeat, const void* dy, long lddy, void* dfeat, long lddf, float* dgate, long M, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,23 @@ SIGNATURES = {
     "mi_bn_colsum2": (I, [P, P, L, I, P, P, P, Z, P]),
     "mi_bn_bwd_colsums": (I, [P, P, P, P, P, L, I, P, P, P, Z, P]),
     "mi_bn_bwd_apply": (I, [P, P, P, P, P, P, P, F, P, P, L, I, P]),
+    "mi_gconv_pack_elems": (Z, [I] * 4),
+    "mi_gconv_pack_multi": (I, [P, P, P, P, I, I, P]),
+    "mi_gconv_stats_elems": (Z, [I] * 4),
+    "mi_gconv": (I, [P, L, P, P, L] + [I] * 16 + [P, P, I, P]),
+    "mi_gconv_wgrad_workspace": (Z, [I] * 7),
+    "mi_gconv_wgrad": (I, [P, L, P, L, P] + [I] * 16 + [P, Z, P]),
+    "mi_gbn_finalize": (I, [P, I, I, L, P, P, P, P, F, F, P, P, P, P, P]),
+    "mi_gbn_fold": (I, [P, P, P, P, F, P, P, I, P]),
+    "mi_gbn_apply": (I, [P, L, P, P, P, L, P, L, I, L, I, I, P]),
+    "mi_gcolsum_workspace": (Z, [L, I]),
+    "mi_gbn_bwd_sums": (I, [P, L, I, P, L, P, L, I, P, P, L, I, P, P, I, P, Z, P]),
+    "mi_gbn_bwd_apply": (I, [P, L, I, P, L, P, L, I, P, P, P, P, P, F, P, L, L, I, P]),
+    "mi_gbinary": (I, [I, I, P, L, P, L, P, L, L, I, P]),
+    "mi_gavgpool": (I, [P, L, P, L] + [I] * 11 + [P]),
+    "mi_gresize": (I, [P, L, P, L, I] + [I] * 7 + [F, F, I, P]),
+    "mi_gra_fwd": (I, [P, P, L, P, L, L, I, P]),
+    "mi_gra_bwd": (I, [P, P, L, P, L, P, L, P, L, I, P]),
 }
 
 _lib = None

@@ -1,0 +1,615 @@
+// General implicit-GEMM convolution for gfx950: any kh x kw taps, per-axis stride / padding / dilation, any channel counts,
+// operands given as channel-slice VIEWS of NHWC bf16 tensors (pointer to channel 0 of the slice + elements per pixel row),
+// so that torch.split / torch.cat of the reference's Res2Net bottleneck (core/models/classifiers/pranet/Res2Net_v1b.py:68-84)
+// and of the RFB / partial decoder (PraNet_Res2Net.py:50-57,84-91) are views, never copies.
+//
+//   forward    out[m][n] = sum_{t,c} a[src(m,t)][c] * wp[t][n][c]  (+ bias[n])      m = (b,ho,wo)
+//   data grad  the same kernel in gather mode MI_GATHER_DGRAD on the transposed pack
+//   weight grad  dw[o][i][t] = sum_m dy[m][o] * x[src(m,t)][i]   (gwgrad_kernel: split-K slabs + fixed-order reducer)
+//
+// Replaces nn.Conv2d forward / convolution_backward for every conv of the PraNet path: 26/52/104/208-channel
+// 3x3 group convs, 1x3 / 3x1 / 1x5 / 5x1 / 1x7 / 7x1 and dilated 3 / 5 / 7 convs of RFB_modified, 5x5 reverse-attention convs,
+// the 3-channel stem conv and the one-channel side outputs.  Channel counts that are not multiples of the 32-channel K chunk
+// are padded in LDS (zero fill on load), never in HBM.
+//
+// Tile: 128 pixels x BN channels (BN = 32 | 64 | 128), 4 waves, each 32 rows x BN columns of v_mfma_f32_16x16x32_bf16;
+// operands are register-staged (global -> VGPR -> LDS, double buffered): the sources are arbitrary-alignment slices, which the
+// LDS-DMA path of igemm_nt.hip (16-byte granules) cannot fetch.  The epilogue stages the tile in LDS, stores rows with
+// the widest access the view's alignment allows, and (optionally) emits per-tile column sums / sums of squares of the ROUNDED
+// outputs - the first level of the BatchNorm batch statistics (nn.BatchNorm2d in train(), PraNet_Res2Net.py:13,17-19) - so
+// that no separate pass over the conv output is needed for them.
+#include "mi_common.h"
+
+namespace {
+
+constexpr int GBM = 128;       // pixels per tile
+constexpr int GKC = 32;        // channels per K chunk (one MFMA k)
+constexpr int GRS = 40;        // LDS row stride in elements (80 B): 16 consecutive rows start in 16 distinct 16-B bank groups
+
+struct GConvP {
+    const __bf16* A;
+    const __bf16* Wp;
+    void* out;
+    const float* bias;
+    float* stats;
+    long lda, ldo;
+    int M, N, Ca, Cpad, Npad, T;
+    int Ha, Wa, Ho, Wo;
+    int kw, sh, sw, ph, pw, dh, dw, mode, nchunks;
+};
+
+template <int VEC>
+__device__ __forceinline__ void gload16(const __bf16* src, int c0, int C, bool ok, bf16x8 (&r)[2]) {
+    // 16 channels c0 .. c0+15 of one pixel row; channels >= C (and everything when !ok) read as zero
+    if constexpr (VEC == 8) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = c0 + 8 * h;
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
+            if (ok && c < C) v = *reinterpret_cast<const bf16x8*>(src + c);
+            r[h] = v;
+        }
+    } else if constexpr (VEC == 2) {
+        union { bf16x8 v[2]; uint32_t u[8]; } x;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c0 + 2 * j;
+            x.u[j] = (ok && c < C) ? *reinterpret_cast<const uint32_t*>(src + c) : 0u;
+        }
+        r[0] = x.v[0];
+        r[1] = x.v[1];
+    } else {
+        union { bf16x8 v[2]; uint16_t u[16]; } x;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int c = c0 + j;
+            x.u[j] = (ok && c < C) ? *reinterpret_cast<const uint16_t*>(src + c) : (uint16_t)0;
+        }
+        r[0] = x.v[0];
+        r[1] = x.v[1];
+    }
+}
+
+template <int BN, bool OUTF32>
+struct GSmem {
+    static constexpr int AB = 2 * (GBM + BN) * GRS * 2;                               // double-buffered operand tiles
+    static constexpr int CS = OUTF32 ? GBM * (BN + 4) * 4 : GBM * (BN + 8) * 2;       // staged output tile
+    static constexpr int RED = 2 * (256 / BN > 0 ? 256 / BN : 1) * BN * 4;            // stats partials of the row groups
+    static constexpr int BYTES = (AB > CS + RED ? AB : CS + RED);
+};
+
+template <int BN, int AVEC, int OVEC, bool OUTF32>
+__global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
+    constexpr int NT = BN / 16;
+    __shared__ __attribute__((aligned(16))) char smem[GSmem<BN, OUTF32>::BYTES];
+    __bf16* As = reinterpret_cast<__bf16*>(smem);                         // [2][GBM][GRS]
+    __bf16* Bs = As + 2 * GBM * GRS;                                      // [2][BN][GRS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * GBM, n0 = blockIdx.y * BN;
+
+    // A loader: thread -> (row, half): 16 channels of one pixel per K chunk
+    const int arow = tid >> 1, ahalf = tid & 1;
+    const int am = m0 + arow;
+    const bool am_ok = am < p.M;
+    int ab, aoh, aow;
+    {
+        const int hw = p.Ho * p.Wo;
+        const int mm = am_ok ? am : 0;
+        ab = mm / hw;
+        const int rem = mm - ab * hw;
+        aoh = rem / p.Wo;
+        aow = rem - aoh * p.Wo;
+    }
+    // B loader: thread -> (n row, 8-channel chunk); BN = 128 takes two rows per thread
+    constexpr int BROWS = (BN * 4 + 255) / 256;
+    const int bch = tid & 3;
+
+    bf16x8 ra[2], rb[BROWS];
+    auto load = [&](int it) {
+        const int tap = it / p.nchunks, kc = it - tap * p.nchunks;
+        const int ky = tap / p.kw, kx = tap - ky * p.kw;
+        bool ok = am_ok;
+        int ih, iw;
+        if (p.mode == MI_GATHER_FWD) {
+            ih = aoh * p.sh + ky * p.dh - p.ph;
+            iw = aow * p.sw + kx * p.dw - p.pw;
+        } else {
+            const int nh = aoh + p.ph - ky * p.dh, nw = aow + p.pw - kx * p.dw;
+            ih = nh / p.sh;
+            iw = nw / p.sw;
+            ok = ok && nh >= 0 && nw >= 0 && ih * p.sh == nh && iw * p.sw == nw;
+        }
+        ok = ok && (unsigned)ih < (unsigned)p.Ha && (unsigned)iw < (unsigned)p.Wa;
+        const long pix = ok ? ((long)ab * p.Ha + ih) * p.Wa + iw : 0;
+        gload16<AVEC>(p.A + pix * p.lda, kc * GKC + ahalf * 16, p.Ca, ok, ra);
+        const __bf16* wt = p.Wp + ((long)tap * p.Npad) * p.Cpad + kc * GKC + bch * 8;
+#pragma unroll
+        for (int j = 0; j < BROWS; ++j) {
+            const int nr = (tid >> 2) + j * 64;
+            const int n = n0 + nr;
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+            if (nr < BN && n < p.Npad) v = *reinterpret_cast<const bf16x8*>(wt + (long)n * p.Cpad);
+            rb[j] = v;
+        }
+    };
+    auto stash = [&](int buf) {
+        __bf16* a = As + buf * GBM * GRS + arow * GRS + ahalf * 16;
+        *reinterpret_cast<bf16x8*>(a) = ra[0];
+        *reinterpret_cast<bf16x8*>(a + 8) = ra[1];
+#pragma unroll
+        for (int j = 0; j < BROWS; ++j) {
+            const int nr = (tid >> 2) + j * 64;
+            if (nr < BN) *reinterpret_cast<bf16x8*>(Bs + buf * BN * GRS + nr * GRS + bch * 8) = rb[j];
+        }
+    };
+
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int total = p.T * p.nchunks;
+    const int frow = lane & 15, fk = (lane >> 4) * 8;
+    load(0);
+    stash(0);
+    __syncthreads();
+    for (int it = 0; it < total; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < total) load(it + 1);
+        const __bf16* a = As + buf * GBM * GRS + (wave * 32 + frow) * GRS + fk;
+        const __bf16* b = Bs + buf * BN * GRS + frow * GRS + fk;
+        bf16x8 fa[2], fb[NT];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(a + i * 16 * GRS);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(b + j * 16 * GRS);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        if (it + 1 < total) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: (+ bias) -> LDS image of the tile -> row stores (+ column statistics of the rounded values)
+    const int fq = lane >> 4;
+    if constexpr (OUTF32) {
+        float* Cs = reinterpret_cast<float*>(smem);
+        constexpr int CSW = BN + 4;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + j * 16 + frow;
+            const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Cs[(wave * 32 + i * 16 + fq * 4 + r) * CSW + j * 16 + frow] = acc[i][j][r] + bv;
+        }
+        __syncthreads();
+        float* out = reinterpret_cast<float*>(p.out);
+        for (int idx = tid; idx < GBM * BN; idx += 256) {
+            const int row = idx / BN, col = idx - row * BN;
+            const int m = m0 + row, n = n0 + col;
+            if (m < p.M && n < p.N) out[(long)m * p.ldo + n] = Cs[row * CSW + col];
+        }
+    } else {
+        __bf16* Cs = reinterpret_cast<__bf16*>(smem);
+        constexpr int CSW = BN + 8;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + j * 16 + frow;
+            const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Cs[(wave * 32 + i * 16 + fq * 4 + r) * CSW + j * 16 + frow] = (__bf16)(acc[i][j][r] + bv);
+        }
+        __syncthreads();
+        __bf16* out = reinterpret_cast<__bf16*>(p.out);
+        constexpr int G = BN / OVEC;                 // stores per row
+        for (int idx = tid; idx < GBM * G; idx += 256) {
+            const int row = idx / G, cg = idx - row * G;
+            const int m = m0 + row, n = n0 + cg * OVEC;
+            if (m < p.M && n < p.N) {
+                __bf16* dst = out + (long)m * p.ldo + n;
+                const __bf16* src = Cs + row * CSW + cg * OVEC;
+                if constexpr (OVEC == 8) *reinterpret_cast<bf16x8*>(dst) = *reinterpret_cast<const bf16x8*>(src);
+                else if constexpr (OVEC == 2) *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(src);
+                else *dst = *src;
+            }
+        }
+        if (p.stats) {
+            // thread -> (column, row group): fixed-order sums over the group's rows, then over the groups
+            constexpr int RG = 256 / BN > 0 ? 256 / BN : 1;      // 8 | 4 | 2 row groups
+            constexpr int RPG = GBM / RG;
+            float* red = reinterpret_cast<float*>(smem + GSmem<BN, false>::CS);
+            const int col = tid % BN, rg = tid / BN;
+            if (rg < RG) {
+                float s1 = 0.f, s2 = 0.f;
+                for (int r = 0; r < RPG; ++r) {
+                    const int row = rg * RPG + r;
+                    if (m0 + row < p.M) {
+                        const float v = (float)Cs[row * CSW + col];
+                        s1 += v;
+                        s2 += v * v;
+                    }
+                }
+                red[(rg * 2 + 0) * BN + col] = s1;
+                red[(rg * 2 + 1) * BN + col] = s2;
+            }
+            __syncthreads();
+            if (tid < BN && n0 + tid < p.N) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int g = 0; g < RG; ++g) {
+                    s1 += red[(g * 2 + 0) * BN + tid];
+                    s2 += red[(g * 2 + 1) * BN + tid];
+                }
+                float* st = p.stats + (long)blockIdx.x * 2 * p.N;
+                st[n0 + tid] = s1;
+                st[p.N + n0 + tid] = s2;
+            }
+        }
+    }
+}
+
+template <int BN, int AVEC, int OVEC, bool OUTF32>
+void glaunch(const GConvP& p, hipStream_t s) {
+    dim3 grid((p.M + GBM - 1) / GBM, (p.N + BN - 1) / BN);
+    hipLaunchKernelGGL((gconv_kernel<BN, AVEC, OVEC, OUTF32>), grid, dim3(256), 0, s, p);
+}
+
+template <int BN, int AVEC>
+void glaunch_o(const GConvP& p, int ovec, bool f32, hipStream_t s) {
+    if (f32) {
+        if constexpr (BN == 32) glaunch<32, AVEC, 1, true>(p, s);
+        return;
+    }
+    if (ovec == 8) glaunch<BN, AVEC, 8, false>(p, s);
+    else if (ovec == 2) glaunch<BN, AVEC, 2, false>(p, s);
+    else glaunch<BN, AVEC, 1, false>(p, s);
+}
+
+template <int BN>
+void glaunch_a(const GConvP& p, int avec, int ovec, bool f32, hipStream_t s) {
+    if (avec == 8) glaunch_o<BN, 8>(p, ovec, f32, s);
+    else if (avec == 2) glaunch_o<BN, 2>(p, ovec, f32, s);
+    else glaunch_o<BN, 1>(p, ovec, f32, s);
+}
+
+int view_vec(const void* ptr, long ld, int C) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+    if ((a & 15) == 0 && ld % 8 == 0 && C % 8 == 0) return 8;
+    if ((a & 3) == 0 && ld % 2 == 0 && C % 2 == 0) return 2;
+    return 1;
+}
+
+inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+constexpr int WTO = 64, WTI = 64, WKP = 32;     // output tile 64 (o) x 64 (i), 32 pixels per K step
+constexpr int WRS = 144;                        // LDS bytes per pixel row of a tile: 64 channels bf16 + 16 B pad (8-B aligned for the transposed reads)
+
+struct GWgP {
+    const __bf16* dY;
+    const __bf16* X;
+    float* slab;
+    long ldy, ldx;
+    int M, O, I, T;
+    int Ho, Wo, Ha, Wa;
+    int kw, sh, sw, ph, pw, dh, dw;
+    int S, rows_per_split, o_tiles, i_tiles;
+};
+
+template <int VEC>
+__device__ __forceinline__ bf16x8 gload8(const __bf16* src, int c0, int C, bool ok) {
+    union { bf16x8 v; uint32_t u[4]; uint16_t h[8]; } x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x.u[j] = 0u;
+    if constexpr (VEC == 8) {
+        if (ok && c0 < C) x.v = *reinterpret_cast<const bf16x8*>(src + c0);
+    } else if constexpr (VEC == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (ok && c0 + 2 * j < C) x.u[j] = *reinterpret_cast<const uint32_t*>(src + c0 + 2 * j);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (ok && c0 + j < C) x.h[j] = *reinterpret_cast<const uint16_t*>(src + c0 + j);
+    }
+    return x.v;
+}
+
+__device__ __forceinline__ s16x4 tr_read(const char* lds_generic) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_generic));
+}
+
+// One workgroup = one (K split, tap, o tile, i tile).  Both operands have the contraction index (pixel) as their memory row, so the
+// tiles are staged pixel-major and the MFMA fragments come from ds_read_b64_tr_b16 (hardware transpose), as in igemm_tn.hip.
+template <int YVEC, int XVEC>
+__global__ __launch_bounds__(256) void gwgrad_kernel(GWgP p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * WKP * WRS];      // [buf][dy | x][32 pixels][144 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles = p.o_tiles * p.i_tiles;
+    int id = blockIdx.x;
+    const int tile = id % tiles;
+    id /= tiles;
+    const int t = id % p.T, split = id / p.T;
+    const int ot = tile / p.i_tiles, itile = tile - ot * p.i_tiles;
+    const int o0 = ot * WTO, i0 = itile * WTI;
+    const int ky = t / p.kw, kx = t - ky * p.kw;
+    const int m_begin = split * p.rows_per_split;
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+    const int nk = m_end > m_begin ? (m_end - m_begin + WKP - 1) / WKP : 0;
+    const int lpx = tid >> 3, lch = tid & 7;          // loader: pixel row of the step, 8-channel chunk
+    const int hw = p.Ho * p.Wo;
+
+    bf16x8 ry, rx;
+    auto load = [&](int kt) {
+        const int m = m_begin + kt * WKP + lpx;
+        const bool ok = m < m_end;
+        const int mm = ok ? m : 0;
+        ry = gload8<YVEC>(p.dY + (long)mm * p.ldy, o0 + lch * 8, p.O, ok);
+        const int b = mm / hw, rem = mm - b * hw;
+        const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+        const int ih = oh * p.sh + ky * p.dh - p.ph, iw = ow * p.sw + kx * p.dw - p.pw;
+        const bool xok = ok && (unsigned)ih < (unsigned)p.Ha && (unsigned)iw < (unsigned)p.Wa;
+        const long pix = xok ? ((long)b * p.Ha + ih) * p.Wa + iw : 0;
+        rx = gload8<XVEC>(p.X + pix * p.ldx, i0 + lch * 8, p.I, xok);
+    };
+    auto stash = [&](int buf) {
+        char* sy = smem + buf * (2 * WKP * WRS) + lpx * WRS + lch * 16;
+        *reinterpret_cast<bf16x8*>(sy) = ry;
+        *reinterpret_cast<bf16x8*>(sy + WKP * WRS) = rx;
+    };
+
+    // D rows = i (A operand = X^T), D cols = o (B operand = dY^T); wave owns 32 (i) x 32 (o)
+    const int wi = wave & 1, wo = wave >> 1;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // transposed read: lanes 16g .. 16g+15 fetch pixel rows 4g + q (q = (lane & 15) >> 2; +16 for the second half of k), the lane's
+    // 8 bytes at channel 4 * (lane & 3) of the 16-channel block; lane i of the group receives channel i of the four rows
+    const int g = lane >> 4, q = (lane & 15) >> 2, pc = lane & 3;
+    const int row_off = (g * 4 + q) * WRS + pc * 8;
+
+    if (nk > 0) {
+        load(0);
+        stash(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) load(kt + 1);
+            const char* sy = smem + buf * (2 * WKP * WRS) + row_off;
+            const char* sx = sy + WKP * WRS;
+            union { bf16x8 v; s16x4 h[2]; } xf[2], yf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const char* base = sx + (wi * 32 + a * 16) * 2;
+                xf[a].h[0] = tr_read(base);
+                xf[a].h[1] = tr_read(base + 16 * WRS);
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const char* base = sy + (wo * 32 + b * 16) * 2;
+                yf[b].h[0] = tr_read(base);
+                yf[b].h[1] = tr_read(base + 16 * WRS);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[a].v, yf[b].v, acc[a][b], 0, 0, 0);
+            if (kt + 1 < nk) stash(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    // slab[split][t][o][i] over the padded tile grid (i fastest): the lane owns o = column, four consecutive i = rows
+    const int Opad = p.o_tiles * WTO, Ipad = p.i_tiles * WTI;
+    float* slab = p.slab + ((long)(split * p.T + t) * Opad) * Ipad;
+    const int fcol = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int o = o0 + wo * 32 + b * 16 + fcol;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int i = i0 + wi * 32 + a * 16 + fq * 4;
+            *reinterpret_cast<f32x4*>(slab + (long)o * Ipad + i) = acc[a][b];
+        }
+    }
+}
+
+// dw[o][i][t] (+)= sum over the K splits in ascending order (bitwise reproducible)
+__global__ void gwgrad_reduce_kernel(const float* slab, float* dw, int O, int I, int T, int Opad, int Ipad, int S, int accumulate) {
+    const long n = (long)O * I * T;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int t = (int)(e % T);
+        const long oi = e / T;
+        const int i = (int)(oi % I), o = (int)(oi / I);
+        const float* src = slab + ((long)t * Opad + o) * Ipad + i;
+        const long sstride = (long)T * Opad * Ipad;
+        float v = 0.f;
+        for (int s = 0; s < S; ++s) v += src[s * sstride];
+        dw[e] = accumulate ? dw[e] + v : v;
+    }
+}
+
+void gwgrad_plan(int M, int O, int I, int T, int* S, int* rows, int* ot, int* it) {
+    *ot = (O + WTO - 1) / WTO;
+    *it = (I + WTI - 1) / WTI;
+    const int tiles = *ot * *it * T;
+    int s = (1024 + tiles - 1) / tiles;
+    const int smax = (M + 255) / 256;
+    if (s > smax) s = smax;
+    if (s < 1) s = 1;
+    int r = (M + s - 1) / s;
+    r = rup(r, WKP);
+    s = (M + r - 1) / r;
+    *S = s;
+    *rows = r;
+}
+
+// ------------------------------------------------------------------------------------------------ weight pack (table driven)
+// table rows (int64[n][8]): {w_off, wp_off, wpt_off or -1, O, I, T, first_block, -}; a block packs 1024 elements of one conv's
+// padded [T][Opad][Ipad] operand (Opad, Ipad = O, I rounded up to 32; the padding is written as zeros every time).
+__global__ __launch_bounds__(256) void gpack_kernel(const float* wflat, __bf16* wp, __bf16* wpt, const long* table, int n_desc) {
+    int lo = 0, hi = n_desc - 1;
+    const long bid = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid * 8 + 6] <= bid) lo = mid;
+        else hi = mid - 1;
+    }
+    const long* d = table + lo * 8;
+    const int O = (int)d[3], I = (int)d[4], T = (int)d[5];
+    const int Opad = (O + 31) & ~31, Ipad = (I + 31) & ~31;
+    const long n = (long)T * Opad * Ipad;
+    const float* w = wflat + d[0];
+    const long base = (bid - d[6]) * 1024;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long e = base + k * 256 + threadIdx.x;
+        if (e >= n) break;
+        {
+            const int i = (int)(e % Ipad);
+            const long r = e / Ipad;
+            const int o = (int)(r % Opad), t = (int)(r / Opad);
+            const float v = (o < O && i < I) ? w[((long)o * I + i) * T + t] : 0.f;
+            wp[d[1] + e] = (__bf16)v;
+        }
+        if (d[2] >= 0) {
+            const int o = (int)(e % Opad);
+            const long r = e / Opad;
+            const int i = (int)(r % Ipad), t = (int)(r / Ipad);
+            const float v = (o < O && i < I) ? w[((long)o * I + i) * T + t] : 0.f;
+            wpt[d[2] + e] = (__bf16)v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t mi_gconv_pack_elems(int O, int I, int kh, int kw) { return (size_t)kh * kw * rup(O, 32) * rup(I, 32); }
+
+int mi_gconv_pack_multi(const float* wflat, void* wp_bf16, void* wpt_bf16, const int64_t* table_dev, int n_desc, int total_blocks, void* stream) {
+    MI_REQUIRE(wflat && wp_bf16 && table_dev, "mi_gconv_pack_multi: null operand");
+    MI_REQUIRE(n_desc > 0 && total_blocks > 0, "mi_gconv_pack_multi: empty table");
+    hipLaunchKernelGGL(gpack_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, wflat, (__bf16*)wp_bf16, (__bf16*)wpt_bf16,
+                       (const long*)table_dev, n_desc);
+    MI_CHECK_LAUNCH("gpack_kernel");
+    return MI_OK;
+}
+
+int mi_gconv(const void* a, long lda, const void* wp, void* out, long ldo, int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N,
+             int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int mode, const float* bias, float* stats, int out_f32,
+             void* stream) {
+    MI_REQUIRE(a && wp && out, "mi_gconv: null operand");
+    MI_REQUIRE(B > 0 && Ha > 0 && Wa > 0 && Ho > 0 && Wo > 0 && Ca > 0 && N > 0, "mi_gconv: empty shape");
+    MI_REQUIRE(kh > 0 && kw > 0 && sh > 0 && sw > 0 && dh > 0 && dw > 0 && ph >= 0 && pw >= 0, "mi_gconv: bad conv geometry");
+    MI_REQUIRE(mode == MI_GATHER_FWD || mode == MI_GATHER_DGRAD, "mi_gconv: gather mode %d", mode);
+    MI_REQUIRE(lda >= Ca && ldo >= N, "mi_gconv: a view's row stride is smaller than its channel count (lda %ld / Ca %d, ldo %ld / N %d)", lda, Ca, ldo, N);
+    MI_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15) == 0, "mi_gconv: the packed weights must be 16-byte aligned");
+    MI_REQUIRE(!(out_f32 && stats), "mi_gconv: batch statistics are taken from bf16 outputs");
+    MI_REQUIRE((long)B * Ho * Wo < (1L << 31) && (long)B * Ha * Wa < (1L << 31), "mi_gconv: more than 2^31 pixels");
+    if (mode == MI_GATHER_FWD) {
+        MI_REQUIRE((Ha + 2 * ph - dh * (kh - 1) - 1) / sh + 1 == Ho && (Wa + 2 * pw - dw * (kw - 1) - 1) / sw + 1 == Wo,
+                   "mi_gconv: output %dx%d does not follow from input %dx%d", Ho, Wo, Ha, Wa);
+    } else {
+        MI_REQUIRE((Ho + 2 * ph - dh * (kh - 1) - 1) / sh + 1 == Ha && (Wo + 2 * pw - dw * (kw - 1) - 1) / sw + 1 == Wa,
+                   "mi_gconv: gradient input %dx%d does not follow from the forward input %dx%d", Ha, Wa, Ho, Wo);
+    }
+    GConvP p;
+    p.A = (const __bf16*)a;
+    p.Wp = (const __bf16*)wp;
+    p.out = out;
+    p.bias = bias;
+    p.stats = stats;
+    p.lda = lda;
+    p.ldo = ldo;
+    p.M = B * Ho * Wo;
+    p.N = N;
+    p.Ca = Ca;
+    p.Cpad = rup(Ca, 32);
+    p.Npad = rup(N, 32);
+    p.T = kh * kw;
+    p.Ha = Ha; p.Wa = Wa; p.Ho = Ho; p.Wo = Wo;
+    p.kw = kw; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.dh = dh; p.dw = dw;
+    p.mode = mode;
+    p.nchunks = p.Cpad / GKC;
+    const int avec = view_vec(a, lda, Ca);
+    int ovec = 1;
+    if (!out_f32) ovec = view_vec(out, ldo, N);
+    else MI_REQUIRE((reinterpret_cast<uintptr_t>(out) & 3) == 0, "mi_gconv: fp32 output must be 4-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const long mt = (p.M + GBM - 1) / GBM;
+    if (out_f32) {
+        MI_REQUIRE(N <= 32, "mi_gconv: fp32 outputs are the one-channel side maps (N <= 32), got N = %d", N);
+        glaunch_a<32>(p, avec, 1, true, s);
+    } else if (N <= 32) glaunch_a<32>(p, avec, ovec, false, s);
+    else if (N <= 64 || N % 128 == 64 || mt * ((N + 127) / 128) < 512) glaunch_a<64>(p, avec, ovec, false, s);
+    else glaunch_a<128>(p, avec, ovec, false, s);
+    MI_CHECK_LAUNCH("gconv_kernel");
+    return MI_OK;
+}
+
+size_t mi_gconv_stats_elems(int B, int Ho, int Wo, int N) { return (size_t)(((long)B * Ho * Wo + GBM - 1) / GBM) * 2 * N; }
+
+size_t mi_gconv_wgrad_workspace(int B, int Ho, int Wo, int O, int I, int kh, int kw) {
+    int S, rows, ot, it;
+    gwgrad_plan(B * Ho * Wo, O, I, kh * kw, &S, &rows, &ot, &it);
+    return (size_t)S * kh * kw * ot * WTO * it * WTI * sizeof(float);
+}
+
+int mi_gconv_wgrad(const void* dy, long ldy, const void* x, long ldx, float* dw, int B, int Ha, int Wa, int I, int Ho, int Wo, int O,
+                   int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw_, int accumulate, void* workspace, size_t workspace_bytes,
+                   void* stream) {
+    MI_REQUIRE(dy && x && dw && workspace, "mi_gconv_wgrad: null operand");
+    MI_REQUIRE(B > 0 && Ha > 0 && Wa > 0 && Ho > 0 && Wo > 0 && I > 0 && O > 0, "mi_gconv_wgrad: empty shape");
+    MI_REQUIRE(ldy >= O && ldx >= I, "mi_gconv_wgrad: a view's row stride is smaller than its channel count");
+    MI_REQUIRE((Ha + 2 * ph - dh * (kh - 1) - 1) / sh + 1 == Ho && (Wa + 2 * pw - dw_ * (kw - 1) - 1) / sw + 1 == Wo,
+               "mi_gconv_wgrad: output %dx%d does not follow from input %dx%d", Ho, Wo, Ha, Wa);
+    MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "mi_gconv_wgrad: workspace must be 16-byte aligned");
+    GWgP p;
+    p.dY = (const __bf16*)dy;
+    p.X = (const __bf16*)x;
+    p.slab = (float*)workspace;
+    p.ldy = ldy;
+    p.ldx = ldx;
+    p.M = B * Ho * Wo;
+    p.O = O; p.I = I; p.T = kh * kw;
+    p.Ho = Ho; p.Wo = Wo; p.Ha = Ha; p.Wa = Wa;
+    p.kw = kw; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.dh = dh; p.dw = dw_;
+    gwgrad_plan(p.M, O, I, p.T, &p.S, &p.rows_per_split, &p.o_tiles, &p.i_tiles);
+    const size_t need = (size_t)p.S * p.T * p.o_tiles * WTO * p.i_tiles * WTI * sizeof(float);
+    if (workspace_bytes < need) return mi_set_error(MI_ENOMEM, "mi_gconv_wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t s = (hipStream_t)stream;
+    const int yv = view_vec(dy, ldy, O), xv = view_vec(x, ldx, I);
+    const dim3 grid(p.o_tiles * p.i_tiles * p.T * p.S);
+#define GW(YV, XV) hipLaunchKernelGGL((gwgrad_kernel<YV, XV>), grid, dim3(256), 0, s, p)
+    if (yv == 8 && xv == 8) GW(8, 8);
+    else if (yv == 8 && xv == 2) GW(8, 2);
+    else if (yv == 8) GW(8, 1);
+    else if (yv == 2 && xv == 8) GW(2, 8);
+    else if (yv == 2 && xv == 2) GW(2, 2);
+    else if (yv == 2) GW(2, 1);
+    else if (xv == 8) GW(1, 8);
+    else if (xv == 2) GW(1, 2);
+    else GW(1, 1);
+#undef GW
+    MI_CHECK_LAUNCH("gwgrad_kernel");
+    const long n = (long)O * I * p.T;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(gwgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slab, dw, O, I, p.T, p.o_tiles * WTO, p.i_tiles * WTI, p.S, accumulate);
+    MI_CHECK_LAUNCH("gwgrad_reduce_kernel");
+    return MI_OK;
+}
+
+}  // extern "C"

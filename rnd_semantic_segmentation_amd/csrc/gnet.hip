@@ -1,0 +1,544 @@
+// The non-GEMM kernels of the PraNet path on channel-slice VIEWS of NHWC tensors (pointer + elements per pixel
+// row, any channel count): trainable BatchNorm2d on batch statistics split into finalize / apply / backward sums / backward apply
+// (the first-level statistics come out of the conv epilogue, gconv.hip), average pools, bilinear resizing with either
+// align_corners convention, the elementwise products / sums of the partial decoder and the reverse-attention gate.
+//   reference: core/models/classifiers/pranet/PraNet_Res2Net.py:7-179, Res2Net_v1b.py:15-170.
+// Every reduction has a fixed order (no float atomics): two runs give the same bits.
+#include "mi_common.h"
+
+namespace {
+
+__device__ __forceinline__ float ldf(const __bf16* p) { return (float)*p; }
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ void stf(__bf16* p, float v) { *p = (__bf16)v; }
+__device__ __forceinline__ void stf(float* p, float v) { *p = v; }
+
+// ------------------------------------------------------------------------------------------------ BatchNorm: finalize
+// partials[tile][2][C] (sum, sum of squares per 128-pixel tile, written by gconv_kernel) -> batch mean / biased variance in double,
+// invstd, the folded affine (scale = gamma * invstd, shift = beta - mean * scale) and torch's running-statistics update
+// (momentum m: running = (1 - m) * running + m * batch, unbiased variance for running_var; nn.BatchNorm2d defaults).
+__global__ __launch_bounds__(256) void gbn_finalize_kernel(const float* partials, int tiles, int C, double count, const float* gamma, const float* beta,
+                                                           float* running_mean, float* running_var, float momentum, float eps, float* mean_out,
+                                                           float* invstd_out, float* scale_out, float* shift_out) {
+    __shared__ double red[2][4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int t = ry; t < tiles; t += 4) {
+            s1 += (double)partials[(long)t * 2 * C + c];
+            s2 += (double)partials[(long)t * 2 * C + C + c];
+        }
+    red[0][ry][cx] = s1;
+    red[1][ry][cx] = s2;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        s1 = red[0][0][cx] + red[0][1][cx] + red[0][2][cx] + red[0][3][cx];
+        s2 = red[1][0][cx] + red[1][1][cx] + red[1][2][cx] + red[1][3][cx];
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        mean_out[c] = (float)mean;
+        invstd_out[c] = invstd;
+        const float sc = g * invstd;
+        scale_out[c] = sc;
+        shift_out[c] = b - (float)mean * sc;
+        if (running_mean) {
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
+// eval(): scale = gamma * rsqrt(running_var + eps), shift = beta - running_mean * scale
+__global__ void gbn_fold_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, float* scale, float* shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const float sc = gamma[c] * (1.f / sqrtf(rv[c] + eps));
+        scale[c] = sc;
+        shift[c] = beta[c] - rm[c] * sc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm: apply
+// out = relu?(y * scale[c] + shift[c] (+ add)), one thread per VEC channels of a pixel
+template <int VEC, typename TO>
+__global__ __launch_bounds__(256) void gbn_apply_kernel(const __bf16* y, long ldy, const float* scale, const float* shift, const __bf16* add, long ldadd,
+                                                        TO* out, long ldo, long M, int C, int relu) {
+    const int cv = C / VEC;
+    const long n = M * cv;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const long m = e / cv;
+        const int c0 = (int)(e - m * cv) * VEC;
+        float v[VEC];
+        if constexpr (VEC == 8) {
+            const bf16x8 yv = *reinterpret_cast<const bf16x8*>(y + m * ldy + c0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (float)yv[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v[j] = (float)y[m * ldy + c0 + j];
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[j] = v[j] * scale[c0 + j] + shift[c0 + j];
+        if (add) {
+            if constexpr (VEC == 8) {
+                const bf16x8 av = *reinterpret_cast<const bf16x8*>(add + m * ldadd + c0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)av[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) v[j] += (float)add[m * ldadd + c0 + j];
+            }
+        }
+        if (relu) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        if constexpr (VEC == 8 && sizeof(TO) == 2) {
+            bf16x8 ov;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ov[j] = (__bf16)v[j];
+            *reinterpret_cast<bf16x8*>(out + m * ldo + c0) = ov;
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) stf(out + m * ldo + c0 + j, v[j]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ column sums (BatchNorm backward, bias gradients)
+// partial[blk][0][c] = sum_m g'[m][c], partial[blk][1][c] = sum_m g'[m][c] * (y[m][c] - mean[c]) * invstd[c] over the block's rows;
+// g' = g where mask[m][c] > 0 (mask = the layer's ReLU output) or g itself when mask is NULL; y NULL: the first sum only.
+constexpr int CS_ROWS = 256;
+template <typename TG, typename TM>
+__global__ __launch_bounds__(256) void gcolsum_partial_kernel(const TG* g, long ldg, const __bf16* y, long ldy, const TM* mask, long ldm, const float* mean,
+                                                              const float* invstd, long M, int C, float* partial) {
+    __shared__ float red[2][4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cx;
+    const long r0 = (long)blockIdx.x * CS_ROWS;
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C) {
+        const float mu = y ? mean[c] : 0.f, is = y ? invstd[c] : 0.f;
+        for (int r = ry; r < CS_ROWS; r += 4) {
+            const long m = r0 + r;
+            if (m >= M) break;
+            float gv = ldf(g + m * ldg + c);
+            if (mask && !(ldf(mask + m * ldm + c) > 0.f)) gv = 0.f;
+            s1 += gv;
+            if (y) s2 += gv * (((float)y[m * ldy + c] - mu) * is);
+        }
+    }
+    red[0][ry][cx] = s1;
+    red[1][ry][cx] = s2;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        partial[((long)blockIdx.x * 2 + 0) * C + c] = red[0][0][cx] + red[0][1][cx] + red[0][2][cx] + red[0][3][cx];
+        partial[((long)blockIdx.x * 2 + 1) * C + c] = red[1][0][cx] + red[1][1][cx] + red[1][2][cx] + red[1][3][cx];
+    }
+}
+
+// out1[c] (+)= sum over blocks of partial[blk][0][c], out2 likewise (ascending block order, accumulated in double)
+__global__ __launch_bounds__(256) void gcolsum_final_kernel(const float* partial, int blocks, int C, float* out1, float* out2, int accumulate) {
+    __shared__ double red[2][4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int b = ry; b < blocks; b += 4) {
+            s1 += (double)partial[((long)b * 2 + 0) * C + c];
+            s2 += (double)partial[((long)b * 2 + 1) * C + c];
+        }
+    red[0][ry][cx] = s1;
+    red[1][ry][cx] = s2;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        const float a = (float)(red[0][0][cx] + red[0][1][cx] + red[0][2][cx] + red[0][3][cx]);
+        const float b = (float)(red[1][0][cx] + red[1][1][cx] + red[1][2][cx] + red[1][3][cx]);
+        if (out1) out1[c] = accumulate ? out1[c] + a : a;
+        if (out2) out2[c] = accumulate ? out2[c] + b : b;
+    }
+}
+
+// dy = gamma * invstd * (g' - dbeta / n - xhat * dgamma / n)
+template <typename TG, typename TM>
+__global__ __launch_bounds__(256) void gbn_bwd_apply_kernel(const TG* g, long ldg, const __bf16* y, long ldy, const TM* mask, long ldm, const float* mean,
+                                                            const float* invstd, const float* gamma, const float* dbeta, const float* dgamma,
+                                                            float inv_count, __bf16* dy, long lddy, long M, int C) {
+    const long n = M * C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const long m = e / C;
+        const int c = (int)(e - m * C);
+        float gv = ldf(g + m * ldg + c);
+        if (mask && !(ldf(mask + m * ldm + c) > 0.f)) gv = 0.f;
+        const float is = invstd[c];
+        const float xhat = ((float)y[m * ldy + c] - mean[c]) * is;
+        const float ga = gamma ? gamma[c] : 1.f;
+        dy[m * lddy + c] = (__bf16)(ga * is * (gv - dbeta[c] * inv_count - xhat * dgamma[c] * inv_count));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ elementwise on views
+enum { OP_ADD = 0, OP_MUL = 1, OP_COPY = 2, OP_RELU_MASK = 3 /* a where b > 0 else 0 */ };
+template <int OP, typename TA, typename TB, typename TO>
+__global__ __launch_bounds__(256) void gbinary_kernel(const TA* a, long lda, const TB* b, long ldb, TO* out, long ldo, long M, int C) {
+    const long n = M * C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const long m = e / C;
+        const int c = (int)(e - m * C);
+        const float av = ldf(a + m * lda + c);
+        float r;
+        if constexpr (OP == OP_COPY) r = av;
+        else {
+            const float bv = ldf(b + m * ldb + c);
+            r = OP == OP_ADD ? av + bv : (OP == OP_MUL ? av * bv : (bv > 0.f ? av : 0.f));
+        }
+        stf(out + m * ldo + c, r);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ average pools (NHWC bf16 views)
+// include_pad != 0: AvgPool2d(k, s, p) with torch's default count_include_pad=True (Res2Net_v1b.py:40: divisor k*k);
+// include_pad == 0: AvgPool2d(s, s, ceil_mode=True, count_include_pad=False) of the downsample path (Res2Net_v1b.py:122-123).
+struct PoolP {
+    int B, H, W, C, Ho, Wo, k, s, p, include_pad;
+    long ldx, ldo;
+};
+__global__ __launch_bounds__(256) void gavgpool_fwd_kernel(const __bf16* x, __bf16* out, PoolP q) {
+    const long n = (long)q.B * q.Ho * q.Wo * q.C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % q.C);
+        long m = e / q.C;
+        const int ow = (int)(m % q.Wo);
+        const long t = m / q.Wo;
+        const int oh = (int)(t % q.Ho), b = (int)(t / q.Ho);
+        float s = 0.f;
+        int cnt = 0;
+        for (int ky = 0; ky < q.k; ++ky) {
+            const int ih = oh * q.s - q.p + ky;
+            if ((unsigned)ih >= (unsigned)q.H) continue;
+            for (int kx = 0; kx < q.k; ++kx) {
+                const int iw = ow * q.s - q.p + kx;
+                if ((unsigned)iw >= (unsigned)q.W) continue;
+                s += (float)x[(((long)b * q.H + ih) * q.W + iw) * q.ldx + c];
+                ++cnt;
+            }
+        }
+        const float div = q.include_pad ? (float)(q.k * q.k) : (float)(cnt > 0 ? cnt : 1);
+        out[m * q.ldo + c] = (__bf16)(s / div);
+    }
+}
+// dx[b][ih][iw][c] = sum over the windows that contain (ih, iw) of dout / divisor(window); q.ldx / q.ldo are the strides of dx / dout
+__global__ __launch_bounds__(256) void gavgpool_bwd_kernel(const __bf16* dout, __bf16* dx, PoolP q) {
+    const long n = (long)q.B * q.H * q.W * q.C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % q.C);
+        long m = e / q.C;
+        const int iw = (int)(m % q.W);
+        const long t = m / q.W;
+        const int ih = (int)(t % q.H), b = (int)(t / q.H);
+        float s = 0.f;
+        for (int oh = (ih + q.p) / q.s; oh >= 0 && oh * q.s - q.p + q.k - 1 >= ih; --oh) {
+            if (oh >= q.Ho) continue;
+            for (int ow = (iw + q.p) / q.s; ow >= 0 && ow * q.s - q.p + q.k - 1 >= iw; --ow) {
+                if (ow >= q.Wo) continue;
+                float div = (float)(q.k * q.k);
+                if (!q.include_pad) {
+                    const int h0 = max(oh * q.s - q.p, 0), h1 = min(oh * q.s - q.p + q.k, q.H);
+                    const int w0 = max(ow * q.s - q.p, 0), w1 = min(ow * q.s - q.p + q.k, q.W);
+                    div = (float)((h1 - h0) * (w1 - w0));
+                }
+                s += (float)dout[(((long)b * q.Ho + oh) * q.Wo + ow) * q.ldo + c] / div;
+            }
+        }
+        dx[m * q.ldx + c] = (__bf16)s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ bilinear resize (both conventions)
+// ATen's upsample_bilinear2d: src = align ? scale * dst : max(scale * (dst + 0.5) - 0.5, 0); i0 = (int)src; i1 = i0 + (i0 < in - 1);
+// l1 = src - i0.  scale is computed on the host the way torch does (align: (in - 1) / (out - 1); otherwise 1 / scale_factor when the
+// caller gave a scale_factor - F.interpolate(..., scale_factor=s) of PraNet_Res2Net.py:127-177 - or in / out when it gave a size).
+struct ResizeP {
+    int B, H, W, C, Ho, Wo, align;
+    float sh, sw;
+    long ldx, ldo;
+};
+__device__ __forceinline__ void rs_src(int d, float scale, int align, int in, int& i0, int& p, float& l1) {
+    float s = align ? scale * (float)d : fmaxf(scale * ((float)d + 0.5f) - 0.5f, 0.f);
+    i0 = (int)s;
+    if (i0 > in - 1) i0 = in - 1;
+    p = i0 < in - 1 ? 1 : 0;
+    l1 = s - (float)i0;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gresize_fwd_kernel(const T* x, T* out, ResizeP q) {
+    const long n = (long)q.B * q.Ho * q.Wo * q.C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % q.C);
+        long m = e / q.C;
+        const int ow = (int)(m % q.Wo);
+        const long t = m / q.Wo;
+        const int oh = (int)(t % q.Ho), b = (int)(t / q.Ho);
+        int h0, hp, w0, wp;
+        float hl, wl;
+        rs_src(oh, q.sh, q.align, q.H, h0, hp, hl);
+        rs_src(ow, q.sw, q.align, q.W, w0, wp, wl);
+        const T* r0 = x + (((long)b * q.H + h0) * q.W) * q.ldx + c;
+        const T* r1 = r0 + (long)hp * q.W * q.ldx;
+        const float v00 = ldf(r0 + (long)w0 * q.ldx), v01 = ldf(r0 + (long)(w0 + wp) * q.ldx);
+        const float v10 = ldf(r1 + (long)w0 * q.ldx), v11 = ldf(r1 + (long)(w0 + wp) * q.ldx);
+        const float v = (1.f - hl) * ((1.f - wl) * v00 + wl * v01) + hl * ((1.f - wl) * v10 + wl * v11);
+        stf(out + m * q.ldo + c, v);
+    }
+}
+// gather form of the backward: one thread per SOURCE element sums, in ascending destination order, the contributions of every
+// destination pixel whose two-tap footprint touches it (the candidate range comes from inverting the monotone source map, widened
+// by two on each side; each candidate is tested with the forward formula itself).  q.ldx / q.ldo: strides of dx / dout.
+template <typename T>
+__global__ __launch_bounds__(256) void gresize_bwd_kernel(const T* dout, T* dx, ResizeP q) {
+    const long n = (long)q.B * q.H * q.W * q.C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % q.C);
+        long m = e / q.C;
+        const int iw = (int)(m % q.W);
+        const long t = m / q.W;
+        const int ih = (int)(t % q.H), b = (int)(t / q.H);
+        auto range = [&](int i, float scale, int out, int& lo, int& hi) {
+            if (scale <= 0.f) {
+                lo = 0;
+                hi = out - 1;
+                return;
+            }
+            const float off = q.align ? 0.f : 0.5f;
+            lo = (int)floorf(((float)(i - 1) + off) / scale - off) - 2;
+            hi = (int)ceilf(((float)(i + 1) + off) / scale - off) + 2;
+            if (lo < 0) lo = 0;
+            if (hi > out - 1) hi = out - 1;
+        };
+        int hlo, hhi, wlo, whi;
+        range(ih, q.sh, q.Ho, hlo, hhi);
+        range(iw, q.sw, q.Wo, wlo, whi);
+        float s = 0.f;
+        for (int oh = hlo; oh <= hhi; ++oh) {
+            int h0, hp;
+            float hl;
+            rs_src(oh, q.sh, q.align, q.H, h0, hp, hl);
+            float wh = 0.f;
+            if (h0 == ih) wh += 1.f - hl;
+            if (h0 + hp == ih) wh += hl;          // (a clamped second tap lands on the same row)
+            if (wh == 0.f) continue;
+            float rs = 0.f;
+            const T* drow = dout + (((long)b * q.Ho + oh) * q.Wo) * q.ldo + c;
+            for (int ow = wlo; ow <= whi; ++ow) {
+                int w0, wp;
+                float wl;
+                rs_src(ow, q.sw, q.align, q.W, w0, wp, wl);
+                float ww = 0.f;
+                if (w0 == iw) ww += 1.f - wl;
+                if (w0 + wp == iw) ww += wl;
+                if (ww != 0.f) rs += ww * ldf(drow + (long)ow * q.ldo);
+            }
+            s += wh * rs;
+        }
+        stf(dx + m * q.ldx + c, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ reverse attention (PraNet_Res2Net.py:131-133)
+// out[m][c] = (1 - sigmoid(gate[m])) * feat[m][c]   ( `-1*(torch.sigmoid(crop)) + 1` expanded over the channels, times the feature )
+__global__ __launch_bounds__(256) void gra_fwd_kernel(const float* gate, const __bf16* feat, long ldf_, __bf16* out, long ldo, long M, int C) {
+    const long n = M * C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const long m = e / C;
+        const int c = (int)(e - m * C);
+        const float a = -1.f * (1.f / (1.f + __expf(-gate[m]))) + 1.f;
+        out[m * ldo + c] = (__bf16)(a * (float)feat[m * ldf_ + c]);
+    }
+}
+// dfeat[m][c] = (1 - s) * dy[m][c];  dgate[m] = -s (1 - s) * sum_c feat[m][c] * dy[m][c]     one wave per pixel, fixed-order butterfly
+__global__ __launch_bounds__(256) void gra_bwd_kernel(const float* gate, const __bf16* feat, long ldf_, const __bf16* dy, long lddy, __bf16* dfeat, long lddf,
+                                                      float* dgate, long M, int C) {
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float s = 1.f / (1.f + __expf(-gate[m]));
+    const float a = 1.f - s;
+    float dot = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float d = (float)dy[m * lddy + c];
+        dot += (float)feat[m * ldf_ + c] * d;
+        dfeat[m * lddf + c] = (__bf16)(a * d);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+    if (lane == 0) dgate[m] = -s * a * dot;
+}
+
+inline int grid_for(long n) {
+    long b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_gbn_finalize(const float* partials, int tiles, int C, long count, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                    float momentum, float eps, float* mean_out, float* invstd_out, float* scale_out, float* shift_out, void* stream) {
+    MI_REQUIRE(partials && mean_out && invstd_out && scale_out && shift_out, "mi_gbn_finalize: null operand");
+    MI_REQUIRE(tiles > 0 && C > 0 && count > 0, "mi_gbn_finalize: empty shape");
+    MI_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "mi_gbn_finalize: running_mean and running_var come together");
+    hipLaunchKernelGGL(gbn_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, partials, tiles, C, (double)count, gamma, beta,
+                       running_mean, running_var, momentum, eps, mean_out, invstd_out, scale_out, shift_out);
+    MI_CHECK_LAUNCH("gbn_finalize_kernel");
+    return MI_OK;
+}
+
+int mi_gbn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, float* scale, float* shift, int C,
+                void* stream) {
+    MI_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C > 0, "mi_gbn_fold: null operand");
+    hipLaunchKernelGGL(gbn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean, running_var, eps, scale, shift, C);
+    MI_CHECK_LAUNCH("gbn_fold_kernel");
+    return MI_OK;
+}
+
+int mi_gbn_apply(const void* y, long ldy, const float* scale, const float* shift, const void* add, long ldadd, void* out, long ldo, int out_f32, long M, int C,
+                 int relu, void* stream) {
+    MI_REQUIRE(y && scale && shift && out, "mi_gbn_apply: null operand");
+    MI_REQUIRE(M > 0 && C > 0 && ldy >= C && ldo >= C && (!add || ldadd >= C), "mi_gbn_apply: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const __bf16* yy = (const __bf16*)y;
+    const __bf16* aa = (const __bf16*)add;
+    const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool v8 = !out_f32 && C % 8 == 0 && ldy % 8 == 0 && ldo % 8 == 0 && al16(y) && al16(out) && (!add || (ldadd % 8 == 0 && al16(add)));
+    if (out_f32) hipLaunchKernelGGL((gbn_apply_kernel<1, float>), dim3(grid_for(M * C)), dim3(256), 0, s, yy, ldy, scale, shift, aa, ldadd, (float*)out, ldo, M, C, relu);
+    else if (v8) hipLaunchKernelGGL((gbn_apply_kernel<8, __bf16>), dim3(grid_for(M * C / 8)), dim3(256), 0, s, yy, ldy, scale, shift, aa, ldadd, (__bf16*)out, ldo, M, C, relu);
+    else hipLaunchKernelGGL((gbn_apply_kernel<1, __bf16>), dim3(grid_for(M * C)), dim3(256), 0, s, yy, ldy, scale, shift, aa, ldadd, (__bf16*)out, ldo, M, C, relu);
+    MI_CHECK_LAUNCH("gbn_apply_kernel");
+    return MI_OK;
+}
+
+size_t mi_gcolsum_workspace(long M, int C) { return (size_t)((M + CS_ROWS - 1) / CS_ROWS) * 2 * C * sizeof(float); }
+
+int mi_gbn_bwd_sums(const void* g, long ldg, int g_f32, const void* y, long ldy, const void* mask, long ldm, int mask_f32, const float* mean,
+                    const float* invstd, long M, int C, float* dbeta, float* dgamma, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    MI_REQUIRE(g && workspace && (dbeta || dgamma), "mi_gbn_bwd_sums: null operand");
+    MI_REQUIRE(M > 0 && C > 0 && ldg >= C, "mi_gbn_bwd_sums: bad shape");
+    MI_REQUIRE(!y || (mean && invstd && ldy >= C), "mi_gbn_bwd_sums: y needs mean / invstd");
+    MI_REQUIRE(g_f32 || !mask_f32, "mi_gbn_bwd_sums: an fp32 mask goes with an fp32 gradient");
+    if (workspace_bytes < mi_gcolsum_workspace(M, C)) return mi_set_error(MI_ENOMEM, "mi_gbn_bwd_sums: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = (int)((M + CS_ROWS - 1) / CS_ROWS);
+    const dim3 grid(blocks, (C + 63) / 64);
+    float* part = (float*)workspace;
+    const __bf16* yy = (const __bf16*)y;
+    if (g_f32 && mask_f32)
+        hipLaunchKernelGGL((gcolsum_partial_kernel<float, float>), grid, dim3(256), 0, s, (const float*)g, ldg, yy, ldy, (const float*)mask, ldm, mean, invstd, M, C, part);
+    else if (g_f32)
+        hipLaunchKernelGGL((gcolsum_partial_kernel<float, __bf16>), grid, dim3(256), 0, s, (const float*)g, ldg, yy, ldy, (const __bf16*)mask, ldm, mean, invstd, M, C, part);
+    else
+        hipLaunchKernelGGL((gcolsum_partial_kernel<__bf16, __bf16>), grid, dim3(256), 0, s, (const __bf16*)g, ldg, yy, ldy, (const __bf16*)mask, ldm, mean, invstd, M, C, part);
+    MI_CHECK_LAUNCH("gcolsum_partial_kernel");
+    hipLaunchKernelGGL(gcolsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, s, part, blocks, C, dbeta, dgamma, accumulate);
+    MI_CHECK_LAUNCH("gcolsum_final_kernel");
+    return MI_OK;
+}
+
+int mi_gbn_bwd_apply(const void* g, long ldg, int g_f32, const void* y, long ldy, const void* mask, long ldm, int mask_f32, const float* mean,
+                     const float* invstd, const float* gamma, const float* dbeta, const float* dgamma, float inv_count, void* dy, long lddy, long M, int C,
+                     void* stream) {
+    MI_REQUIRE(g && y && mean && invstd && dbeta && dgamma && dy, "mi_gbn_bwd_apply: null operand");
+    MI_REQUIRE(M > 0 && C > 0 && ldg >= C && ldy >= C && lddy >= C, "mi_gbn_bwd_apply: bad shape");
+    MI_REQUIRE(g_f32 || !mask_f32, "mi_gbn_bwd_apply: an fp32 mask goes with an fp32 gradient");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(grid_for(M * C));
+    const __bf16* yy = (const __bf16*)y;
+    if (g_f32 && mask_f32)
+        hipLaunchKernelGGL((gbn_bwd_apply_kernel<float, float>), grid, dim3(256), 0, s, (const float*)g, ldg, yy, ldy, (const float*)mask, ldm, mean, invstd, gamma, dbeta, dgamma, inv_count, (__bf16*)dy, lddy, M, C);
+    else if (g_f32)
+        hipLaunchKernelGGL((gbn_bwd_apply_kernel<float, __bf16>), grid, dim3(256), 0, s, (const float*)g, ldg, yy, ldy, (const __bf16*)mask, ldm, mean, invstd, gamma, dbeta, dgamma, inv_count, (__bf16*)dy, lddy, M, C);
+    else
+        hipLaunchKernelGGL((gbn_bwd_apply_kernel<__bf16, __bf16>), grid, dim3(256), 0, s, (const __bf16*)g, ldg, yy, ldy, (const __bf16*)mask, ldm, mean, invstd, gamma, dbeta, dgamma, inv_count, (__bf16*)dy, lddy, M, C);
+    MI_CHECK_LAUNCH("gbn_bwd_apply_kernel");
+    return MI_OK;
+}
+
+/* op: 0 add, 1 mul, 2 copy (b ignored), 3 relu mask (a where b > 0).  dtype: 0 = all bf16, 1 = all fp32, 2 = fp32 a -> bf16 out (copy: the cast),
+ * 3 = bf16 a -> fp32 out (copy) */
+int mi_gbinary(int op, int dtype, const void* a, long lda, const void* b, long ldb, void* out, long ldo, long M, int C, void* stream) {
+    MI_REQUIRE(a && out && (b || op == OP_COPY), "mi_gbinary: null operand");
+    MI_REQUIRE(M > 0 && C > 0 && lda >= C && ldo >= C && (op == OP_COPY || ldb >= C), "mi_gbinary: bad shape");
+    MI_REQUIRE(op >= 0 && op <= 3 && dtype >= 0 && dtype <= 3 && (dtype < 2 || op == OP_COPY), "mi_gbinary: op %d / dtype %d", op, dtype);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(grid_for(M * C));
+#define GB(OP, TA, TB, TO) hipLaunchKernelGGL((gbinary_kernel<OP, TA, TB, TO>), grid, dim3(256), 0, s, (const TA*)a, lda, (const TB*)b, ldb, (TO*)out, ldo, M, C)
+    if (dtype == 0) {
+        if (op == OP_ADD) GB(OP_ADD, __bf16, __bf16, __bf16);
+        else if (op == OP_MUL) GB(OP_MUL, __bf16, __bf16, __bf16);
+        else if (op == OP_COPY) GB(OP_COPY, __bf16, __bf16, __bf16);
+        else GB(OP_RELU_MASK, __bf16, __bf16, __bf16);
+    } else if (dtype == 1) {
+        if (op == OP_ADD) GB(OP_ADD, float, float, float);
+        else if (op == OP_MUL) GB(OP_MUL, float, float, float);
+        else if (op == OP_COPY) GB(OP_COPY, float, float, float);
+        else GB(OP_RELU_MASK, float, float, float);
+    } else if (dtype == 2) GB(OP_COPY, float, float, __bf16);
+    else GB(OP_COPY, __bf16, __bf16, float);
+#undef GB
+    MI_CHECK_LAUNCH("gbinary_kernel");
+    return MI_OK;
+}
+
+int mi_gavgpool(const void* x, long ldx, void* out, long ldo, int B, int H, int W, int C, int Ho, int Wo, int k, int stride, int pad, int include_pad,
+                int backward, void* stream) {
+    MI_REQUIRE(x && out, "mi_gavgpool: null operand");
+    MI_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && k > 0 && stride > 0 && pad >= 0 && ldx >= C && ldo >= C, "mi_gavgpool: bad shape");
+    MI_REQUIRE((Ho - 1) * stride - pad < H && (Wo - 1) * stride - pad < W, "mi_gavgpool: the last window starts outside the input");
+    PoolP q{B, H, W, C, Ho, Wo, k, stride, pad, include_pad, ldx, ldo};
+    hipStream_t s = (hipStream_t)stream;
+    if (!backward) hipLaunchKernelGGL(gavgpool_fwd_kernel, dim3(grid_for((long)B * Ho * Wo * C)), dim3(256), 0, s, (const __bf16*)x, (__bf16*)out, q);
+    else hipLaunchKernelGGL(gavgpool_bwd_kernel, dim3(grid_for((long)B * H * W * C)), dim3(256), 0, s, (const __bf16*)out, (__bf16*)const_cast<void*>(x), q);
+    MI_CHECK_LAUNCH("gavgpool_kernel");
+    return MI_OK;
+}
+
+int mi_gresize(const void* x, long ldx, void* out, long ldo, int f32, int B, int H, int W, int C, int Ho, int Wo, int align_corners, float scale_h, float scale_w,
+               int backward, void* stream) {
+    MI_REQUIRE(x && out, "mi_gresize: null operand");
+    MI_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && ldx >= C && ldo >= C, "mi_gresize: bad shape");
+    ResizeP q{B, H, W, C, Ho, Wo, align_corners, scale_h, scale_w, ldx, ldo};
+    hipStream_t s = (hipStream_t)stream;
+    if (!backward) {
+        const dim3 grid(grid_for((long)B * Ho * Wo * C));
+        if (f32) hipLaunchKernelGGL((gresize_fwd_kernel<float>), grid, dim3(256), 0, s, (const float*)x, (float*)out, q);
+        else hipLaunchKernelGGL((gresize_fwd_kernel<__bf16>), grid, dim3(256), 0, s, (const __bf16*)x, (__bf16*)out, q);
+    } else {       // x = dx (written), out = dout (read)
+        const dim3 grid(grid_for((long)B * H * W * C));
+        if (f32) hipLaunchKernelGGL((gresize_bwd_kernel<float>), grid, dim3(256), 0, s, (const float*)out, (float*)const_cast<void*>(x), q);
+        else hipLaunchKernelGGL((gresize_bwd_kernel<__bf16>), grid, dim3(256), 0, s, (const __bf16*)out, (__bf16*)const_cast<void*>(x), q);
+    }
+    MI_CHECK_LAUNCH("gresize_kernel");
+    return MI_OK;
+}
+
+int mi_gra_fwd(const float* gate, const void* feat, long ldfeat, void* out, long ldo, long M, int C, void* stream) {
+    MI_REQUIRE(gate && feat && out && M > 0 && C > 0 && ldfeat >= C && ldo >= C, "mi_gra_fwd: bad operand");
+    hipLaunchKernelGGL(gra_fwd_kernel, dim3(grid_for(M * C)), dim3(256), 0, (hipStream_t)stream, gate, (const __bf16*)feat, ldfeat, (__bf16*)out, ldo, M, C);
+    MI_CHECK_LAUNCH("gra_fwd_kernel");
+    return MI_OK;
+}
+
+int mi_gra_bwd(const float* gate, const void* feat, long ldfeat, const void* dy, long lddy, void* dfeat, long lddf, float* dgate, long M, int C, void* stream) {
+    MI_REQUIRE(gate && feat && dy && dfeat && dgate && M > 0 && C > 0 && ldfeat >= C && lddy >= C && lddf >= C, "mi_gra_bwd: bad operand");
+    hipLaunchKernelGGL(gra_bwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, gate, (const __bf16*)feat, ldfeat, (const __bf16*)dy, lddy,
+                       (__bf16*)dfeat, lddf, dgate, M, C);
+    MI_CHECK_LAUNCH("gra_bwd_kernel");
+    return MI_OK;
+}
+
+}  // extern "C"

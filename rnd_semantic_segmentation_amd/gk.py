@@ -1,0 +1,257 @@
+"""Tensor-level wrappers over the view-based C-ABI entry points of the PraNet path (include/mi355seg.h: mi_gconv ... mi_gra_bwd).
+
+A tensor handed to these functions is an NHWC tensor [B,H,W,C] or a CHANNEL SLICE of one (`t[..., a:b]`): last-dim stride 1, pixel
+stride `ld` (elements per pixel row of the parent), no other gaps.  One-channel fp32 maps are [B,H,W,1] with ld 1.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check
+from .kernels import _p, _stream, _workspace, GATHER_FWD, GATHER_DGRAD  # noqa: F401
+
+OP_ADD, OP_MUL, OP_COPY, OP_RELU_MASK = 0, 1, 2, 3
+
+
+def view(t, dtype=None):
+    """(pointer, ld) of an NHWC tensor or channel slice; raises for anything the kernels cannot address."""
+    if not t.is_cuda:
+        raise _lib.MiError("tensor must live on the GPU (no CPU path exists)")
+    if dtype is not None and t.dtype != dtype:
+        raise _lib.MiError("expected %s, got %s" % (dtype, t.dtype))
+    if t.dim() != 4:
+        raise _lib.MiError("expected [B,H,W,C], got %s" % (tuple(t.shape),))
+    B, H, W, C = t.shape
+    s = t.stride()
+    ld = s[2] if W > 1 else (s[1] // max(W, 1) if H > 1 else (s[0] // max(H * W, 1) if B > 1 else C))
+    if C > 1 and s[3] != 1:
+        raise _lib.MiError("channels must be contiguous, strides %s" % (s,))
+    if ld < C or (W > 1 and s[2] != ld) or (H > 1 and s[1] != W * ld) or (B > 1 and s[0] != H * W * ld):
+        raise _lib.MiError("not a channel-slice view of an NHWC tensor: shape %s strides %s" % (tuple(t.shape), s))
+    return ctypes.c_void_p(t.data_ptr()), int(ld)
+
+
+def new(B, H, W, C, device, dtype=torch.bfloat16):
+    return torch.empty((B, H, W, C), dtype=dtype, device=device)
+
+
+def conv_out_hw(H, W, kh, kw, sh, sw, ph, pw, dh, dw):
+    return (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1, (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+
+
+def gconv(a, wp, N, geom, out=None, mode=GATHER_FWD, out_hw=None, bias=None, stats=False, out_f32=False):
+    """geom = (kh, kw, sh, sw, ph, pw, dh, dw).  FWD: a is the input, returns (out [B,Ho,Wo,N], stats or None).
+    DGRAD: a is d loss / d conv output, out_hw the forward input's (H, W), wp the transposed pack, N the forward input channels."""
+    kh, kw, sh, sw, ph, pw, dh, dw = geom
+    B, Ha, Wa, Ca = a.shape
+    if mode == GATHER_FWD:
+        Ho, Wo = conv_out_hw(Ha, Wa, *geom)
+    else:
+        Ho, Wo = out_hw
+    if out is None:
+        out = new(B, Ho, Wo, N, a.device, torch.float32 if out_f32 else torch.bfloat16)
+    pa, lda = view(a, torch.bfloat16)
+    po, ldo = view(out, torch.float32 if out_f32 else torch.bfloat16)
+    if tuple(out.shape) != (B, Ho, Wo, N):
+        raise _lib.MiError("gconv: out is %s, the conv writes %s" % (tuple(out.shape), (B, Ho, Wo, N)))
+    L = _lib.lib()
+    st = None
+    if stats:
+        st = torch.empty(int(L.mi_gconv_stats_elems(B, Ho, Wo, N)), dtype=torch.float32, device=a.device)
+    check(L.mi_gconv(pa, lda, _p(wp), po, ldo, B, Ha, Wa, Ca, Ho, Wo, N, kh, kw, sh, sw, ph, pw, dh, dw, mode, _p(bias), _p(st), int(out_f32), _stream()),
+          "mi_gconv")
+    return out, st
+
+
+def gconv_wgrad(dy, x, dw, geom, accumulate=False):
+    """dw [O,I,kh,kw] fp32 (+)= conv weight gradient; dy [B,Ho,Wo,O], x [B,Ha,Wa,I] bf16 views."""
+    kh, kw, sh, sw, ph, pw, dh, dw_ = geom
+    B, Ho, Wo, O = dy.shape
+    _, Ha, Wa, I = x.shape
+    if not (dw.is_contiguous() and dw.dtype == torch.float32 and dw.numel() == O * I * kh * kw):
+        raise _lib.MiError("gconv_wgrad: dw must be contiguous fp32 [O,I,kh,kw]")
+    py, ldy = view(dy, torch.bfloat16)
+    px, ldx = view(x, torch.bfloat16)
+    L = _lib.lib()
+    ws = _workspace(L.mi_gconv_wgrad_workspace(B, Ho, Wo, O, I, kh, kw), dy.device, "gwgrad")
+    check(L.mi_gconv_wgrad(py, ldy, px, ldx, _p(dw), B, Ha, Wa, I, Ho, Wo, O, kh, kw, sh, sw, ph, pw, dh, dw_, int(accumulate), _p(ws), ws.numel(), _stream()),
+          "mi_gconv_wgrad")
+    return dw
+
+
+def gconv_pack_multi(wflat, wp, wpt, table_dev, n_desc, total_blocks):
+    check(_lib.lib().mi_gconv_pack_multi(_p(wflat), _p(wp), _p(wpt), _p(table_dev), n_desc, total_blocks, _stream()), "mi_gconv_pack_multi")
+
+
+def pack_elems(O, I, kh, kw):
+    return int(_lib.lib().mi_gconv_pack_elems(O, I, kh, kw))
+
+
+def gconv_pack(w):
+    """One conv's fp32 OIHW weight -> (forward pack, data-gradient pack); the module-level path packs every conv in one launch."""
+    O, I, kh, kw = w.shape
+    n = pack_elems(O, I, kh, kw)
+    wp = torch.empty(n, dtype=torch.bfloat16, device=w.device)
+    wpt = torch.empty(n, dtype=torch.bfloat16, device=w.device)
+    table = torch.tensor([[0, 0, 0, O, I, kh * kw, 0, 0]], dtype=torch.int64, device=w.device)
+    gconv_pack_multi(w.detach().contiguous().view(-1), wp, wpt, table, 1, -(-n // 1024))
+    return wp, wpt
+
+
+def gbn_finalize(stats, C, count, gamma, beta, running_mean, running_var, momentum, eps):
+    dev = stats.device
+    out = torch.empty((4, C), dtype=torch.float32, device=dev)       # mean, invstd, scale, shift
+    tiles = stats.numel() // (2 * C)
+    check(_lib.lib().mi_gbn_finalize(_p(stats), tiles, C, int(count), _p(gamma), _p(beta), _p(running_mean), _p(running_var), float(momentum), float(eps),
+                                     _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), _stream()), "mi_gbn_finalize")
+    return out
+
+
+def gbn_fold(gamma, beta, rm, rv, eps):
+    C = gamma.numel()
+    out = torch.empty((2, C), dtype=torch.float32, device=gamma.device)
+    check(_lib.lib().mi_gbn_fold(_p(gamma), _p(beta), _p(rm), _p(rv), float(eps), _p(out[0]), _p(out[1]), C, _stream()), "mi_gbn_fold")
+    return out[0], out[1]
+
+
+def gbn_apply(y, scale, shift, relu, add=None, out=None, out_f32=False):
+    B, H, W, C = y.shape
+    if out is None:
+        out = new(B, H, W, C, y.device, torch.float32 if out_f32 else torch.bfloat16)
+    py, ldy = view(y, torch.bfloat16)
+    po, ldo = view(out, torch.float32 if out_f32 else torch.bfloat16)
+    pa, lda = view(add, torch.bfloat16) if add is not None else (None, 0)
+    check(_lib.lib().mi_gbn_apply(py, ldy, _p(scale), _p(shift), pa, lda, po, ldo, int(out_f32), B * H * W, C, int(relu), _stream()), "mi_gbn_apply")
+    return out
+
+
+def _gm(g, mask):
+    pg, ldg = view(g)
+    gf = g.dtype == torch.float32
+    if mask is None:
+        return pg, ldg, int(gf), None, 0, 0
+    pm, ldm = view(mask)
+    return pg, ldg, int(gf), pm, ldm, int(mask.dtype == torch.float32)
+
+
+def gbn_bwd_sums(g, y, mask, mean, invstd, dbeta, dgamma, accumulate=False):
+    """dbeta / dgamma: fp32 [C] slots written (or accumulated into); y None: dbeta only."""
+    B, H, W, C = g.shape
+    M = B * H * W
+    pg, ldg, gf, pm, ldm, mf = _gm(g, mask)
+    py, ldy = view(y, torch.bfloat16) if y is not None else (None, 0)
+    L = _lib.lib()
+    ws = _workspace(L.mi_gcolsum_workspace(M, C), g.device, "gcolsum")
+    check(L.mi_gbn_bwd_sums(pg, ldg, gf, py, ldy, pm, ldm, mf, _p(mean), _p(invstd), M, C, _p(dbeta), _p(dgamma), int(accumulate), _p(ws), ws.numel(),
+                            _stream()), "mi_gbn_bwd_sums")
+
+
+def gbn_bwd_apply(g, y, mask, mean, invstd, gamma, dbeta, dgamma, count, out=None):
+    B, H, W, C = g.shape
+    if out is None:
+        out = new(B, H, W, C, g.device)
+    pg, ldg, gf, pm, ldm, mf = _gm(g, mask)
+    py, ldy = view(y, torch.bfloat16)
+    po, ldo = view(out, torch.bfloat16)
+    check(_lib.lib().mi_gbn_bwd_apply(pg, ldg, gf, py, ldy, pm, ldm, mf, _p(mean), _p(invstd), _p(gamma), _p(dbeta), _p(dgamma), ctypes.c_float(1.0 / count),
+                                      po, ldo, B * H * W, C, _stream()), "mi_gbn_bwd_apply")
+    return out
+
+
+def gbinary(op, a, b=None, out=None, out_dtype=None):
+    B, H, W, C = a.shape
+    if out_dtype is None:
+        out_dtype = a.dtype if out is None else out.dtype
+    if out is None:
+        out = new(B, H, W, C, a.device, out_dtype)
+    if a.dtype == out.dtype:
+        dt = 0 if a.dtype == torch.bfloat16 else 1
+    else:
+        dt = 2 if a.dtype == torch.float32 else 3
+    pa, lda = view(a)
+    pb, ldb = view(b, a.dtype) if b is not None else (None, 0)
+    po, ldo = view(out)
+    check(_lib.lib().mi_gbinary(op, dt, pa, lda, pb, ldb, po, ldo, B * H * W, C, _stream()), "mi_gbinary")
+    return out
+
+
+def gavgpool(x, k, stride, pad, include_pad, out_hw, out=None):
+    B, H, W, C = x.shape
+    Ho, Wo = out_hw
+    if out is None:
+        out = new(B, Ho, Wo, C, x.device)
+    px, ldx = view(x, torch.bfloat16)
+    po, ldo = view(out, torch.bfloat16)
+    check(_lib.lib().mi_gavgpool(px, ldx, po, ldo, B, H, W, C, Ho, Wo, k, stride, pad, int(include_pad), 0, _stream()), "mi_gavgpool")
+    return out
+
+
+def gavgpool_bwd(dout, in_hw, k, stride, pad, include_pad, dx=None):
+    B, Ho, Wo, C = dout.shape
+    H, W = in_hw
+    if dx is None:
+        dx = new(B, H, W, C, dout.device)
+    px, ldx = view(dx, torch.bfloat16)
+    po, ldo = view(dout, torch.bfloat16)
+    check(_lib.lib().mi_gavgpool(px, ldx, po, ldo, B, H, W, C, Ho, Wo, k, stride, pad, int(include_pad), 1, _stream()), "mi_gavgpool(bwd)")
+    return dx
+
+
+def resize_scales(in_hw, out_hw, align_corners, scale_factor=None):
+    """The per-axis source scale as ATen's area_pixel_compute_scale computes it (fp32)."""
+    def one(i, o):
+        if align_corners:
+            return float(torch.tensor((i - 1) / (o - 1) if o > 1 else 0.0, dtype=torch.float32))
+        if scale_factor is not None:
+            return float(torch.tensor(1.0 / scale_factor, dtype=torch.float32))
+        return float(torch.tensor(i / o, dtype=torch.float32))
+    return one(in_hw[0], out_hw[0]), one(in_hw[1], out_hw[1])
+
+
+def gresize(x, out_hw, align_corners, scale_factor=None, out=None):
+    B, H, W, C = x.shape
+    Ho, Wo = out_hw
+    if out is None:
+        out = new(B, Ho, Wo, C, x.device, x.dtype)
+    sh, sw = resize_scales((H, W), out_hw, align_corners, scale_factor)
+    px, ldx = view(x)
+    po, ldo = view(out, x.dtype)
+    check(_lib.lib().mi_gresize(px, ldx, po, ldo, int(x.dtype == torch.float32), B, H, W, C, Ho, Wo, int(align_corners), sh, sw, 0, _stream()), "mi_gresize")
+    return out
+
+
+def gresize_bwd(dout, in_hw, align_corners, scale_factor=None, dx=None):
+    B, Ho, Wo, C = dout.shape
+    H, W = in_hw
+    if dx is None:
+        dx = new(B, H, W, C, dout.device, dout.dtype)
+    sh, sw = resize_scales((H, W), (Ho, Wo), align_corners, scale_factor)
+    px, ldx = view(dx, dout.dtype)
+    po, ldo = view(dout)
+    check(_lib.lib().mi_gresize(px, ldx, po, ldo, int(dout.dtype == torch.float32), B, H, W, C, Ho, Wo, int(align_corners), sh, sw, 1, _stream()), "mi_gresize(bwd)")
+    return dx
+
+
+def gra_fwd(gate, feat, out=None):
+    """gate fp32 [B,H,W,1], feat bf16 [B,H,W,C] -> (1 - sigmoid(gate)) * feat"""
+    B, H, W, C = feat.shape
+    if out is None:
+        out = new(B, H, W, C, feat.device)
+    pf, ldf = view(feat, torch.bfloat16)
+    po, ldo = view(out, torch.bfloat16)
+    if not (gate.dtype == torch.float32 and gate.is_contiguous() and gate.numel() == B * H * W):
+        raise _lib.MiError("gra_fwd: gate must be contiguous fp32 with one value per pixel")
+    check(_lib.lib().mi_gra_fwd(_p(gate), pf, ldf, po, ldo, B * H * W, C, _stream()), "mi_gra_fwd")
+    return out
+
+
+def gra_bwd(gate, feat, dy):
+    B, H, W, C = feat.shape
+    dfeat = new(B, H, W, C, feat.device)
+    dgate = torch.empty((B, H, W, 1), dtype=torch.float32, device=feat.device)
+    pf, ldf = view(feat, torch.bfloat16)
+    pd, ldd = view(dy, torch.bfloat16)
+    po, ldo = view(dfeat, torch.bfloat16)
+    check(_lib.lib().mi_gra_bwd(_p(gate), pf, ldf, pd, ldd, po, ldo, _p(dgate), B * H * W, C, _stream()), "mi_gra_bwd")
+    return dfeat, dgate

@@ -1,0 +1,275 @@
+"""GPU parity of the view-based kernels of the PraNet path (csrc/gconv.hip, csrc/gnet.hip) through the C-ABI, each against the torch
+op the reference calls (core/models/classifiers/pranet/PraNet_Res2Net.py, Res2Net_v1b.py) evaluated in float64 on the SAME bf16-rounded
+operands.  bf16 outputs: within one bf16 ulp of the exact value (2^-8 relative) plus the fp32-accumulation noise; fp32 outputs: 2e-5 of
+the tensor's range.  Every case runs on channel-slice views of wider tensors where the network does."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gk():
+    import __graft_entry__ as entry
+    entry.build()
+    from rnd_semantic_segmentation_amd import gk as g
+    return g
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(torch.bfloat16)
+
+
+def _nhwc(x_nchw):
+    return x_nchw.permute(0, 2, 3, 1).contiguous()
+
+
+def _embed(x_nhwc, ld, off):
+    """x as the channel slice [off, off + C) of a wider NHWC tensor filled with a sentinel."""
+    B, H, W, C = x_nhwc.shape
+    big = torch.full((B, H, W, ld), 7.0, dtype=x_nhwc.dtype, device=x_nhwc.device)
+    big[..., off:off + C] = x_nhwc
+    return big, big[..., off:off + C]
+
+
+def _close_bf16(got, ref, what, ulps=1.0, floor=2e-5):
+    got = got.double().cpu()
+    ref = ref.double()
+    tol = ulps * 2.0 ** -8 * ref.abs() + floor * ref.abs().max()
+    bad = (got - ref).abs() > tol
+    assert not bad.any(), "%s: %d of %d outside tolerance, worst %.3e (ref max %.3e)" % (what, int(bad.sum()), bad.numel(), float((got - ref).abs().max()), float(ref.abs().max()))
+
+
+CONV_CASES = [
+    # Cin, Cout, (kh, kw), (sh, sw), (ph, pw), (dh, dw), B, H, W, (ld_in, off_in), (ld_out, off_out)
+    (26, 26, (3, 3), (1, 1), (1, 1), (1, 1), 2, 13, 11, (104, 26), (104, 52)),       # Res2Net group conv on a split / into a cat
+    (52, 52, (3, 3), (2, 2), (1, 1), (1, 1), 2, 14, 10, (208, 52), (208, 0)),        # 'stage' block: stride 2
+    (3, 32, (3, 3), (2, 2), (1, 1), (1, 1), 2, 18, 22, (3, 0), (32, 0)),             # stem conv on the image (odd alignment)
+    (32, 32, (1, 7), (1, 1), (0, 3), (1, 1), 2, 9, 12, (32, 0), (32, 0)),            # RFB 1x7
+    (32, 32, (7, 1), (1, 1), (3, 0), (1, 1), 2, 9, 12, (32, 0), (128, 96)),          # RFB 7x1
+    (32, 32, (3, 3), (1, 1), (7, 7), (7, 7), 2, 11, 11, (32, 0), (128, 32)),         # RFB dilation 7 into the cat
+    (256, 256, (5, 5), (1, 1), (2, 2), (1, 1), 1, 11, 11, (256, 0), (256, 0)),       # reverse-attention 5x5
+    (128, 208, (1, 1), (1, 1), (0, 0), (1, 1), 2, 12, 12, (128, 0), (208, 0)),       # conv1 of a bottleneck: N = 208
+    (104, 256, (1, 1), (1, 1), (0, 0), (1, 1), 3, 17, 9, (104, 0), (256, 0)),        # conv3
+    (96, 96, (3, 3), (1, 1), (1, 1), (1, 1), 2, 12, 12, (96, 0), (96, 0)),           # partial decoder
+    (64, 1, (3, 3), (1, 1), (1, 1), (1, 1), 2, 12, 12, (64, 0), (1, 0)),             # one-channel side output
+]
+
+
+def _conv_setup(case, seed):
+    Cin, Cout, k, s, p, d, B, H, W, (ldi, offi), (ldo, offo) = case
+    x = _rand((B, Cin, H, W), seed)
+    w = _rand((Cout, Cin) + k, seed + 1, 1.0 / np.sqrt(Cin * k[0] * k[1])).float()
+    geom = k + s + p + d
+    return x, w, geom
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_gconv_forward_and_batch_statistics(gk, case):
+    Cin, Cout, k, s, p, d, B, H, W, (ldi, offi), (ldo, offo) = case
+    x, w, geom = _conv_setup(case, 100 + Cin)
+    wq = w.to(torch.bfloat16)
+    ref = F.conv2d(x.double(), wq.double(), None, s, p, d)
+    xv_big, xv = _embed(_nhwc(x).cuda(), ldi, offi)
+    wp, _ = gk.gconv_pack(w.cuda())
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    obig = torch.full((B, Ho, Wo, ldo), 3.0, dtype=torch.bfloat16, device="cuda")
+    out, st = gk.gconv(xv, wp, Cout, geom, out=obig[..., offo:offo + Cout], stats=True)
+    torch.cuda.synchronize()
+    _close_bf16(out.permute(0, 3, 1, 2), ref, "conv %s" % (case,))
+    rest = torch.cat([obig[..., :offo], obig[..., offo + Cout:]], -1)
+    assert bool((rest == 3.0).all()), "the conv wrote outside its channel slice"
+    # statistics of the ROUNDED outputs, tile partials summed here
+    tiles = st.numel() // (2 * Cout)
+    st = st.view(tiles, 2, Cout).double().sum(0).cpu()
+    o64 = out.double().cpu().reshape(-1, Cout)
+    assert torch.allclose(st[0], o64.sum(0), rtol=1e-5, atol=1e-4 * float(o64.abs().max()))
+    assert torch.allclose(st[1], (o64 * o64).sum(0), rtol=1e-5, atol=1e-6)
+
+
+def test_gconv_fp32_output_with_bias(gk):
+    """agg.conv5 = nn.Conv2d(96, 1, 1) with bias (PraNet_Res2Net.py:77) and the one-channel side maps: fp32 store, no rounding."""
+    x = _rand((2, 96, 12, 12), 5)
+    w = _rand((1, 96, 1, 1), 6, 0.1).float()
+    b = torch.tensor([0.37])
+    ref = F.conv2d(x.double(), w.to(torch.bfloat16).double(), b.double())
+    wp, _ = gk.gconv_pack(w.cuda())
+    out, _ = gk.gconv(_nhwc(x).cuda(), wp, 1, (1, 1, 1, 1, 0, 0, 1, 1), bias=b.cuda(), out_f32=True)
+    assert out.dtype == torch.float32
+    assert float((out.permute(0, 3, 1, 2).double().cpu() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_gconv_data_and_weight_gradient(gk, case):
+    Cin, Cout, k, s, p, d, B, H, W, (ldi, offi), (ldo, offo) = case
+    x, w, geom = _conv_setup(case, 300 + Cin)
+    xd = x.double().requires_grad_(True)
+    wd = w.to(torch.bfloat16).double().requires_grad_(True)
+    y = F.conv2d(xd, wd, None, s, p, d)
+    dy = _rand(tuple(y.shape), 17)
+    y.backward(dy.double())
+    _, wpt = gk.gconv_pack(w.cuda())
+    dbig, dyv = _embed(_nhwc(dy).cuda(), ldo, offo)
+    xbig, xv = _embed(_nhwc(x).cuda(), ldi, offi)
+    if Cin != 3:                         # the image needs no gradient
+        gbig = torch.full((B, H, W, ldi), 5.0, dtype=torch.bfloat16, device="cuda")
+        dx, _ = gk.gconv(dyv, wpt, Cin, geom, out=gbig[..., offi:offi + Cin], mode=gk.GATHER_DGRAD, out_hw=(H, W))
+        torch.cuda.synchronize()
+        _close_bf16(dx.permute(0, 3, 1, 2), xd.grad, "dgrad %s" % (case,))
+    dw = torch.empty_like(w, device="cuda")
+    gk.gconv_wgrad(dyv, xv, dw, geom)
+    got = dw.double().cpu()
+    err = float((got - wd.grad).abs().max()) / float(wd.grad.abs().max())
+    assert err < 2e-5, "wgrad %s: %.3e" % (case, err)
+    gk.gconv_wgrad(dyv, xv, dw, geom, accumulate=True)
+    assert float((dw.double().cpu() - 2 * wd.grad).abs().max()) / float(wd.grad.abs().max()) < 4e-5
+
+
+def test_gconv_weight_gradient_is_bit_reproducible_and_splits_k(gk):
+    """M = 16 x 44 x 44 pixels: several K splits; two runs give the same bits (fixed-order slab reduction)."""
+    x = _rand((16, 52, 44, 44), 1)
+    dy = _rand((16, 52, 44, 44), 2)
+    dw1 = torch.empty((52, 52, 3, 3), device="cuda")
+    dw2 = torch.empty_like(dw1)
+    geom = (3, 3, 1, 1, 1, 1, 1, 1)
+    a, b = _nhwc(dy).cuda(), _nhwc(x).cuda()
+    gk.gconv_wgrad(a, b, dw1, geom)
+    gk.gconv_wgrad(a, b, dw2, geom)
+    assert torch.equal(dw1, dw2)
+    ref = torch.nn.grad.conv2d_weight(x.float().cuda(), (52, 52, 3, 3), dy.float().cuda(), 1, 1, 1)
+    assert float((dw1 - ref).abs().max()) / float(ref.abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("C,relu,with_add,f32", [(26, True, False, False), (104, True, True, False), (32, False, False, False), (1, False, False, True),
+                                                 (256, True, False, False)])
+def test_batchnorm_train_forward_backward(gk, C, relu, with_add, f32):
+    """conv statistics -> mi_gbn_finalize -> mi_gbn_apply, and the two backward kernels, against nn.BatchNorm2d in train() (float64)."""
+    B, H, W = 3, 13, 9
+    x = _rand((B, max(C, 8), H, W), 40 + C)
+    w = _rand((C, max(C, 8), 1, 1), 41 + C, 0.3).float()
+    wp, _ = gk.gconv_pack(w.cuda())
+    y, st = gk.gconv(_nhwc(x).cuda(), wp, C, (1, 1, 1, 1, 0, 0, 1, 1), stats=True)          # y: bf16 conv output + tile statistics
+    bn = torch.nn.BatchNorm2d(C).double()
+    with torch.no_grad():
+        bn.weight.copy_(torch.linspace(0.5, 1.5, C))
+        bn.bias.copy_(torch.linspace(-0.3, 0.4, C))
+        bn.running_mean.copy_(torch.linspace(-1, 1, C))
+        bn.running_var.copy_(torch.linspace(0.5, 2, C))
+    rm, rv = bn.running_mean.float().cuda(), bn.running_var.float().cuda()
+    yd = y.permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
+    add = _rand((B, C, H, W), 43) if with_add else None
+    ref = bn(yd)
+    if add is not None:
+        ref = ref + add.double()
+    if relu:
+        ref = F.relu(ref)
+    g = _rand((B, C, H, W), 44)
+    if f32:
+        g = g.float() * 1.37
+    ref.backward(g.double())
+    fin = gk.gbn_finalize(st, C, B * H * W, bn.weight.float().cuda(), bn.bias.float().cuda(), rm, rv, 0.1, 1e-5)
+    mean, invstd, scale, shift = fin[0], fin[1], fin[2], fin[3]
+    addv = _embed(_nhwc(add).cuda(), C + 6, 4)[1] if add is not None else None
+    out = gk.gbn_apply(y, scale, shift, relu, add=addv, out_f32=f32)
+    torch.cuda.synchronize()
+    if f32:
+        assert float((out.permute(0, 3, 1, 2).double().cpu() - ref.detach()).abs().max()) < 2e-5 * float(ref.abs().max()) + 1e-5
+    else:
+        _close_bf16(out.permute(0, 3, 1, 2), ref.detach(), "bn apply C=%d" % C, floor=1e-4)
+    assert torch.allclose(rm.double().cpu(), bn.running_mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(rv.double().cpu(), bn.running_var, rtol=1e-4, atol=1e-6)
+    # backward: the ReLU mask comes from the stored output
+    gv = _nhwc(g).cuda()
+    dbeta, dgamma = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    mask = out if relu else None
+    gk.gbn_bwd_sums(gv, y, mask, mean, invstd, dbeta, dgamma)
+    dy = gk.gbn_bwd_apply(gv, y, mask, mean, invstd, bn.weight.float().cuda(), dbeta, dgamma, B * H * W)
+    torch.cuda.synchronize()
+    # the reference masks by its own (float64) output; a bf16-rounded output that became exactly 0 differs only where |ref| < 1 ulp
+    assert torch.allclose(dbeta.double().cpu(), bn.bias.grad, rtol=2e-3, atol=2e-3 * float(bn.bias.grad.abs().max()))
+    assert torch.allclose(dgamma.double().cpu(), bn.weight.grad, rtol=2e-3, atol=2e-3 * float(bn.weight.grad.abs().max()))
+    e = float((dy.permute(0, 3, 1, 2).double().cpu() - yd.grad).abs().max()) / float(yd.grad.abs().max())
+    assert e < 1.5e-2, e                # bf16 dy (2^-8) on top of the mask agreement
+
+
+def test_bias_gradient_is_a_column_sum(gk):
+    g = torch.randn(2, 12, 12, 1, device="cuda")
+    db = torch.zeros(1, device="cuda")
+    gk.gbn_bwd_sums(g, None, None, None, None, db, None)
+    assert abs(float(db) - float(g.double().sum())) < 1e-4
+
+
+@pytest.mark.parametrize("k,s,p,inc,H,W", [(3, 1, 1, True, 9, 11), (3, 2, 1, True, 12, 10), (2, 2, 0, False, 12, 10), (2, 2, 0, False, 13, 9)])
+def test_average_pools(gk, k, s, p, inc, H, W):
+    """AvgPool2d(3, stride, 1) of the 'stage' blocks and AvgPool2d(s, s, ceil_mode=True, count_include_pad=False) of the downsample path."""
+    C = 26
+    x = _rand((2, C, H, W), 60)
+    xd = x.double().requires_grad_(True)
+    ref = F.avg_pool2d(xd, k, s, p, ceil_mode=not inc, count_include_pad=inc)
+    g = _rand(tuple(ref.shape), 61)
+    ref.backward(g.double())
+    xbig, xv = _embed(_nhwc(x).cuda(), 104, 78)
+    out = gk.gavgpool(xv, k, s, p, inc, (ref.shape[2], ref.shape[3]))
+    _close_bf16(out.permute(0, 3, 1, 2), ref.detach(), "avgpool")
+    dx = gk.gavgpool_bwd(_nhwc(g).cuda(), (H, W), k, s, p, inc)
+    _close_bf16(dx.permute(0, 3, 1, 2), xd.grad, "avgpool bwd")
+
+
+@pytest.mark.parametrize("H,W,sf,align,f32", [(11, 11, 32, False, True), (44, 44, 0.25, False, True), (11, 11, 2, False, True), (12, 9, 8, False, True),
+                                               (6, 5, 2, True, False), (3, 3, 2, True, False)])
+def test_bilinear_resize_both_conventions(gk, H, W, sf, align, f32):
+    """F.interpolate(scale_factor=..., mode='bilinear') with align_corners False (PraNet_Res2Net.py:127-177) on fp32 one-channel maps and
+    nn.Upsample(scale_factor=2, align_corners=True) (:67) on bf16 feature maps; forward and backward."""
+    C = 1 if f32 else 32
+    x = _rand((2, C, H, W), 70)
+    x = x.float() if f32 else x
+    xd = x.double().requires_grad_(True)
+    ref = F.interpolate(xd, scale_factor=sf, mode="bilinear", align_corners=align)
+    g = _rand(tuple(ref.shape), 71)
+    g = g.float() if f32 else g
+    ref.backward(g.double())
+    out = gk.gresize(_nhwc(x).cuda(), (ref.shape[2], ref.shape[3]), align, sf)
+    dx = gk.gresize_bwd(_nhwc(g).cuda(), (H, W), align, sf)
+    torch.cuda.synchronize()
+    if f32:
+        assert float((out.permute(0, 3, 1, 2).double().cpu() - ref.detach()).abs().max()) < 1e-5
+        assert float((dx.permute(0, 3, 1, 2).double().cpu() - xd.grad).abs().max()) < 1e-5 * max(1.0, float(xd.grad.abs().max()))
+    else:
+        _close_bf16(out.permute(0, 3, 1, 2), ref.detach(), "resize")
+        _close_bf16(dx.permute(0, 3, 1, 2), xd.grad, "resize bwd")
+
+
+def test_resize_to_a_given_size(gk):
+    """pranet_tester.py:39: F.upsample(output, size=(h, w), mode='bilinear', align_corners=False) - scale = in / out."""
+    x = torch.randn(1, 1, 88, 88)
+    ref = F.interpolate(x, size=(300, 211), mode="bilinear", align_corners=False)
+    out = gk.gresize(_nhwc(x).cuda(), (300, 211), False, None)
+    assert float((out.permute(0, 3, 1, 2).cpu() - ref).abs().max()) < 1e-5
+
+
+def test_elementwise_and_reverse_attention(gk):
+    a, b = _rand((2, 26, 7, 9), 80), _rand((2, 26, 7, 9), 81)
+    abig, av = _embed(_nhwc(a).cuda(), 104, 26)
+    bv = _nhwc(b).cuda()
+    _close_bf16(gk.gbinary(gk.OP_ADD, av, bv).permute(0, 3, 1, 2), a.double() + b.double(), "add")
+    _close_bf16(gk.gbinary(gk.OP_MUL, av, bv).permute(0, 3, 1, 2), a.double() * b.double(), "mul")
+    _close_bf16(gk.gbinary(gk.OP_RELU_MASK, av, bv).permute(0, 3, 1, 2), torch.where(b > 0, a, torch.zeros_like(a)).double(), "mask")
+    assert torch.equal(gk.gbinary(gk.OP_COPY, av).cpu(), _nhwc(a))
+    f = torch.randn(2, 7, 9, 1, device="cuda")
+    assert torch.equal(gk.gbinary(gk.OP_COPY, f, out_dtype=torch.bfloat16), f.to(torch.bfloat16))
+    # reverse attention
+    feat = _rand((2, 64, 7, 9), 82)
+    gate = torch.randn(2, 1, 7, 9)
+    fd, gd = feat.double().requires_grad_(True), gate.double().requires_grad_(True)
+    ref = (-1 * torch.sigmoid(gd) + 1).expand(-1, 64, -1, -1).mul(fd)
+    dy = _rand((2, 64, 7, 9), 83)
+    ref.backward(dy.double())
+    gt = _nhwc(gate).cuda()
+    out = gk.gra_fwd(gt, _nhwc(feat).cuda())
+    _close_bf16(out.permute(0, 3, 1, 2), ref.detach(), "reverse attention")
+    dfeat, dgate = gk.gra_bwd(gt, _nhwc(feat).cuda(), _nhwc(dy).cuda())
+    _close_bf16(dfeat.permute(0, 3, 1, 2), fd.grad, "reverse attention dfeat")
+    assert float((dgate.permute(0, 3, 1, 2).double().cpu() - gd.grad).abs().max()) < 1e-4 * float(gd.grad.abs().max()) + 1e-5
