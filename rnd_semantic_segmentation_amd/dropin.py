@@ -3,8 +3,8 @@ so the reference's own scripts / plugins (`from core.configs import cfg`,
 `from core.trainers.aspp_trainer import ASPPTrainer`, `from base.base_trainer import BaseTrainer`, ...)
 run on the MI355X engine unchanged.  Installed by the tiny top-level `core/` and `base/` packages.
 
-Only the DeepLabV2 hot path and its FADA adversarial step are mapped; the other model families of the
-reference (gald, pranet, attn, vgg) are out of scope and raise ImportError with that message.
+Mapped: the DeepLabV2 hot path, its FADA adversarial step and the PraNet path (row N3); the other model families of
+the reference (gald, attn, vgg) are out of scope and raise ImportError with that message.
 """
 import importlib
 import importlib.abc
@@ -28,11 +28,16 @@ ALIASES = {
     "core.testers.aspp_tester": _PKG + "tester",                      # core/testers/aspp_tester.py
     "core.utils.utility": _PKG + "metrics",                           # core/utils/utility.py (DeepLab subset)
     "core.utils.adapt_lr": _PKG + "metrics",                          # core/utils/adapt_lr.py:12-17
+    "core.trainers.pranet_trainer": _PKG + "pranet",                  # core/trainers/pranet_trainer.py
+    "core.testers.pranet_tester": _PKG + "pranet",                    # core/testers/pranet_tester.py
+    "core.models.classifiers.pranet.PraNet_Res2Net": _PKG + "pranet", # PraNet, RFB_modified, aggregation
+    "core.models.classifiers.pranet.Res2Net_v1b": _PKG + "pranet",    # Bottle2neck
+    "core.utils.utils": _PKG + "pranet",                              # clip_gradient, AvgMeter (core/utils/utils.py:6-38)
     "core.datasets.build": _PKG + "data",                             # core/datasets/build.py:5-30
     "base.base_trainer": _PKG + "plugin",                             # base/base_trainer.py
     "base.base_model": _PKG + "plugin",                               # base/base_model.py
 }
-PACKAGES = {"core.models", "core.models.classifiers", "core.models.classifiers.aspp", "core.components", "core.trainers", "core.adapters", "core.combos",
+PACKAGES = {"core.models", "core.models.classifiers", "core.models.classifiers.aspp", "core.models.classifiers.pranet", "core.components", "core.trainers", "core.adapters", "core.combos",
             "core.testers", "core.utils", "core.datasets"}
 
 

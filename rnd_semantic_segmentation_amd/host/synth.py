@@ -139,6 +139,25 @@ def synth_label(batch, height, width, num_classes=19, seed=1234, ignore=255, bor
     return lab
 
 
+def synth_polyp(batch, height, width, seed=1234):
+    """(image float32 [B,3,H,W], mask float32 [B,1,H,W] in {0,1}): one or two elliptic blobs per image; the image is the noise of
+    synth_image plus a brightness offset inside the blob, so that a network CAN learn the mask (training-parity tests)."""
+    img = synth_image(batch, height, width, seed=seed)
+    yy, xx = np.mgrid[0:height, 0:width].astype(np.float64)
+    mask = np.zeros((batch, 1, height, width), np.float32)
+    par = uniform("polyp", (batch, 2, 5), salt=seed) + 0.5          # in [0, 1)
+    for b in range(batch):
+        for k in range(2):
+            cy, cx, ry, rx, on = par[b, k]
+            if k == 1 and on < 0.5:
+                continue
+            cy, cx = (0.2 + 0.6 * cy) * height, (0.2 + 0.6 * cx) * width
+            ry, rx = (0.08 + 0.17 * ry) * height, (0.08 + 0.17 * rx) * width
+            mask[b, 0][((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0] = 1.0
+    img = img + 1.5 * mask
+    return img.astype(np.float32), mask
+
+
 def bf16_round(a):
     """Round float32 numpy array to the nearest bf16 (ties to even), returned as float32."""
     a = np.ascontiguousarray(a, dtype=np.float32)

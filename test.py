@@ -20,9 +20,13 @@ def test(cfg, config, args):
     data = build_dataset(cfg, mode="test", is_source=False)
     loader = torch.utils.data.DataLoader(data, batch_size=cfg.TEST.BATCH_SIZE, shuffle=False, num_workers=2, pin_memory=True,
                                          collate_fn=build_collate_fn(cfg), sampler=None)
-    if not name.startswith("aspp"):
-        raise NotImplementedError("tester %r: only 'aspp*' is on the MI355X hot path" % name)
-    tester = ASPPTester(cfg, device, loader, logger, config["palette"], config["trainid2name"], saveres=args.saveres)
+    if name.startswith("pranet"):                            # reference test.py:35-36
+        from core.testers.pranet_tester import PranetTester
+        tester = PranetTester(cfg, device, loader, logger)
+    elif not name.startswith("aspp"):
+        raise NotImplementedError("tester %r: 'aspp*' and 'pranet*' are on the MI355X engine" % name)
+    else:
+        tester = ASPPTester(cfg, device, loader, logger, config["palette"], config["trainid2name"], saveres=args.saveres)
     if cfg.resume:
         tester._load_checkpoint()
     else:

@@ -145,3 +145,23 @@ print("rccl c-abi ok")
 '''
     r = run(["-c", code], {})
     assert r.returncode == 0 and "rccl c-abi ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_pranet_train_src_then_test_py_roundtrip(tmp_path):
+    """BASELINE config[3] through the unchanged scripts: `train_src.py --model pranet -cfg configs/pranet_src_polyp.yaml` (reference
+    train_src.py:29-30) trains PraNet on synthetic polyp crops - three passes per batch, warm-up schedule, PraNet-<epoch>.pth with the
+    reference's checkpoint keys - and `test.py -c renders/kvasir.json` (reference test.py:35-36) resumes from it and prints the meters."""
+    out = str(tmp_path / "pranet") + "/"
+    r = run(["train_src.py", "--model", "pranet", "-cfg", "configs/pranet_src_polyp.yaml", "OUTPUT_DIR", out, "SOLVER.EPOCHS", "2", "SOLVER.CHECKPOINT_PERIOD", "1",
+             "SOLVER.BATCH_SIZE", "2", "INPUT.TRAINSIZE", "96"], {"MI_SYNTH_LEN": "4"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    log = r.stderr + r.stdout
+    assert "lateral-2:" in log and "learning_rate: 0.00001250" in log and "learning_rate: 0.00003000" in log       # BASE_LR / 8, then warm-up step 1
+    ck = torch.load(os.path.join(out, "PraNet-2.pth"), map_location="cpu")
+    assert set(ck) == {"epoch", "model", "optimizer"} and ck["epoch"] == 2 and len(ck["model"]) == 922
+    assert int(ck["model"]["resnet.bn1.num_batches_tracked"]) == 12                                                 # 2 epochs x 2 batches x 3 passes
+    assert set(ck["optimizer"]["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(ck["optimizer"]["state"][0]["step"]) == 12
+    r = run(["test.py", "-cfg", "configs/pranet_src_polyp.yaml", "-c", "renders/kvasir.json", "OUTPUT_DIR", out, "resume", os.path.join(out, "PraNet-2.pth"),
+             "INPUT.INPUT_SIZE_TEST", "(96, 96)"], {"MI_SYNTH_LEN": "3"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "Micro metric, val result: mIoU/mF1" in r.stderr + r.stdout

@@ -19,9 +19,13 @@ def main(name, cfg, local_rank):
     loader = torch.utils.data.DataLoader(
         data, batch_size=max(1, cfg.SOLVER.BATCH_SIZE // world), shuffle=sampler is None, num_workers=4, pin_memory=True,
         collate_fn=build_collate_fn(cfg), sampler=sampler, drop_last=True)
-    if name != "aspp":
-        raise NotImplementedError("model %r: only 'aspp' (DeepLabV2-ResNet + ASPP) is on the MI355X hot path" % name)
-    ASPPTrainer(name, cfg, loader, local_rank).train()
+    if name == "aspp":
+        ASPPTrainer(name, cfg, loader, local_rank).train()
+    elif name == "pranet":                                   # reference train_src.py:29-30
+        from core.trainers.pranet_trainer import PraNetTrainer
+        PraNetTrainer(name, cfg, loader, local_rank).train()
+    else:
+        raise NotImplementedError("model %r: 'aspp' (DeepLabV2-ResNet + ASPP) and 'pranet' are on the MI355X engine" % name)
 
 
 if __name__ == "__main__":
