@@ -211,6 +211,10 @@ int mi_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, si
 int mi_adam_step_clamped(float* p, float* g, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2,
                          float eps, int step, float grad_clamp, void* stream);
 
+/* the same with hyper = {lr, beta1, beta2, eps, grad_clamp (<= 0: none), step} read from DEVICE memory at run time (HIP-graph replay: by-value
+ * arguments are frozen into a captured graph; the step count and with it the bias corrections change on every replay) */
+int mi_adam_step_dev(float* p, float* g, float* exp_avg, float* exp_avg_sq, size_t n, const float* hyper /*[6], device*/, void* stream);
+
 /* ---- exact-fp32 evaluation path (test.py / ASPPTester; csrc/igemm_f32.hip) ---------------------------------------
  * The reference computes in fp32; BASELINE.json asks for argmax masks identical to it.  These entry points run the same
  * graph on fp32 NHWC activations with fp32 weights on the f32-input MFMA (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain,

@@ -50,6 +50,7 @@ SIGNATURES = {
     "mi_upsample_softce": (I, [P, F, F, P, I, I, P, P] + [I] * 6 + [F, P, Z, P]),
     "mi_adam_step": (I, [P, P, P, P, Z, F, F, F, F, I, P]),
     "mi_adam_step_clamped": (I, [P, P, P, P, Z, F, F, F, F, I, F, P]),
+    "mi_adam_step_dev": (I, [P, P, P, P, Z, P, P]),
     "mi_sgd_step": (I, [P, P, P, Z, F, F, F, P]),
     "mi_sgd_step_dev": (I, [P, P, P, Z, P, P]),
     "mi_pack_weight_f32": (I, [P, P, I, I, I, P]),

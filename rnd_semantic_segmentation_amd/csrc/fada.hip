@@ -235,6 +235,28 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float*
     }
 }
 
+// The same update with every hyper-parameter read from DEVICE memory (hyper = {lr, beta1, beta2, eps, grad_clamp (<= 0: none), step}): a
+// captured HIP graph freezes by-value kernel arguments, and Adam's bias corrections change with the step count on every replay.
+__global__ void adam_dev_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                                const float* __restrict__ hyper) {
+    const float lr = hyper[0], beta1 = hyper[1], beta2 = hyper[2], eps = hyper[3], clamp = hyper[4], step = hyper[5];
+    const float step_size = (float)((double)lr / (1.0 - pow((double)beta1, (double)step)));
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float gi = g[i];
+        if (clamp > 0.f) {
+            gi = fminf(fmaxf(gi, -clamp), clamp);
+            g[i] = gi;
+        }
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    }
+}
+
 inline unsigned nblk(long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
 inline int npx_bound(const Axis& ax) {
@@ -301,6 +323,15 @@ extern "C" int mi_adam_step(float* p, const float* g, float* exp_avg, float* exp
     hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, const_cast<float*>(g), exp_avg, exp_avg_sq, n,
                        (float)(lr / bc1), beta1, beta2, (float)(1.0 / sqrt(bc2)), eps, 0.f);
     MI_CHECK_LAUNCH("mi_adam_step");
+    return MI_OK;
+}
+
+extern "C" int mi_adam_step_dev(float* p, float* g, float* exp_avg, float* exp_avg_sq, size_t n, const float* hyper, void* stream) {
+    MI_REQUIRE(p && g && exp_avg && exp_avg_sq && hyper && n > 0, "mi_adam_step_dev: bad argument");
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, exp_avg, exp_avg_sq, n, hyper);
+    MI_CHECK_LAUNCH("mi_adam_step_dev");
     return MI_OK;
 }
 

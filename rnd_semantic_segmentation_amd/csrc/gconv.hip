@@ -38,25 +38,27 @@ struct GConvP {
     int kw, sh, sw, ph, pw, dh, dw, mode, nchunks;
 };
 
+__device__ __attribute__((aligned(256))) uint32_t g_gzero[64];        // source of every padded / out-of-range access (zero-initialised)
+
+// Loads are UNCONDITIONAL (an out-of-range access reads the zero page instead of being branched around): with control flow around a load
+// the compiler cannot count the loads in flight and waits for all of them (s_waitcnt vmcnt(0)) at the first use - which also drains the
+// prefetch of the chunk after next, i.e. every K step would pay a full memory round trip.
 template <int VEC>
 __device__ __forceinline__ void gload16(const __bf16* src, int c0, int C, bool ok, bf16x8 (&r)[2]) {
     // 16 channels c0 .. c0+15 of one pixel row; channels >= C (and everything when !ok) read as zero
+    const __bf16* zero = reinterpret_cast<const __bf16*>(g_gzero);
     if constexpr (VEC == 8) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int c = c0 + 8 * h;
-            bf16x8 v;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
-            if (ok && c < C) v = *reinterpret_cast<const bf16x8*>(src + c);
-            r[h] = v;
+            r[h] = *reinterpret_cast<const bf16x8*>((ok && c < C) ? src + c : zero);
         }
     } else if constexpr (VEC == 2) {
         union { bf16x8 v[2]; uint32_t u[8]; } x;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = c0 + 2 * j;
-            x.u[j] = (ok && c < C) ? *reinterpret_cast<const uint32_t*>(src + c) : 0u;
+            x.u[j] = *reinterpret_cast<const uint32_t*>((ok && c < C) ? src + c : zero);
         }
         r[0] = x.v[0];
         r[1] = x.v[1];
@@ -65,7 +67,7 @@ __device__ __forceinline__ void gload16(const __bf16* src, int c0, int C, bool o
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int c = c0 + j;
-            x.u[j] = (ok && c < C) ? *reinterpret_cast<const uint16_t*>(src + c) : (uint16_t)0;
+            x.u[j] = *reinterpret_cast<const uint16_t*>((ok && c < C) ? src + c : zero);
         }
         r[0] = x.v[0];
         r[1] = x.v[1];
@@ -106,11 +108,15 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
     constexpr int BROWS = (BN * 4 + 255) / 256;
     const int bch = tid & 3;
 
-    bf16x8 ra[2], rb[BROWS];
-    auto load = [&](int it) {
+    // two register sets: the chunk after next is in flight while the next one waits in registers and the current one is in LDS
+    bf16x8 ra0[2], rb0[BROWS], ra1[2], rb1[BROWS];
+    const int total = p.T * p.nchunks;
+    auto load = [&](int it, bf16x8 (&ra)[2], bf16x8 (&rb)[BROWS]) {
+        const bool live = it < total;                  // past the end: every lane reads the zero page (cheap, and keeps the issue unconditional)
+        it = live ? it : 0;
         const int tap = it / p.nchunks, kc = it - tap * p.nchunks;
         const int ky = tap / p.kw, kx = tap - ky * p.kw;
-        bool ok = am_ok;
+        bool ok = am_ok && live;
         int ih, iw;
         if (p.mode == MI_GATHER_FWD) {
             ih = aoh * p.sh + ky * p.dh - p.ph;
@@ -129,14 +135,10 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
         for (int j = 0; j < BROWS; ++j) {
             const int nr = (tid >> 2) + j * 64;
             const int n = n0 + nr;
-            bf16x8 v;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
-            if (nr < BN && n < p.Npad) v = *reinterpret_cast<const bf16x8*>(wt + (long)n * p.Cpad);
-            rb[j] = v;
+            rb[j] = *reinterpret_cast<const bf16x8*>((live && nr < BN && n < p.Npad) ? wt + (long)n * p.Cpad : reinterpret_cast<const __bf16*>(g_gzero));
         }
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf, const bf16x8 (&ra)[2], const bf16x8 (&rb)[BROWS]) {
         __bf16* a = As + buf * GBM * GRS + arow * GRS + ahalf * 16;
         *reinterpret_cast<bf16x8*>(a) = ra[0];
         *reinterpret_cast<bf16x8*>(a + 8) = ra[1];
@@ -153,14 +155,8 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int total = p.T * p.nchunks;
     const int frow = lane & 15, fk = (lane >> 4) * 8;
-    load(0);
-    stash(0);
-    __syncthreads();
-    for (int it = 0; it < total; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < total) load(it + 1);
+    auto compute = [&](int buf) {
         const __bf16* a = As + buf * GBM * GRS + (wave * 32 + frow) * GRS + fk;
         const __bf16* b = Bs + buf * BN * GRS + frow * GRS + fk;
         bf16x8 fa[2], fb[NT];
@@ -172,7 +168,22 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        if (it + 1 < total) stash(buf ^ 1);
+    };
+    // every load and every LDS write below is issued unconditionally (past the last chunk the lanes read the zero page into a buffer nobody reads): with a
+    // branch around an issue the compiler no longer knows how many loads are in flight and falls back to draining them all
+    load(0, ra0, rb0);
+    load(1, ra1, rb1);
+    stash(0, ra0, rb0);
+    __syncthreads();
+    for (int it = 0; it < total; it += 2) {
+        load(it + 2, ra0, rb0);
+        compute(0);
+        stash(1, ra1, rb1);
+        __syncthreads();
+        if (it + 1 >= total) break;
+        load(it + 3, ra1, rb1);
+        compute(1);
+        stash(0, ra0, rb0);
         __syncthreads();
     }
 
@@ -309,18 +320,15 @@ struct GWgP {
 template <int VEC>
 __device__ __forceinline__ bf16x8 gload8(const __bf16* src, int c0, int C, bool ok) {
     union { bf16x8 v; uint32_t u[4]; uint16_t h[8]; } x;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) x.u[j] = 0u;
+    const __bf16* zero = reinterpret_cast<const __bf16*>(g_gzero);
     if constexpr (VEC == 8) {
-        if (ok && c0 < C) x.v = *reinterpret_cast<const bf16x8*>(src + c0);
+        x.v = *reinterpret_cast<const bf16x8*>((ok && c0 < C) ? src + c0 : zero);
     } else if constexpr (VEC == 2) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (ok && c0 + 2 * j < C) x.u[j] = *reinterpret_cast<const uint32_t*>(src + c0 + 2 * j);
+        for (int j = 0; j < 4; ++j) x.u[j] = *reinterpret_cast<const uint32_t*>((ok && c0 + 2 * j < C) ? src + c0 + 2 * j : zero);
     } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (ok && c0 + j < C) x.h[j] = *reinterpret_cast<const uint16_t*>(src + c0 + j);
+        for (int j = 0; j < 8; ++j) x.h[j] = *reinterpret_cast<const uint16_t*>((ok && c0 + j < C) ? src + c0 + j : zero);
     }
     return x.v;
 }
@@ -349,10 +357,10 @@ __global__ __launch_bounds__(256) void gwgrad_kernel(GWgP p) {
     const int lpx = tid >> 3, lch = tid & 7;          // loader: pixel row of the step, 8-channel chunk
     const int hw = p.Ho * p.Wo;
 
-    bf16x8 ry, rx;
-    auto load = [&](int kt) {
+    bf16x8 ry0, rx0, ry1, rx1;
+    auto load = [&](int kt, bf16x8& ry, bf16x8& rx) {
         const int m = m_begin + kt * WKP + lpx;
-        const bool ok = m < m_end;
+        const bool ok = m < m_end;                     // (a step past the last one has every row >= m_end: zero-page reads)
         const int mm = ok ? m : 0;
         ry = gload8<YVEC>(p.dY + (long)mm * p.ldy, o0 + lch * 8, p.O, ok);
         const int b = mm / hw, rem = mm - b * hw;
@@ -362,7 +370,7 @@ __global__ __launch_bounds__(256) void gwgrad_kernel(GWgP p) {
         const long pix = xok ? ((long)b * p.Ha + ih) * p.Wa + iw : 0;
         rx = gload8<XVEC>(p.X + pix * p.ldx, i0 + lch * 8, p.I, xok);
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf, const bf16x8& ry, const bf16x8& rx) {
         char* sy = smem + buf * (2 * WKP * WRS) + lpx * WRS + lch * 16;
         *reinterpret_cast<bf16x8*>(sy) = ry;
         *reinterpret_cast<bf16x8*>(sy + WKP * WRS) = rx;
@@ -380,63 +388,81 @@ __global__ __launch_bounds__(256) void gwgrad_kernel(GWgP p) {
     const int g = lane >> 4, q = (lane & 15) >> 2, pc = lane & 3;
     const int row_off = (g * 4 + q) * WRS + pc * 8;
 
+    auto compute = [&](int buf) {
+        const char* sy = smem + buf * (2 * WKP * WRS) + row_off;
+        const char* sx = sy + WKP * WRS;
+        union { bf16x8 v; s16x4 h[2]; } xf[2], yf[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const char* base = sx + (wi * 32 + a * 16) * 2;
+            xf[a].h[0] = tr_read(base);
+            xf[a].h[1] = tr_read(base + 16 * WRS);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const char* base = sy + (wo * 32 + b * 16) * 2;
+            yf[b].h[0] = tr_read(base);
+            yf[b].h[1] = tr_read(base + 16 * WRS);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[a].v, yf[b].v, acc[a][b], 0, 0, 0);
+    };
     if (nk > 0) {
-        load(0);
-        stash(0);
+        load(0, ry0, rx0);
+        load(1, ry1, rx1);
+        stash(0, ry0, rx0);
         __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int buf = kt & 1;
-            if (kt + 1 < nk) load(kt + 1);
-            const char* sy = smem + buf * (2 * WKP * WRS) + row_off;
-            const char* sx = sy + WKP * WRS;
-            union { bf16x8 v; s16x4 h[2]; } xf[2], yf[2];
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const char* base = sx + (wi * 32 + a * 16) * 2;
-                xf[a].h[0] = tr_read(base);
-                xf[a].h[1] = tr_read(base + 16 * WRS);
-            }
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const char* base = sy + (wo * 32 + b * 16) * 2;
-                yf[b].h[0] = tr_read(base);
-                yf[b].h[1] = tr_read(base + 16 * WRS);
-            }
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[a].v, yf[b].v, acc[a][b], 0, 0, 0);
-            if (kt + 1 < nk) stash(buf ^ 1);
+        for (int kt = 0; kt < nk; kt += 2) {
+            load(kt + 2, ry0, rx0);
+            compute(0);
+            stash(1, ry1, rx1);
+            __syncthreads();
+            if (kt + 1 >= nk) break;
+            load(kt + 3, ry1, rx1);
+            compute(1);
+            stash(0, ry0, rx0);
             __syncthreads();
         }
     }
-    // slab[split][t][o][i] over the padded tile grid (i fastest): the lane owns o = column, four consecutive i = rows
-    const int Opad = p.o_tiles * WTO, Ipad = p.i_tiles * WTI;
-    float* slab = p.slab + ((long)(split * p.T + t) * Opad) * Ipad;
+    // slab[split][t][o][i], o < O, i < roundup(I, 4) (i fastest): the lane owns o = column, four consecutive i = rows
+    const int Ip = (p.I + 3) & ~3;
+    float* slab = p.slab + ((long)(split * p.T + t) * p.O) * Ip;
     const int fcol = lane & 15, fq = lane >> 4;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int o = o0 + wo * 32 + b * 16 + fcol;
+        if (o >= p.O) continue;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const int i = i0 + wi * 32 + a * 16 + fq * 4;
-            *reinterpret_cast<f32x4*>(slab + (long)o * Ipad + i) = acc[a][b];
+            if (i < Ip) *reinterpret_cast<f32x4*>(slab + (long)o * Ip + i) = acc[a][b];
         }
     }
 }
 
-// dw[o][i][t] (+)= sum over the K splits in ascending order (bitwise reproducible)
-__global__ void gwgrad_reduce_kernel(const float* slab, float* dw, int O, int I, int T, int Opad, int Ipad, int S, int accumulate) {
-    const long n = (long)O * I * T;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-        const int t = (int)(e % T);
-        const long oi = e / T;
-        const int i = (int)(oi % I), o = (int)(oi / I);
-        const float* src = slab + ((long)t * Opad + o) * Ipad + i;
-        const long sstride = (long)T * Opad * Ipad;
+// dw[o][i][t] (+)= sum over the K splits (bitwise reproducible); 8 lanes per output element (t, o, i: i fastest): lane l adds the splits
+// l, l + 8, ... in ascending order, the eight partial sums are combined by a fixed butterfly
+__global__ __launch_bounds__(256) void gwgrad_reduce_kernel(const float* slab, float* dw, int O, int I, int T, int S, int accumulate) {
+    const int Ip = (I + 3) & ~3;
+    const long n = (long)T * O * I;
+    const long sstride = (long)T * O * Ip;
+    const int l = threadIdx.x & 7;
+    for (long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 3; e < n; e += ((long)gridDim.x * blockDim.x) >> 3) {      // the 8 lanes of a group share e
+        const int i = (int)(e % I);
+        const long r = e / I;
+        const int o = (int)(r % O), t = (int)(r / O);
+        const float* src = slab + ((long)t * O + o) * Ip + i;
         float v = 0.f;
-        for (int s = 0; s < S; ++s) v += src[s * sstride];
-        dw[e] = accumulate ? dw[e] + v : v;
+        for (int s = l; s < S; s += 8) v += src[s * sstride];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        if (l == 0) {
+            float* d = dw + ((long)o * I + i) * T + t;
+            *d = accumulate ? *d + v : v;
+        }
     }
 }
 
@@ -444,8 +470,8 @@ void gwgrad_plan(int M, int O, int I, int T, int* S, int* rows, int* ot, int* it
     *ot = (O + WTO - 1) / WTO;
     *it = (I + WTI - 1) / WTI;
     const int tiles = *ot * *it * T;
-    int s = (1024 + tiles - 1) / tiles;
-    const int smax = (M + 255) / 256;
+    int s = (768 + tiles - 1) / tiles;               // ~768 workgroups
+    const int smax = (M + 8 * WKP - 1) / (8 * WKP);  // at least 8 K steps per split
     if (s > smax) s = smax;
     if (s < 1) s = 1;
     int r = (M + s - 1) / s;
@@ -554,6 +580,7 @@ int mi_gconv(const void* a, long lda, const void* wp, void* out, long ldo, int B
         MI_REQUIRE(N <= 32, "mi_gconv: fp32 outputs are the one-channel side maps (N <= 32), got N = %d", N);
         glaunch_a<32>(p, avec, 1, true, s);
     } else if (N <= 32) glaunch_a<32>(p, avec, ovec, false, s);
+    else if (mt * ((N + 63) / 64) < 256) glaunch_a<32>(p, avec, ovec, false, s);          // few pixels (1/32 resolution): narrower tiles, more workgroups
     else if (N <= 64 || N % 128 == 64 || mt * ((N + 127) / 128) < 512) glaunch_a<64>(p, avec, ovec, false, s);
     else glaunch_a<128>(p, avec, ovec, false, s);
     MI_CHECK_LAUNCH("gconv_kernel");
@@ -565,7 +592,7 @@ size_t mi_gconv_stats_elems(int B, int Ho, int Wo, int N) { return (size_t)(((lo
 size_t mi_gconv_wgrad_workspace(int B, int Ho, int Wo, int O, int I, int kh, int kw) {
     int S, rows, ot, it;
     gwgrad_plan(B * Ho * Wo, O, I, kh * kw, &S, &rows, &ot, &it);
-    return (size_t)S * kh * kw * ot * WTO * it * WTI * sizeof(float);
+    return (size_t)S * kh * kw * O * ((I + 3) & ~3) * sizeof(float);
 }
 
 int mi_gconv_wgrad(const void* dy, long ldy, const void* x, long ldx, float* dw, int B, int Ha, int Wa, int I, int Ho, int Wo, int O,
@@ -588,7 +615,7 @@ int mi_gconv_wgrad(const void* dy, long ldy, const void* x, long ldx, float* dw,
     p.Ho = Ho; p.Wo = Wo; p.Ha = Ha; p.Wa = Wa;
     p.kw = kw; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.dh = dh; p.dw = dw_;
     gwgrad_plan(p.M, O, I, p.T, &p.S, &p.rows_per_split, &p.o_tiles, &p.i_tiles);
-    const size_t need = (size_t)p.S * p.T * p.o_tiles * WTO * p.i_tiles * WTI * sizeof(float);
+    const size_t need = (size_t)p.S * p.T * O * ((I + 3) & ~3) * sizeof(float);
     if (workspace_bytes < need) return mi_set_error(MI_ENOMEM, "mi_gconv_wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
     hipStream_t s = (hipStream_t)stream;
     const int yv = view_vec(dy, ldy, O), xv = view_vec(x, ldx, I);
@@ -606,8 +633,8 @@ int mi_gconv_wgrad(const void* dy, long ldy, const void* x, long ldx, float* dw,
 #undef GW
     MI_CHECK_LAUNCH("gwgrad_kernel");
     const long n = (long)O * I * p.T;
-    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    hipLaunchKernelGGL(gwgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slab, dw, O, I, p.T, p.o_tiles * WTO, p.i_tiles * WTI, p.S, accumulate);
+    const int blocks = (int)((n + 31) / 32 < 4096 ? (n + 31) / 32 : 4096);          // 32 output elements (8 lanes each) per block
+    hipLaunchKernelGGL(gwgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slab, dw, O, I, p.T, p.S, accumulate);
     MI_CHECK_LAUNCH("gwgrad_reduce_kernel");
     return MI_OK;
 }

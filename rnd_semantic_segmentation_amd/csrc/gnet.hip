@@ -5,6 +5,8 @@
 //   reference: core/models/classifiers/pranet/PraNet_Res2Net.py:7-179, Res2Net_v1b.py:15-170.
 // Every reduction has a fixed order (no float atomics): two runs give the same bits.
 #include "mi_common.h"
+#include <initializer_list>
+#include <utility>
 
 namespace {
 
@@ -13,6 +15,77 @@ __device__ __forceinline__ float ldf(const float* p) { return *p; }
 __device__ __forceinline__ void stf(__bf16* p, float v) { *p = (__bf16)v; }
 __device__ __forceinline__ void stf(float* p, float v) { *p = v; }
 
+
+// VEC consecutive channels of one pixel as floats (VEC = 8: one 16-byte access, 2: one 4-byte access, 1: scalar); fp32 sources are scalar
+template <int VEC>
+__device__ __forceinline__ void ldv(const __bf16* p, float (&v)[VEC]) {
+    if constexpr (VEC == 8) {
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)x[j];
+    } else if constexpr (VEC == 2) {
+        const bf16x2 x = *reinterpret_cast<const bf16x2*>(p);
+        v[0] = (float)x[0];
+        v[1] = (float)x[1];
+    } else {
+        v[0] = (float)*p;
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void ldv(const float* p, float (&v)[VEC]) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) v[j] = p[j];
+}
+template <int VEC>
+__device__ __forceinline__ void stv(__bf16* p, const float (&v)[VEC]) {
+    if constexpr (VEC == 8) {
+        bf16x8 x;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = (__bf16)v[j];
+        *reinterpret_cast<bf16x8*>(p) = x;
+    } else if constexpr (VEC == 2) {
+        bf16x2 x;
+        x[0] = (__bf16)v[0];
+        x[1] = (__bf16)v[1];
+        *reinterpret_cast<bf16x2*>(p) = x;
+    } else {
+        *p = (__bf16)v[0];
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void stv(float* p, const float (&v)[VEC]) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) p[j] = v[j];
+}
+// VEC per-channel fp32 parameters starting at channel c0 (c0 % VEC == 0; VEC == 8: two 16-byte loads - the parameter vectors of this path are
+// 32-byte aligned rows of 256-byte aligned buffers)
+template <int VEC>
+__device__ __forceinline__ void ldp(const float* p, float (&v)[VEC]) {
+    if constexpr (VEC == 8) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = a[j];
+            v[4 + j] = b[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[j] = p[j];
+    }
+}
+// widest access every one of the given bf16 views allows: 8 channels (16-byte aligned, ld % 8 == 0), 2, or 1
+inline int common_vec(int C, std::initializer_list<std::pair<const void*, long>> views) {
+    int v = 8;
+    if (C % 8) v = C % 2 ? 1 : 2;
+    for (const auto& pv : views) {
+        if (!pv.first) continue;
+        const uintptr_t a = reinterpret_cast<uintptr_t>(pv.first);
+        if (v == 8 && ((a & 15) || pv.second % 8)) v = 2;
+        if (v == 2 && ((a & 3) || pv.second % 2)) v = 1;
+    }
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------------ BatchNorm: finalize
 // partials[tile][2][C] (sum, sum of squares per 128-pixel tile, written by gconv_kernel) -> batch mean / biased variance in double,
 // invstd, the folded affine (scale = gamma * invstd, shift = beta - mean * scale) and torch's running-statistics update
@@ -20,12 +93,12 @@ __device__ __forceinline__ void stf(float* p, float v) { *p = v; }
 __global__ __launch_bounds__(256) void gbn_finalize_kernel(const float* partials, int tiles, int C, double count, const float* gamma, const float* beta,
                                                            float* running_mean, float* running_var, float momentum, float eps, float* mean_out,
                                                            float* invstd_out, float* scale_out, float* shift_out) {
-    __shared__ double red[2][4][64];
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx;
+    __shared__ double red[2][32][8];
+    const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;          // 8 channels x 32 tile lanes: short serial chains, the loads of a lane independent
+    const int c = blockIdx.x * 8 + cx;
     double s1 = 0.0, s2 = 0.0;
     if (c < C)
-        for (int t = ry; t < tiles; t += 4) {
+        for (int t = ry; t < tiles; t += 32) {
             s1 += (double)partials[(long)t * 2 * C + c];
             s2 += (double)partials[(long)t * 2 * C + C + c];
         }
@@ -33,8 +106,12 @@ __global__ __launch_bounds__(256) void gbn_finalize_kernel(const float* partials
     red[1][ry][cx] = s2;
     __syncthreads();
     if (ry == 0 && c < C) {
-        s1 = red[0][0][cx] + red[0][1][cx] + red[0][2][cx] + red[0][3][cx];
-        s2 = red[1][0][cx] + red[1][1][cx] + red[1][2][cx] + red[1][3][cx];
+        s1 = s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            s1 += red[0][k][cx];
+            s2 += red[1][k][cx];
+        }
         const double mean = s1 / count;
         double var = s2 / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -73,83 +150,118 @@ __global__ __launch_bounds__(256) void gbn_apply_kernel(const __bf16* y, long ld
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
         const long m = e / cv;
         const int c0 = (int)(e - m * cv) * VEC;
-        float v[VEC];
-        if constexpr (VEC == 8) {
-            const bf16x8 yv = *reinterpret_cast<const bf16x8*>(y + m * ldy + c0);
+        float v[VEC], a[VEC], sc[VEC], sh[VEC];
+        ldv<VEC>(y + m * ldy + c0, v);
+        ldp<VEC>(scale + c0, sc);
+        ldp<VEC>(shift + c0, sh);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (float)yv[j];
-        } else {
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) v[j] = (float)y[m * ldy + c0 + j];
-        }
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) v[j] = v[j] * scale[c0 + j] + shift[c0 + j];
+        for (int j = 0; j < VEC; ++j) v[j] = v[j] * sc[j] + sh[j];
         if (add) {
-            if constexpr (VEC == 8) {
-                const bf16x8 av = *reinterpret_cast<const bf16x8*>(add + m * ldadd + c0);
+            ldv<VEC>(add + m * ldadd + c0, a);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += (float)av[j];
-            } else {
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) v[j] += (float)add[m * ldadd + c0 + j];
-            }
+            for (int j = 0; j < VEC; ++j) v[j] += a[j];
         }
         if (relu) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) v[j] = fmaxf(v[j], 0.f);
         }
-        if constexpr (VEC == 8 && sizeof(TO) == 2) {
-            bf16x8 ov;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) ov[j] = (__bf16)v[j];
-            *reinterpret_cast<bf16x8*>(out + m * ldo + c0) = ov;
-        } else {
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) stf(out + m * ldo + c0 + j, v[j]);
-        }
+        stv<VEC>(out + m * ldo + c0, v);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ column sums (BatchNorm backward, bias gradients)
 // partial[blk][0][c] = sum_m g'[m][c], partial[blk][1][c] = sum_m g'[m][c] * (y[m][c] - mean[c]) * invstd[c] over the block's rows;
 // g' = g where mask[m][c] > 0 (mask = the layer's ReLU output) or g itself when mask is NULL; y NULL: the first sum only.
-constexpr int CS_ROWS = 256;
-template <typename TG, typename TM>
+// Thread layout: tx = chunk of VEC channels, ty = row lane (TX x TY = 256, TX = chunks per row rounded up to a power of two); a block
+// sums `rows_per_block` rows in registers, the row lanes are combined through LDS in a fixed order.
+struct ColsumPlan {
+    int vec, tx, ty, rows_per_block, blocks;
+};
+inline ColsumPlan colsum_plan(long M, int C, int vec) {
+    ColsumPlan q;
+    q.vec = vec;
+    const int cv = (C + vec - 1) / vec;
+    int tx = 1;
+    while (tx < cv && tx < 256) tx <<= 1;
+    q.tx = tx;
+    q.ty = 256 / tx;
+    long rpb = (M + 383) / 384;                       // ~384 blocks at most (1.5 per CU)
+    const long lo = (long)q.ty * 4;
+    if (rpb < lo) rpb = lo;
+    rpb = (rpb + q.ty - 1) / q.ty * q.ty;
+    q.rows_per_block = (int)rpb;
+    q.blocks = (int)((M + rpb - 1) / rpb);
+    return q;
+}
+template <int VEC, typename TG, typename TM>
 __global__ __launch_bounds__(256) void gcolsum_partial_kernel(const TG* g, long ldg, const __bf16* y, long ldy, const TM* mask, long ldm, const float* mean,
-                                                              const float* invstd, long M, int C, float* partial) {
-    __shared__ float red[2][4][64];
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int c = blockIdx.y * 64 + cx;
-    const long r0 = (long)blockIdx.x * CS_ROWS;
-    float s1 = 0.f, s2 = 0.f;
-    if (c < C) {
-        const float mu = y ? mean[c] : 0.f, is = y ? invstd[c] : 0.f;
-        for (int r = ry; r < CS_ROWS; r += 4) {
+                                                              const float* invstd, long M, int C, float* partial, int tx_n, int rows_per_block) {
+    __shared__ float red[2][256][VEC];
+    const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n, ty_n = 256 / tx_n;
+    float s1[VEC], s2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s1[j] = s2[j] = 0.f;
+    const int c0 = (blockIdx.y * tx_n + tx) * VEC;      // (blockIdx.y > 0 only when a row has more than 256 chunks)
+    if (c0 < C) {
+        float mu[VEC], is[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            mu[j] = y ? mean[c0 + j] : 0.f;
+            is[j] = y ? invstd[c0 + j] : 0.f;
+        }
+        const long r0 = (long)blockIdx.x * rows_per_block;
+        for (int r = ty; r < rows_per_block; r += ty_n) {
             const long m = r0 + r;
             if (m >= M) break;
-            float gv = ldf(g + m * ldg + c);
-            if (mask && !(ldf(mask + m * ldm + c) > 0.f)) gv = 0.f;
-            s1 += gv;
-            if (y) s2 += gv * (((float)y[m * ldy + c] - mu) * is);
+            float gv[VEC], yv[VEC], mv[VEC];
+            ldv<VEC>(g + m * ldg + c0, gv);
+            if (mask) {
+                ldv<VEC>(mask + m * ldm + c0, mv);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+                    if (!(mv[j] > 0.f)) gv[j] = 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) s1[j] += gv[j];
+            if (y) {
+                ldv<VEC>(y + m * ldy + c0, yv);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) s2[j] += gv[j] * ((yv[j] - mu[j]) * is[j]);
+            }
         }
     }
-    red[0][ry][cx] = s1;
-    red[1][ry][cx] = s2;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        red[0][threadIdx.x][j] = s1[j];
+        red[1][threadIdx.x][j] = s2[j];
+    }
     __syncthreads();
-    if (ry == 0 && c < C) {
-        partial[((long)blockIdx.x * 2 + 0) * C + c] = red[0][0][cx] + red[0][1][cx] + red[0][2][cx] + red[0][3][cx];
-        partial[((long)blockIdx.x * 2 + 1) * C + c] = red[1][0][cx] + red[1][1][cx] + red[1][2][cx] + red[1][3][cx];
+    if (ty == 0) {
+        if (c0 < C) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float a = 0.f, b = 0.f;
+                for (int k = 0; k < ty_n; ++k) {
+                    a += red[0][k * tx_n + tx][j];
+                    b += red[1][k * tx_n + tx][j];
+                }
+                if (c0 + j < C) {
+                    partial[((long)blockIdx.x * 2 + 0) * C + c0 + j] = a;
+                    partial[((long)blockIdx.x * 2 + 1) * C + c0 + j] = b;
+                }
+            }
+        }
     }
 }
 
-// out1[c] (+)= sum over blocks of partial[blk][0][c], out2 likewise (ascending block order, accumulated in double)
+// out1[c] (+)= sum over blocks of partial[blk][0][c], out2 likewise (ascending block order within a lane, lanes combined in order; double)
 __global__ __launch_bounds__(256) void gcolsum_final_kernel(const float* partial, int blocks, int C, float* out1, float* out2, int accumulate) {
-    __shared__ double red[2][4][64];
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx;
+    __shared__ double red[2][32][8];
+    const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cx;
     double s1 = 0.0, s2 = 0.0;
     if (c < C)
-        for (int b = ry; b < blocks; b += 4) {
+        for (int b = ry; b < blocks; b += 32) {
             s1 += (double)partial[((long)b * 2 + 0) * C + c];
             s2 += (double)partial[((long)b * 2 + 1) * C + c];
         }
@@ -157,47 +269,69 @@ __global__ __launch_bounds__(256) void gcolsum_final_kernel(const float* partial
     red[1][ry][cx] = s2;
     __syncthreads();
     if (ry == 0 && c < C) {
-        const float a = (float)(red[0][0][cx] + red[0][1][cx] + red[0][2][cx] + red[0][3][cx]);
-        const float b = (float)(red[1][0][cx] + red[1][1][cx] + red[1][2][cx] + red[1][3][cx]);
-        if (out1) out1[c] = accumulate ? out1[c] + a : a;
-        if (out2) out2[c] = accumulate ? out2[c] + b : b;
+        s1 = s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            s1 += red[0][k][cx];
+            s2 += red[1][k][cx];
+        }
+        if (out1) out1[c] = accumulate ? out1[c] + (float)s1 : (float)s1;
+        if (out2) out2[c] = accumulate ? out2[c] + (float)s2 : (float)s2;
     }
 }
 
 // dy = gamma * invstd * (g' - dbeta / n - xhat * dgamma / n)
-template <typename TG, typename TM>
+template <int VEC, typename TG, typename TM>
 __global__ __launch_bounds__(256) void gbn_bwd_apply_kernel(const TG* g, long ldg, const __bf16* y, long ldy, const TM* mask, long ldm, const float* mean,
                                                             const float* invstd, const float* gamma, const float* dbeta, const float* dgamma,
                                                             float inv_count, __bf16* dy, long lddy, long M, int C) {
-    const long n = M * C;
+    const int cv = C / VEC;
+    const long n = M * cv;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-        const long m = e / C;
-        const int c = (int)(e - m * C);
-        float gv = ldf(g + m * ldg + c);
-        if (mask && !(ldf(mask + m * ldm + c) > 0.f)) gv = 0.f;
-        const float is = invstd[c];
-        const float xhat = ((float)y[m * ldy + c] - mean[c]) * is;
-        const float ga = gamma ? gamma[c] : 1.f;
-        dy[m * lddy + c] = (__bf16)(ga * is * (gv - dbeta[c] * inv_count - xhat * dgamma[c] * inv_count));
+        const long m = e / cv;
+        const int c0 = (int)(e - m * cv) * VEC;
+        float gv[VEC], yv[VEC], mv[VEC], o[VEC];
+        ldv<VEC>(g + m * ldg + c0, gv);
+        ldv<VEC>(y + m * ldy + c0, yv);
+        if (mask) {
+            ldv<VEC>(mask + m * ldm + c0, mv);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                if (!(mv[j] > 0.f)) gv[j] = 0.f;
+        }
+        float is[VEC], mu[VEC], ga[VEC], db[VEC], dg[VEC];
+        ldp<VEC>(invstd + c0, is);
+        ldp<VEC>(mean + c0, mu);
+        ldp<VEC>(dbeta + c0, db);
+        ldp<VEC>(dgamma + c0, dg);
+        if (gamma) ldp<VEC>(gamma + c0, ga);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float xhat = (yv[j] - mu[j]) * is[j];
+            o[j] = (gamma ? ga[j] : 1.f) * is[j] * (gv[j] - db[j] * inv_count - xhat * dg[j] * inv_count);
+        }
+        stv<VEC>(dy + m * lddy + c0, o);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ elementwise on views
 enum { OP_ADD = 0, OP_MUL = 1, OP_COPY = 2, OP_RELU_MASK = 3 /* a where b > 0 else 0 */ };
-template <int OP, typename TA, typename TB, typename TO>
+template <int OP, int VEC, typename TA, typename TB, typename TO>
 __global__ __launch_bounds__(256) void gbinary_kernel(const TA* a, long lda, const TB* b, long ldb, TO* out, long ldo, long M, int C) {
-    const long n = M * C;
+    const int cv = C / VEC;
+    const long n = M * cv;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-        const long m = e / C;
-        const int c = (int)(e - m * C);
-        const float av = ldf(a + m * lda + c);
-        float r;
-        if constexpr (OP == OP_COPY) r = av;
-        else {
-            const float bv = ldf(b + m * ldb + c);
-            r = OP == OP_ADD ? av + bv : (OP == OP_MUL ? av * bv : (bv > 0.f ? av : 0.f));
+        const long m = e / cv;
+        const int c0 = (int)(e - m * cv) * VEC;
+        float av[VEC], bv[VEC], r[VEC];
+        ldv<VEC>(a + m * lda + c0, av);
+        if constexpr (OP != OP_COPY) ldv<VEC>(b + m * ldb + c0, bv);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            if constexpr (OP == OP_COPY) r[j] = av[j];
+            else r[j] = OP == OP_ADD ? av[j] + bv[j] : (OP == OP_MUL ? av[j] * bv[j] : (bv[j] > 0.f ? av[j] : 0.f));
         }
-        stf(out + m * ldo + c, r);
+        stv<VEC>(out + m * ldo + c0, r);
     }
 }
 
@@ -349,6 +483,62 @@ __global__ __launch_bounds__(256) void gresize_bwd_kernel(const T* dout, T* dx, 
     }
 }
 
+// The same sum with one WAVE per source element, for large magnifications (x8 .. x32: 20^2 .. 70^2 candidates and only B * h * w * C sources):
+// lane l takes the candidate rows l, l + 64, ... of the rectangle (each row summed left to right), the 64 partial sums are combined by a fixed
+// butterfly.  Deterministic, a different (equally valid) association than the thread-per-element kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void gresize_bwd_wave_kernel(const T* dout, T* dx, ResizeP q) {
+    const int lane = threadIdx.x & 63;
+    const long e = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long n = (long)q.B * q.H * q.W * q.C;
+    if (e >= n) return;
+    const int c = (int)(e % q.C);
+    long m = e / q.C;
+    const int iw = (int)(m % q.W);
+    const long t = m / q.W;
+    const int ih = (int)(t % q.H), b = (int)(t / q.H);
+    auto range = [&](int i, float scale, int out, int& lo, int& hi) {
+        if (scale <= 0.f) {
+            lo = 0;
+            hi = out - 1;
+            return;
+        }
+        const float off = q.align ? 0.f : 0.5f;
+        lo = (int)floorf(((float)(i - 1) + off) / scale - off) - 2;
+        hi = (int)ceilf(((float)(i + 1) + off) / scale - off) + 2;
+        if (lo < 0) lo = 0;
+        if (hi > out - 1) hi = out - 1;
+    };
+    int hlo, hhi, wlo, whi;
+    range(ih, q.sh, q.Ho, hlo, hhi);
+    range(iw, q.sw, q.Wo, wlo, whi);
+    float s = 0.f;
+    for (int oh = hlo + lane; oh <= hhi; oh += 64) {
+        int h0, hp;
+        float hl;
+        rs_src(oh, q.sh, q.align, q.H, h0, hp, hl);
+        float wh = 0.f;
+        if (h0 == ih) wh += 1.f - hl;
+        if (h0 + hp == ih) wh += hl;
+        if (wh == 0.f) continue;
+        float rs = 0.f;
+        const T* drow = dout + (((long)b * q.Ho + oh) * q.Wo) * q.ldo + c;
+        for (int ow = wlo; ow <= whi; ++ow) {
+            int w0, wp;
+            float wl;
+            rs_src(ow, q.sw, q.align, q.W, w0, wp, wl);
+            float ww = 0.f;
+            if (w0 == iw) ww += 1.f - wl;
+            if (w0 + wp == iw) ww += wl;
+            if (ww != 0.f) rs += ww * ldf(drow + (long)ow * q.ldo);
+        }
+        s += wh * rs;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) stf(dx + m * q.ldx + c, s);
+}
+
 // ------------------------------------------------------------------------------------------------ reverse attention (PraNet_Res2Net.py:131-133)
 // out[m][c] = (1 - sigmoid(gate[m])) * feat[m][c]   ( `-1*(torch.sigmoid(crop)) + 1` expanded over the channels, times the feature )
 __global__ __launch_bounds__(256) void gra_fwd_kernel(const float* gate, const __bf16* feat, long ldf_, __bf16* out, long ldo, long M, int C) {
@@ -393,7 +583,7 @@ int mi_gbn_finalize(const float* partials, int tiles, int C, long count, const f
     MI_REQUIRE(partials && mean_out && invstd_out && scale_out && shift_out, "mi_gbn_finalize: null operand");
     MI_REQUIRE(tiles > 0 && C > 0 && count > 0, "mi_gbn_finalize: empty shape");
     MI_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "mi_gbn_finalize: running_mean and running_var come together");
-    hipLaunchKernelGGL(gbn_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, partials, tiles, C, (double)count, gamma, beta,
+    hipLaunchKernelGGL(gbn_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, partials, tiles, C, (double)count, gamma, beta,
                        running_mean, running_var, momentum, eps, mean_out, invstd_out, scale_out, shift_out);
     MI_CHECK_LAUNCH("gbn_finalize_kernel");
     return MI_OK;
@@ -414,16 +604,17 @@ int mi_gbn_apply(const void* y, long ldy, const float* scale, const float* shift
     hipStream_t s = (hipStream_t)stream;
     const __bf16* yy = (const __bf16*)y;
     const __bf16* aa = (const __bf16*)add;
-    const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    const bool v8 = !out_f32 && C % 8 == 0 && ldy % 8 == 0 && ldo % 8 == 0 && al16(y) && al16(out) && (!add || (ldadd % 8 == 0 && al16(add)));
+    int vec = out_f32 ? 1 : common_vec(C, {{y, ldy}, {out, ldo}, {add, ldadd}});
+    if (vec == 8 && ((reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15)) vec = 2;
     if (out_f32) hipLaunchKernelGGL((gbn_apply_kernel<1, float>), dim3(grid_for(M * C)), dim3(256), 0, s, yy, ldy, scale, shift, aa, ldadd, (float*)out, ldo, M, C, relu);
-    else if (v8) hipLaunchKernelGGL((gbn_apply_kernel<8, __bf16>), dim3(grid_for(M * C / 8)), dim3(256), 0, s, yy, ldy, scale, shift, aa, ldadd, (__bf16*)out, ldo, M, C, relu);
+    else if (vec == 8) hipLaunchKernelGGL((gbn_apply_kernel<8, __bf16>), dim3(grid_for(M * C / 8)), dim3(256), 0, s, yy, ldy, scale, shift, aa, ldadd, (__bf16*)out, ldo, M, C, relu);
+    else if (vec == 2) hipLaunchKernelGGL((gbn_apply_kernel<2, __bf16>), dim3(grid_for(M * C / 2)), dim3(256), 0, s, yy, ldy, scale, shift, aa, ldadd, (__bf16*)out, ldo, M, C, relu);
     else hipLaunchKernelGGL((gbn_apply_kernel<1, __bf16>), dim3(grid_for(M * C)), dim3(256), 0, s, yy, ldy, scale, shift, aa, ldadd, (__bf16*)out, ldo, M, C, relu);
     MI_CHECK_LAUNCH("gbn_apply_kernel");
     return MI_OK;
 }
 
-size_t mi_gcolsum_workspace(long M, int C) { return (size_t)((M + CS_ROWS - 1) / CS_ROWS) * 2 * C * sizeof(float); }
+size_t mi_gcolsum_workspace(long M, int C) { (void)M; return (size_t)770 * 2 * C * sizeof(float); }      // colsum_plan never uses more than 769 blocks
 
 int mi_gbn_bwd_sums(const void* g, long ldg, int g_f32, const void* y, long ldy, const void* mask, long ldm, int mask_f32, const float* mean,
                     const float* invstd, long M, int C, float* dbeta, float* dgamma, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
@@ -433,18 +624,21 @@ int mi_gbn_bwd_sums(const void* g, long ldg, int g_f32, const void* y, long ldy,
     MI_REQUIRE(g_f32 || !mask_f32, "mi_gbn_bwd_sums: an fp32 mask goes with an fp32 gradient");
     if (workspace_bytes < mi_gcolsum_workspace(M, C)) return mi_set_error(MI_ENOMEM, "mi_gbn_bwd_sums: workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    const int blocks = (int)((M + CS_ROWS - 1) / CS_ROWS);
-    const dim3 grid(blocks, (C + 63) / 64);
     float* part = (float*)workspace;
     const __bf16* yy = (const __bf16*)y;
-    if (g_f32 && mask_f32)
-        hipLaunchKernelGGL((gcolsum_partial_kernel<float, float>), grid, dim3(256), 0, s, (const float*)g, ldg, yy, ldy, (const float*)mask, ldm, mean, invstd, M, C, part);
-    else if (g_f32)
-        hipLaunchKernelGGL((gcolsum_partial_kernel<float, __bf16>), grid, dim3(256), 0, s, (const float*)g, ldg, yy, ldy, (const __bf16*)mask, ldm, mean, invstd, M, C, part);
-    else
-        hipLaunchKernelGGL((gcolsum_partial_kernel<__bf16, __bf16>), grid, dim3(256), 0, s, (const __bf16*)g, ldg, yy, ldy, (const __bf16*)mask, ldm, mean, invstd, M, C, part);
+    const int vec = (g_f32 || mask_f32) ? 1 : common_vec(C, {{g, ldg}, {y, ldy}, {mask, ldm}});
+    const ColsumPlan q = colsum_plan(M, C, vec);
+    const int blocks = q.blocks;
+    const dim3 grid(blocks, ((C + vec - 1) / vec + q.tx - 1) / q.tx);
+#define CSK(V, TG, TM) hipLaunchKernelGGL((gcolsum_partial_kernel<V, TG, TM>), grid, dim3(256), 0, s, (const TG*)g, ldg, yy, ldy, (const TM*)mask, ldm, mean, invstd, M, C, part, q.tx, q.rows_per_block)
+    if (g_f32 && mask_f32) CSK(1, float, float);
+    else if (g_f32) CSK(1, float, __bf16);
+    else if (vec == 8) CSK(8, __bf16, __bf16);
+    else if (vec == 2) CSK(2, __bf16, __bf16);
+    else CSK(1, __bf16, __bf16);
+#undef CSK
     MI_CHECK_LAUNCH("gcolsum_partial_kernel");
-    hipLaunchKernelGGL(gcolsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, s, part, blocks, C, dbeta, dgamma, accumulate);
+    hipLaunchKernelGGL(gcolsum_final_kernel, dim3((C + 7) / 8), dim3(256), 0, s, part, blocks, C, dbeta, dgamma, accumulate);
     MI_CHECK_LAUNCH("gcolsum_final_kernel");
     return MI_OK;
 }
@@ -456,14 +650,18 @@ int mi_gbn_bwd_apply(const void* g, long ldg, int g_f32, const void* y, long ldy
     MI_REQUIRE(M > 0 && C > 0 && ldg >= C && ldy >= C && lddy >= C, "mi_gbn_bwd_apply: bad shape");
     MI_REQUIRE(g_f32 || !mask_f32, "mi_gbn_bwd_apply: an fp32 mask goes with an fp32 gradient");
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid(grid_for(M * C));
     const __bf16* yy = (const __bf16*)y;
-    if (g_f32 && mask_f32)
-        hipLaunchKernelGGL((gbn_bwd_apply_kernel<float, float>), grid, dim3(256), 0, s, (const float*)g, ldg, yy, ldy, (const float*)mask, ldm, mean, invstd, gamma, dbeta, dgamma, inv_count, (__bf16*)dy, lddy, M, C);
-    else if (g_f32)
-        hipLaunchKernelGGL((gbn_bwd_apply_kernel<float, __bf16>), grid, dim3(256), 0, s, (const float*)g, ldg, yy, ldy, (const __bf16*)mask, ldm, mean, invstd, gamma, dbeta, dgamma, inv_count, (__bf16*)dy, lddy, M, C);
-    else
-        hipLaunchKernelGGL((gbn_bwd_apply_kernel<__bf16, __bf16>), grid, dim3(256), 0, s, (const __bf16*)g, ldg, yy, ldy, (const __bf16*)mask, ldm, mean, invstd, gamma, dbeta, dgamma, inv_count, (__bf16*)dy, lddy, M, C);
+    int vec = (g_f32 || mask_f32) ? 1 : common_vec(C, {{g, ldg}, {y, ldy}, {mask, ldm}, {dy, lddy}});
+    if (vec == 8 && ((reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(invstd) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(dbeta) |
+                      reinterpret_cast<uintptr_t>(dgamma)) & 15)) vec = 2;
+    const dim3 grid(grid_for(M * C / vec));
+#define BAK(V, TG, TM) hipLaunchKernelGGL((gbn_bwd_apply_kernel<V, TG, TM>), grid, dim3(256), 0, s, (const TG*)g, ldg, yy, ldy, (const TM*)mask, ldm, mean, invstd, gamma, dbeta, dgamma, inv_count, (__bf16*)dy, lddy, M, C)
+    if (g_f32 && mask_f32) BAK(1, float, float);
+    else if (g_f32) BAK(1, float, __bf16);
+    else if (vec == 8) BAK(8, __bf16, __bf16);
+    else if (vec == 2) BAK(2, __bf16, __bf16);
+    else BAK(1, __bf16, __bf16);
+#undef BAK
     MI_CHECK_LAUNCH("gbn_bwd_apply_kernel");
     return MI_OK;
 }
@@ -475,20 +673,28 @@ int mi_gbinary(int op, int dtype, const void* a, long lda, const void* b, long l
     MI_REQUIRE(M > 0 && C > 0 && lda >= C && ldo >= C && (op == OP_COPY || ldb >= C), "mi_gbinary: bad shape");
     MI_REQUIRE(op >= 0 && op <= 3 && dtype >= 0 && dtype <= 3 && (dtype < 2 || op == OP_COPY), "mi_gbinary: op %d / dtype %d", op, dtype);
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid(grid_for(M * C));
-#define GB(OP, TA, TB, TO) hipLaunchKernelGGL((gbinary_kernel<OP, TA, TB, TO>), grid, dim3(256), 0, s, (const TA*)a, lda, (const TB*)b, ldb, (TO*)out, ldo, M, C)
+    const int vec = dtype == 0 ? common_vec(C, {{a, lda}, {out, ldo}, {op == OP_COPY ? nullptr : b, ldb}}) : 1;
+    const dim3 grid(grid_for(M * C / vec));
+#define GB(OP, V, TA, TB, TO) hipLaunchKernelGGL((gbinary_kernel<OP, V, TA, TB, TO>), grid, dim3(256), 0, s, (const TA*)a, lda, (const TB*)b, ldb, (TO*)out, ldo, M, C)
+#define GBV(OP)                                            \
+    do {                                                   \
+        if (vec == 8) GB(OP, 8, __bf16, __bf16, __bf16);   \
+        else if (vec == 2) GB(OP, 2, __bf16, __bf16, __bf16); \
+        else GB(OP, 1, __bf16, __bf16, __bf16);            \
+    } while (0)
     if (dtype == 0) {
-        if (op == OP_ADD) GB(OP_ADD, __bf16, __bf16, __bf16);
-        else if (op == OP_MUL) GB(OP_MUL, __bf16, __bf16, __bf16);
-        else if (op == OP_COPY) GB(OP_COPY, __bf16, __bf16, __bf16);
-        else GB(OP_RELU_MASK, __bf16, __bf16, __bf16);
+        if (op == OP_ADD) GBV(OP_ADD);
+        else if (op == OP_MUL) GBV(OP_MUL);
+        else if (op == OP_COPY) GBV(OP_COPY);
+        else GBV(OP_RELU_MASK);
     } else if (dtype == 1) {
-        if (op == OP_ADD) GB(OP_ADD, float, float, float);
-        else if (op == OP_MUL) GB(OP_MUL, float, float, float);
-        else if (op == OP_COPY) GB(OP_COPY, float, float, float);
-        else GB(OP_RELU_MASK, float, float, float);
-    } else if (dtype == 2) GB(OP_COPY, float, float, __bf16);
-    else GB(OP_COPY, __bf16, __bf16, float);
+        if (op == OP_ADD) GB(OP_ADD, 1, float, float, float);
+        else if (op == OP_MUL) GB(OP_MUL, 1, float, float, float);
+        else if (op == OP_COPY) GB(OP_COPY, 1, float, float, float);
+        else GB(OP_RELU_MASK, 1, float, float, float);
+    } else if (dtype == 2) GB(OP_COPY, 1, float, float, __bf16);
+    else GB(OP_COPY, 1, __bf16, __bf16, float);
+#undef GBV
 #undef GB
     MI_CHECK_LAUNCH("gbinary_kernel");
     return MI_OK;
@@ -518,9 +724,17 @@ int mi_gresize(const void* x, long ldx, void* out, long ldo, int f32, int B, int
         if (f32) hipLaunchKernelGGL((gresize_fwd_kernel<float>), grid, dim3(256), 0, s, (const float*)x, (float*)out, q);
         else hipLaunchKernelGGL((gresize_fwd_kernel<__bf16>), grid, dim3(256), 0, s, (const __bf16*)x, (__bf16*)out, q);
     } else {       // x = dx (written), out = dout (read)
-        const dim3 grid(grid_for((long)B * H * W * C));
-        if (f32) hipLaunchKernelGGL((gresize_bwd_kernel<float>), grid, dim3(256), 0, s, (const float*)out, (float*)const_cast<void*>(x), q);
-        else hipLaunchKernelGGL((gresize_bwd_kernel<__bf16>), grid, dim3(256), 0, s, (const __bf16*)out, (__bf16*)const_cast<void*>(x), q);
+        const long nsrc = (long)B * H * W * C;
+        const float mag = (scale_h > 0.f ? 1.f / scale_h : (float)Ho) * (scale_w > 0.f ? 1.f / scale_w : (float)Wo);
+        if (mag >= 16.f && nsrc <= (1L << 22)) {         // many candidates per source element, few source elements: one wave each
+            const dim3 grid((unsigned)((nsrc + 3) / 4));
+            if (f32) hipLaunchKernelGGL((gresize_bwd_wave_kernel<float>), grid, dim3(256), 0, s, (const float*)out, (float*)const_cast<void*>(x), q);
+            else hipLaunchKernelGGL((gresize_bwd_wave_kernel<__bf16>), grid, dim3(256), 0, s, (const __bf16*)out, (__bf16*)const_cast<void*>(x), q);
+        } else {
+            const dim3 grid(grid_for(nsrc));
+            if (f32) hipLaunchKernelGGL((gresize_bwd_kernel<float>), grid, dim3(256), 0, s, (const float*)out, (float*)const_cast<void*>(x), q);
+            else hipLaunchKernelGGL((gresize_bwd_kernel<__bf16>), grid, dim3(256), 0, s, (const __bf16*)out, (__bf16*)const_cast<void*>(x), q);
+        }
     }
     MI_CHECK_LAUNCH("gresize_kernel");
     return MI_OK;

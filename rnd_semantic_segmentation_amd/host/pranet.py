@@ -723,14 +723,28 @@ class FlatAdam(torch.optim.Adam):
         self.grad_clamp = grad_clamp
         self._m = self._v = None
         self._steps = 0
+        self.device_hyper = None         # 6-float device tensor (lr, beta1, beta2, eps, clamp, step): HIP-graph mode
+
+    def set_device_hyper(self, enable=True):
+        """Graph mode: step() reads its hyper-parameters and the step count from device memory (mi_adam_step_dev); push_hyper() refreshes the
+        learning rate from param_groups before a replay."""
+        if not enable:
+            self.device_hyper = None
+            return
+        self._ensure_moments()           # (allocated inside a capture they would be re-zeroed by every replay)
+        g = self.param_groups[0]
+        self.device_hyper = torch.tensor([g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.grad_clamp or 0.0, float(self._steps)], dtype=torch.float32,
+                                         device=self.net._store.data.device)
+
+    def push_hyper(self):
+        self.device_hyper[0:1].fill_(float(self.param_groups[0]["lr"]))
 
     def zero_grad(self, set_to_none=True):
         st = self.net._store
         if st is not None:
             st.written.clear()          # every gradient slot is overwritten by the next backward: no 130 MB memset
 
-    @torch.no_grad()
-    def step(self, closure=None):
+    def _ensure_moments(self):
         st = self.net.ensure_flat()
         if self._m is None or self._m.numel() != st.data.numel() or self._m.device != st.data.device:
             self._m, self._v = torch.zeros_like(st.data), torch.zeros_like(st.data)
@@ -742,15 +756,74 @@ class FlatAdam(torch.optim.Adam):
                     self._steps = int(s["step"])
                 s["exp_avg"] = self._m[p._mi_off:p._mi_off + p.numel()].view_as(p)
                 s["exp_avg_sq"] = self._v[p._mi_off:p._mi_off + p.numel()].view_as(p)
+        return st
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        st = self._ensure_moments()
         g = self.param_groups[0]
         if g.get("amsgrad") or g.get("weight_decay", 0) != 0 or g.get("maximize"):
             raise NotImplementedError("FlatAdam implements the reference's configuration (pranet_trainer.py:20)")
         self._steps += 1
-        K.adam_step(st.data, st.grad, self._m, self._v, g["lr"], g["betas"][0], g["betas"][1], g["eps"], self._steps, grad_clamp=self.grad_clamp)
-        step_t = torch.tensor(float(self._steps))
-        for p in st.params:
-            self.state[p]["step"] = step_t
+        if self.device_hyper is not None:
+            if not torch.cuda.is_current_stream_capturing():
+                self.push_hyper()
+            self.device_hyper[5:6].add_(1.0)                           # (captured with the step: every replay advances the device-side count)
+            K.adam_step_dev(st.data, st.grad, self._m, self._v, self.device_hyper)
+        else:
+            K.adam_step(st.data, st.grad, self._m, self._v, g["lr"], g["betas"][0], g["betas"][1], g["eps"], self._steps, grad_clamp=self.grad_clamp)
         st.generation += 1
+
+    def state_dict(self):
+        step_t = torch.tensor(float(self._steps))                      # (graph replays advance the count without running step())
+        for p, s in self.state.items():
+            if "exp_avg" in s:
+                s["step"] = step_t
+        return super().state_dict()
+
+
+class GraphedStep:
+    """One whole optimizer step of pranet_trainer.py:39-60 - weight pack, forward, four structure losses, backward, clamped Adam: ~1 800
+    launches - captured once as a HIP graph and replayed: the host cost of a step becomes one graph launch.  Inputs are copied into static
+    buffers; the learning rate and Adam's step count live in device memory (FlatAdam.set_device_hyper)."""
+
+    def __init__(self, net, opt, images, gts, warmup=3):
+        self.net, self.opt = net, opt
+        self.x, self.gt = images.detach().clone(), gts.detach().clone()
+        net.ensure_flat()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                  # eager warm-up on the capture stream's pool: workspaces, moment buffers, caches
+            for _ in range(warmup):
+                self._core()
+        torch.cuda.current_stream().wait_stream(side)
+        opt.set_device_hyper(True)
+        torch.cuda.synchronize()
+        net._pack_sig = None                           # the weight pack belongs inside the graph: weights change on every replay
+        steps = opt._steps
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.losses = self._core()
+        opt._steps = steps                             # the capture itself executed nothing
+
+    def _core(self):
+        self.opt.zero_grad()
+        ls = [structure_loss(o, self.gt) for o in self.net(self.x)]
+        (ls[3] + ls[2] + ls[1] + ls[0]).backward()
+        self.opt.step()
+        return [l.detach() for l in ls]
+
+    def __call__(self, images=None, gts=None):
+        """Returns the four losses (lateral 5, 4, 3, 2) as device scalars owned by the graph (clone to keep across replays)."""
+        if images is not None:
+            self.x.copy_(images, non_blocking=True)
+            self.gt.copy_(gts, non_blocking=True)
+        self.opt.push_hyper()
+        self.graph.replay()
+        self.opt._steps += 1
+        self.net._stat_gen += 1
+        self.net._store.generation += 1
+        return self.losses
 
 
 def warmup_cosine_lr(base_lr, steps, multiplier=8.0, warm=5, t_max=100):
@@ -809,8 +882,19 @@ class PraNetTrainer(BaseTrainer):
         nhwc = t.float().permute(0, 2, 3, 1).contiguous()
         return gk.gresize(nhwc, (self.trainsize, self.trainsize), True).permute(0, 3, 1, 2).contiguous()
 
+    GRAPH_WARMUP = 3
+
     def train_step(self, images, gts):
-        """One optimizer step (pranet_trainer.py:39-60).  Returns the four losses (lateral 5, 4, 3, 2) as device scalars."""
+        """One optimizer step (pranet_trainer.py:39-60).  Returns the four losses (lateral 5, 4, 3, 2) as device scalars.
+        MI_GRAPH=1: after three eager steps the step is captured as a HIP graph and replayed while the input shape stays the same."""
+        if os.environ.get("MI_GRAPH") == "1":
+            st = self.__dict__.setdefault("_graph", {"eager": 0, "step": None, "shape": None})
+            if st["step"] is not None and st["shape"] == (tuple(images.shape), tuple(gts.shape)):
+                return [l.clone() for l in st["step"](images, gts)]
+            if st["step"] is None and st["eager"] >= self.GRAPH_WARMUP:
+                st["step"], st["shape"] = GraphedStep(self.model, self.optimizer, images, gts, warmup=0), (tuple(images.shape), tuple(gts.shape))
+                return [l.clone() for l in st["step"](images, gts)]
+            st["eager"] += 1
         self.optimizer.zero_grad()
         outs = self.model(images)
         losses = [self.structure_loss(o, gts) for o in outs]
@@ -859,6 +943,7 @@ class PraNetTrainer(BaseTrainer):
             self.logger.info("Loading optimizer from {}".format(self.cfg.resume))
             self.optimizer.load_state_dict(self.checkpoint["optimizer"])
             self.optimizer._m = None                                  # re-adopt the restored moments on the next step
+            self.optimizer._ensure_moments()
         if "epoch" in self.checkpoint:
             self.start_epoch = self.checkpoint["epoch"] + 1
 

@@ -413,6 +413,13 @@ def adam_step(p, g, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_clamp
                                   int(step), _stream()), "mi_adam_step")
 
 
+def adam_step_dev(p, g, exp_avg, exp_avg_sq, hyper):
+    """adam_step with (lr, beta1, beta2, eps, grad_clamp or <= 0, step) in a 6-float device tensor (graph-capturable: see mi355seg.h)."""
+    for t, n in ((p, "p"), (g, "g"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"), (hyper, "hyper")):
+        _chk(t, torch.float32, n)
+    check(_lib.lib().mi_adam_step_dev(_p(p), _p(g), _p(exp_avg), _p(exp_avg_sq), p.numel(), _p(hyper), _stream()), "mi_adam_step_dev")
+
+
 def sgd_step(p, g, buf, lr, momentum, weight_decay):
     for t, n in ((p, "p"), (g, "g"), (buf, "buf")):
         _chk(t, torch.float32, n)
