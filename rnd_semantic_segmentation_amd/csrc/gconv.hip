@@ -19,12 +19,13 @@
 // outputs - the first level of the BatchNorm batch statistics (nn.BatchNorm2d in train(), PraNet_Res2Net.py:13,17-19) - so
 // that no separate pass over the conv output is needed for them.
 #include "mi_common.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int GBM = 128;       // pixels per tile
-constexpr int GKC = 32;        // channels per K chunk (one MFMA k)
-constexpr int GRS = 40;        // LDS row stride in elements (80 B): 16 consecutive rows start in 16 distinct 16-B bank groups
+// K chunk per main-loop step: KC = 32 channels (one MFMA k) or 64 (two; half as many steps, twice the bytes in flight per step - the main loop
+// of these small convs is bound by the round trip of a step's loads, not by the matrix pipe); LDS row stride KC + 8 elements (80 / 144 B)
 
 struct GConvP {
     const __bf16* A;
@@ -74,24 +75,24 @@ __device__ __forceinline__ void gload16(const __bf16* src, int c0, int C, bool o
     }
 }
 
-template <int BN, bool OUTF32>
+template <int BN, int KC, bool OUTF32>
 struct GSmem {
-    static constexpr int AB = 2 * (GBM + BN) * GRS * 2;                               // double-buffered operand tiles
+    static constexpr int AB = 2 * (GBM + BN) * (KC + 8) * 2;                          // double-buffered operand tiles
     static constexpr int CS = OUTF32 ? GBM * (BN + 4) * 4 : GBM * (BN + 8) * 2;       // staged output tile
     static constexpr int RED = 2 * (256 / BN > 0 ? 256 / BN : 1) * BN * 4;            // stats partials of the row groups
     static constexpr int BYTES = (AB > CS + RED ? AB : CS + RED);
 };
 
-template <int BN, int AVEC, int OVEC, bool OUTF32>
+template <int BN, int KC, int AVEC, int OVEC, bool OUTF32>
 __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
-    constexpr int NT = BN / 16;
-    __shared__ __attribute__((aligned(16))) char smem[GSmem<BN, OUTF32>::BYTES];
+    constexpr int NT = BN / 16, GRS = KC + 8, AQ = KC / 32;
+    __shared__ __attribute__((aligned(16))) char smem[GSmem<BN, KC, OUTF32>::BYTES];
     __bf16* As = reinterpret_cast<__bf16*>(smem);                         // [2][GBM][GRS]
     __bf16* Bs = As + 2 * GBM * GRS;                                      // [2][BN][GRS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * GBM, n0 = blockIdx.y * BN;
 
-    // A loader: thread -> (row, half): 16 channels of one pixel per K chunk
+    // A loader: thread -> (row, half): KC / 2 channels of one pixel per K chunk
     const int arow = tid >> 1, ahalf = tid & 1;
     const int am = m0 + arow;
     const bool am_ok = am < p.M;
@@ -104,14 +105,13 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
         aoh = rem / p.Wo;
         aow = rem - aoh * p.Wo;
     }
-    // B loader: thread -> (n row, 8-channel chunk); BN = 128 takes two rows per thread
-    constexpr int BROWS = (BN * 4 + 255) / 256;
-    const int bch = tid & 3;
+    // B loader: BN rows x KC / 8 chunks of 8 channels, chunk index = tid + 256 j -> (row, chunk)
+    constexpr int BCH = KC / 8, BLOADS = BN * BCH, BROWS = (BLOADS + 255) / 256;
 
     // two register sets: the chunk after next is in flight while the next one waits in registers and the current one is in LDS
-    bf16x8 ra0[2], rb0[BROWS], ra1[2], rb1[BROWS];
+    bf16x8 ra0[2 * AQ], rb0[BROWS], ra1[2 * AQ], rb1[BROWS];
     const int total = p.T * p.nchunks;
-    auto load = [&](int it, bf16x8 (&ra)[2], bf16x8 (&rb)[BROWS]) {
+    auto load = [&](int it, bf16x8 (&ra)[2 * AQ], bf16x8 (&rb)[BROWS]) {
         const bool live = it < total;                  // past the end: every lane reads the zero page (cheap, and keeps the issue unconditional)
         it = live ? it : 0;
         const int tap = it / p.nchunks, kc = it - tap * p.nchunks;
@@ -129,23 +129,32 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
         }
         ok = ok && (unsigned)ih < (unsigned)p.Ha && (unsigned)iw < (unsigned)p.Wa;
         const long pix = ok ? ((long)ab * p.Ha + ih) * p.Wa + iw : 0;
-        gload16<AVEC>(p.A + pix * p.lda, kc * GKC + ahalf * 16, p.Ca, ok, ra);
-        const __bf16* wt = p.Wp + ((long)tap * p.Npad) * p.Cpad + kc * GKC + bch * 8;
+#pragma unroll
+        for (int q = 0; q < AQ; ++q) {
+            bf16x8 two[2];
+            gload16<AVEC>(p.A + pix * p.lda, kc * KC + ahalf * (KC / 2) + q * 16, p.Ca, ok, two);
+            ra[2 * q] = two[0];
+            ra[2 * q + 1] = two[1];
+        }
+        const __bf16* wt = p.Wp + ((long)tap * p.Npad) * p.Cpad + kc * KC;
 #pragma unroll
         for (int j = 0; j < BROWS; ++j) {
-            const int nr = (tid >> 2) + j * 64;
+            const int idx = tid + j * 256;
+            const int nr = idx / BCH, ch = idx - nr * BCH;
             const int n = n0 + nr;
-            rb[j] = *reinterpret_cast<const bf16x8*>((live && nr < BN && n < p.Npad) ? wt + (long)n * p.Cpad : reinterpret_cast<const __bf16*>(g_gzero));
+            const bool bok = live && idx < BLOADS && n < p.Npad && kc * KC + ch * 8 < p.Cpad;
+            rb[j] = *reinterpret_cast<const bf16x8*>(bok ? wt + (long)n * p.Cpad + ch * 8 : reinterpret_cast<const __bf16*>(g_gzero));
         }
     };
-    auto stash = [&](int buf, const bf16x8 (&ra)[2], const bf16x8 (&rb)[BROWS]) {
-        __bf16* a = As + buf * GBM * GRS + arow * GRS + ahalf * 16;
-        *reinterpret_cast<bf16x8*>(a) = ra[0];
-        *reinterpret_cast<bf16x8*>(a + 8) = ra[1];
+    auto stash = [&](int buf, const bf16x8 (&ra)[2 * AQ], const bf16x8 (&rb)[BROWS]) {
+        __bf16* a = As + buf * GBM * GRS + arow * GRS + ahalf * (KC / 2);
+#pragma unroll
+        for (int q = 0; q < 2 * AQ; ++q) *reinterpret_cast<bf16x8*>(a + 8 * q) = ra[q];
 #pragma unroll
         for (int j = 0; j < BROWS; ++j) {
-            const int nr = (tid >> 2) + j * 64;
-            if (nr < BN) *reinterpret_cast<bf16x8*>(Bs + buf * BN * GRS + nr * GRS + bch * 8) = rb[j];
+            const int idx = tid + j * 256;
+            const int nr = idx / BCH, ch = idx - nr * BCH;
+            if (idx < BLOADS) *reinterpret_cast<bf16x8*>(Bs + buf * BN * GRS + nr * GRS + ch * 8) = rb[j];
         }
     };
 
@@ -159,15 +168,18 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
     auto compute = [&](int buf) {
         const __bf16* a = As + buf * GBM * GRS + (wave * 32 + frow) * GRS + fk;
         const __bf16* b = Bs + buf * BN * GRS + frow * GRS + fk;
-        bf16x8 fa[2], fb[NT];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(a + i * 16 * GRS);
+        for (int ks = 0; ks < AQ; ++ks) {
+            bf16x8 fa[2], fb[NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(b + j * 16 * GRS);
+            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(a + i * 16 * GRS + ks * 32);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(b + j * 16 * GRS + ks * 32);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
     };
     // every load and every LDS write below is issued unconditionally (past the last chunk the lanes read the zero page into a buffer nobody reads): with a
     // branch around an issue the compiler no longer knows how many loads are in flight and falls back to draining them all
@@ -238,7 +250,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
             // thread -> (column, row group): fixed-order sums over the group's rows, then over the groups
             constexpr int RG = 256 / BN > 0 ? 256 / BN : 1;      // 8 | 4 | 2 row groups
             constexpr int RPG = GBM / RG;
-            float* red = reinterpret_cast<float*>(smem + GSmem<BN, false>::CS);
+            float* red = reinterpret_cast<float*>(smem + GSmem<BN, KC, false>::CS);
             const int col = tid % BN, rg = tid / BN;
             if (rg < RG) {
                 float s1 = 0.f, s2 = 0.f;
@@ -269,28 +281,42 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
     }
 }
 
-template <int BN, int AVEC, int OVEC, bool OUTF32>
+template <int BN, int KC, int AVEC, int OVEC, bool OUTF32>
 void glaunch(const GConvP& p, hipStream_t s) {
     dim3 grid((p.M + GBM - 1) / GBM, (p.N + BN - 1) / BN);
-    hipLaunchKernelGGL((gconv_kernel<BN, AVEC, OVEC, OUTF32>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((gconv_kernel<BN, KC, AVEC, OVEC, OUTF32>), grid, dim3(256), 0, s, p);
 }
 
-template <int BN, int AVEC>
+template <int BN, int KC, int AVEC>
 void glaunch_o(const GConvP& p, int ovec, bool f32, hipStream_t s) {
     if (f32) {
-        if constexpr (BN == 32) glaunch<32, AVEC, 1, true>(p, s);
+        if constexpr (BN == 32) glaunch<32, KC, AVEC, 1, true>(p, s);
         return;
     }
-    if (ovec == 8) glaunch<BN, AVEC, 8, false>(p, s);
-    else if (ovec == 2) glaunch<BN, AVEC, 2, false>(p, s);
-    else glaunch<BN, AVEC, 1, false>(p, s);
+    if (ovec == 8) glaunch<BN, KC, AVEC, 8, false>(p, s);
+    else if (ovec == 2) glaunch<BN, KC, AVEC, 2, false>(p, s);
+    else glaunch<BN, KC, AVEC, 1, false>(p, s);
 }
 
-template <int BN>
+template <int BN, int KC>
 void glaunch_a(const GConvP& p, int avec, int ovec, bool f32, hipStream_t s) {
-    if (avec == 8) glaunch_o<BN, 8>(p, ovec, f32, s);
-    else if (avec == 2) glaunch_o<BN, 2>(p, ovec, f32, s);
-    else glaunch_o<BN, 1>(p, ovec, f32, s);
+    if (avec == 8) glaunch_o<BN, KC, 8>(p, ovec, f32, s);
+    else if (avec == 2) glaunch_o<BN, KC, 2>(p, ovec, f32, s);
+    else glaunch_o<BN, KC, 1>(p, ovec, f32, s);
+}
+
+// BN = 128 keeps 32-channel chunks (its LDS image with 64 would pass the 64 KiB of static LDS)
+template <int BN>
+void glaunch_k(GConvP& p, int avec, int ovec, bool f32, hipStream_t s) {
+    if constexpr (BN <= 64) {
+        if (p.Cpad >= 64 && p.T * ((p.Cpad + 63) / 64) >= 2) {
+            p.nchunks = (p.Cpad + 63) / 64;
+            glaunch_a<BN, 64>(p, avec, ovec, f32, s);
+            return;
+        }
+    }
+    p.nchunks = p.Cpad / 32;
+    glaunch_a<BN, 32>(p, avec, ovec, f32, s);
 }
 
 int view_vec(const void* ptr, long ld, int C) {
@@ -303,7 +329,7 @@ int view_vec(const void* ptr, long ld, int C) {
 inline int rup(int x, int m) { return (x + m - 1) / m * m; }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
-constexpr int WTO = 64, WTI = 64, WKP = 32;     // output tile 64 (o) x 64 (i), 32 pixels per K step
+constexpr int WTO = 64, WTI = 64, WKP = 64;     // output tile 64 (o) x 64 (i), 64 pixels (two MFMA k) per K step
 constexpr int WRS = 144;                        // LDS bytes per pixel row of a tile: 64 channels bf16 + 16 B pad (8-B aligned for the transposed reads)
 
 struct GWgP {
@@ -341,7 +367,7 @@ __device__ __forceinline__ s16x4 tr_read(const char* lds_generic) {
 // tiles are staged pixel-major and the MFMA fragments come from ds_read_b64_tr_b16 (hardware transpose), as in igemm_tn.hip.
 template <int YVEC, int XVEC>
 __global__ __launch_bounds__(256) void gwgrad_kernel(GWgP p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * WKP * WRS];      // [buf][dy | x][32 pixels][144 B]
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * WKP * WRS];      // [buf][dy | x][64 pixels][144 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles = p.o_tiles * p.i_tiles;
     int id = blockIdx.x;
@@ -354,26 +380,32 @@ __global__ __launch_bounds__(256) void gwgrad_kernel(GWgP p) {
     const int m_begin = split * p.rows_per_split;
     const int m_end = min(p.M, m_begin + p.rows_per_split);
     const int nk = m_end > m_begin ? (m_end - m_begin + WKP - 1) / WKP : 0;
-    const int lpx = tid >> 3, lch = tid & 7;          // loader: pixel row of the step, 8-channel chunk
+    const int lpx = tid >> 3, lch = tid & 7;          // loader: pixel rows lpx and lpx + 32 of the step, 8-channel chunk
     const int hw = p.Ho * p.Wo;
 
-    bf16x8 ry0, rx0, ry1, rx1;
-    auto load = [&](int kt, bf16x8& ry, bf16x8& rx) {
-        const int m = m_begin + kt * WKP + lpx;
-        const bool ok = m < m_end;                     // (a step past the last one has every row >= m_end: zero-page reads)
-        const int mm = ok ? m : 0;
-        ry = gload8<YVEC>(p.dY + (long)mm * p.ldy, o0 + lch * 8, p.O, ok);
-        const int b = mm / hw, rem = mm - b * hw;
-        const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
-        const int ih = oh * p.sh + ky * p.dh - p.ph, iw = ow * p.sw + kx * p.dw - p.pw;
-        const bool xok = ok && (unsigned)ih < (unsigned)p.Ha && (unsigned)iw < (unsigned)p.Wa;
-        const long pix = xok ? ((long)b * p.Ha + ih) * p.Wa + iw : 0;
-        rx = gload8<XVEC>(p.X + pix * p.ldx, i0 + lch * 8, p.I, xok);
+    bf16x8 ry0[2], rx0[2], ry1[2], rx1[2];
+    auto load = [&](int kt, bf16x8 (&ry)[2], bf16x8 (&rx)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = m_begin + kt * WKP + lpx + 32 * h;
+            const bool ok = m < m_end;                 // (a step past the last one has every row >= m_end: zero-page reads)
+            const int mm = ok ? m : 0;
+            ry[h] = gload8<YVEC>(p.dY + (long)mm * p.ldy, o0 + lch * 8, p.O, ok);
+            const int b = mm / hw, rem = mm - b * hw;
+            const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+            const int ih = oh * p.sh + ky * p.dh - p.ph, iw = ow * p.sw + kx * p.dw - p.pw;
+            const bool xok = ok && (unsigned)ih < (unsigned)p.Ha && (unsigned)iw < (unsigned)p.Wa;
+            const long pix = xok ? ((long)b * p.Ha + ih) * p.Wa + iw : 0;
+            rx[h] = gload8<XVEC>(p.X + pix * p.ldx, i0 + lch * 8, p.I, xok);
+        }
     };
-    auto stash = [&](int buf, const bf16x8& ry, const bf16x8& rx) {
-        char* sy = smem + buf * (2 * WKP * WRS) + lpx * WRS + lch * 16;
-        *reinterpret_cast<bf16x8*>(sy) = ry;
-        *reinterpret_cast<bf16x8*>(sy + WKP * WRS) = rx;
+    auto stash = [&](int buf, const bf16x8 (&ry)[2], const bf16x8 (&rx)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            char* sy = smem + buf * (2 * WKP * WRS) + (lpx + 32 * h) * WRS + lch * 16;
+            *reinterpret_cast<bf16x8*>(sy) = ry[h];
+            *reinterpret_cast<bf16x8*>(sy + WKP * WRS) = rx[h];
+        }
     };
 
     // D rows = i (A operand = X^T), D cols = o (B operand = dY^T); wave owns 32 (i) x 32 (o)
@@ -389,25 +421,28 @@ __global__ __launch_bounds__(256) void gwgrad_kernel(GWgP p) {
     const int row_off = (g * 4 + q) * WRS + pc * 8;
 
     auto compute = [&](int buf) {
-        const char* sy = smem + buf * (2 * WKP * WRS) + row_off;
-        const char* sx = sy + WKP * WRS;
-        union { bf16x8 v; s16x4 h[2]; } xf[2], yf[2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const char* base = sx + (wi * 32 + a * 16) * 2;
-            xf[a].h[0] = tr_read(base);
-            xf[a].h[1] = tr_read(base + 16 * WRS);
+        for (int ks = 0; ks < WKP / 32; ++ks) {
+            const char* sy = smem + buf * (2 * WKP * WRS) + row_off + ks * 32 * WRS;
+            const char* sx = sy + WKP * WRS;
+            union { bf16x8 v; s16x4 h[2]; } xf[2], yf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const char* base = sx + (wi * 32 + a * 16) * 2;
+                xf[a].h[0] = tr_read(base);
+                xf[a].h[1] = tr_read(base + 16 * WRS);
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const char* base = sy + (wo * 32 + b * 16) * 2;
+                yf[b].h[0] = tr_read(base);
+                yf[b].h[1] = tr_read(base + 16 * WRS);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[a].v, yf[b].v, acc[a][b], 0, 0, 0);
         }
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const char* base = sy + (wo * 32 + b * 16) * 2;
-            yf[b].h[0] = tr_read(base);
-            yf[b].h[1] = tr_read(base + 16 * WRS);
-        }
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[a].v, yf[b].v, acc[a][b], 0, 0, 0);
     };
     if (nk > 0) {
         load(0, ry0, rx0);
@@ -569,7 +604,7 @@ int mi_gconv(const void* a, long lda, const void* wp, void* out, long ldo, int B
     p.Ha = Ha; p.Wa = Wa; p.Ho = Ho; p.Wo = Wo;
     p.kw = kw; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.dh = dh; p.dw = dw;
     p.mode = mode;
-    p.nchunks = p.Cpad / GKC;
+    p.nchunks = p.Cpad / 32;
     const int avec = view_vec(a, lda, Ca);
     int ovec = 1;
     if (!out_f32) ovec = view_vec(out, ldo, N);
@@ -578,11 +613,11 @@ int mi_gconv(const void* a, long lda, const void* wp, void* out, long ldo, int B
     const long mt = (p.M + GBM - 1) / GBM;
     if (out_f32) {
         MI_REQUIRE(N <= 32, "mi_gconv: fp32 outputs are the one-channel side maps (N <= 32), got N = %d", N);
-        glaunch_a<32>(p, avec, 1, true, s);
-    } else if (N <= 32) glaunch_a<32>(p, avec, ovec, false, s);
-    else if (mt * ((N + 63) / 64) < 256) glaunch_a<32>(p, avec, ovec, false, s);          // few pixels (1/32 resolution): narrower tiles, more workgroups
-    else if (N <= 64 || N % 128 == 64 || mt * ((N + 127) / 128) < 512) glaunch_a<64>(p, avec, ovec, false, s);
-    else glaunch_a<128>(p, avec, ovec, false, s);
+        glaunch_k<32>(p, avec, 1, true, s);
+    } else if (N <= 32) glaunch_k<32>(p, avec, ovec, false, s);
+    else if (mt * ((N + 63) / 64) < 256) glaunch_k<32>(p, avec, ovec, false, s);          // few pixels (1/32 resolution): narrower tiles, more workgroups
+    else if (N <= 64 || N % 128 == 64 || mt * ((N + 127) / 128) < 512 || getenv("MI_GCONV_BN128") == nullptr) glaunch_k<64>(p, avec, ovec, false, s);
+    else glaunch_k<128>(p, avec, ovec, false, s);
     MI_CHECK_LAUNCH("gconv_kernel");
     return MI_OK;
 }
