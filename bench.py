@@ -170,24 +170,36 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    events = [] if not args.no_kernel_events else None
+    # The timed region is K steps of the PRODUCT schedule and nothing else (forward as two half-batch lanes, weight gradients beside the
+    # data-gradient chain, bucketed exchange on its side stream).  The per-kernel numbers come from INST extra steps run after it, in
+    # the same process: those keep every launch on the main stream with a HIP event pair around it (an event pair on a shared GPU
+    # would charge each kernel its neighbours' time) and cost ~6 % per step - they are not part of `value`.
+    red = getattr(trainer, "reducer", None)
+    if red is not None:
+        red.measure = True
     t0 = time.perf_counter()
     for i in range(args.steps):
-        # per-launch HIP events cost ~6 % of a step, so only every 8th timed step is instrumented; an instrumented step also keeps the
-        # weight-gradient launches on the main stream (host/engine.py _SideStream) so that each event pair times one kernel alone,
-        # and runs eager (events cannot be taken inside a graph replay)
-        inst = events is not None and i % 8 == 0
-        kernels.PROFILE = events if inst else None
-        if graph:
-            os.environ["MI_GRAPH"] = "0" if inst else "1"
         loss = step()
-    kernels.PROFILE = None
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     note("timed region done: %.1f ms/step" % (1000 * elapsed / args.steps))
+    exposed = red.exposed_ms() if red is not None else None
+    if red is not None:
+        red.measure = False
+    events = [] if not args.no_kernel_events else None
+    INST = 3
+    if events is not None:
+        if graph:
+            os.environ["MI_GRAPH"] = "0"          # events cannot be taken inside a graph replay
+        kernels.PROFILE = events
+        for i in range(INST):
+            step()
+        kernels.PROFILE = None
+        torch.cuda.synchronize()
+        note("instrumented steps done")
     final_loss = float(loss)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -209,7 +221,7 @@ def main():
             "whole_step_mfma_frac": round(ALG_GFLOP_PER_IMAGE * 1e9 * (args.size / 769.0) ** 2 * value / (PEAK_BF16_TFLOPS * 1e12 * world), 4),
         }
         if events:
-            inst_steps = (args.steps + 7) // 8
+            inst_steps = INST
             by, shapes = {}, {}
             fam = {"dilated3x3_family": [0.0, 0.0, 0], "aspp_head": [0.0, 0.0, 0], "pointwise_k256_n1024_class": [0.0, 0.0, 0]}
             for name, e0, e1, flops, tag in events:
@@ -252,10 +264,10 @@ def main():
                                "launches_per_step": n // inst_steps, "avg_launch_us": round(1e6 * tsec / n, 2),
                                "alg_gflop_per_launch": round(fl / n / 1e9, 3), "ms_per_step_in_kernel": round(1e3 * tsec / inst_steps, 3),
                                "instrumented_steps": inst_steps,
-                               "note": "dominant = largest total launch time in the instrumented steps (HIP events on the launch stream around "
-                                       "every launch of every 8th timed step; those steps run single-stream so that an event pair times one "
-                                       "kernel alone; the other timed steps run the forward as two half-batch lanes and the weight gradients "
-                                       "beside the data-gradient chain on extra HIP streams)"}
+                               "note": "dominant = largest total launch time in the instrumented steps: %d extra steps AFTER the timed region, HIP events "
+                                       "on the launch stream around every launch, single-stream so that an event pair times one kernel alone; the "
+                                       "timed steps run the product schedule (two half-batch forward lanes, weight gradients beside the "
+                                       "data-gradient chain on extra HIP streams) and carry no events" % INST}
             out["kernels"] = {k: {"ms_per_step": round(1e3 * v[0] / inst_steps, 3), "tflops": round(v[1] / v[0] / 1e12, 2) if v[1] else None,
                                   "frac_of_mfma_peak": round(v[1] / v[0] / 1e12 / PEAK_BF16_TFLOPS, 4) if v[1] else None,
                                   "launches_per_step": v[2] // inst_steps} for k, v in by.items()}
@@ -276,6 +288,10 @@ def main():
             note("in-step per-shape table: kind k Cin N M flags dil | launches/step  us/launch  TFLOP/s  ms/step")
             for tag, (tsec, fl, n) in sorted(shapes.items(), key=lambda kv: -kv[1][0]):
                 note("%-8s k%d Cin%-5d N%-5d M%-7d f%-4d d%-2d | %3d  %8.1f  %7.0f  %6.3f" % (tuple(tag[:7]) + (n // inst_steps, 1e6 * tsec / n, fl / tsec / 1e12, 1e3 * tsec / inst_steps)))
+        if red is not None:
+            # data-parallel diagnostics of THIS rank (rank 0): how many ranks the process group really has, what travels, and how long the
+            # compute stream waited for the exchange at the join before the optimizer (the part of the all-reduce that backward did not hide)
+            out["ddp"] = dict(red.diag, exchange_ms_exposed=None if exposed is None else round(exposed, 4), backend=dist.get_backend() if dist.is_initialized() else None)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.size)
         print(json.dumps(out), flush=True)

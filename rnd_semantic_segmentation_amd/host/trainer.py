@@ -55,7 +55,7 @@ class ASPPTrainer(BaseTrainer):
         if self.distributed or (dist.is_available() and dist.is_initialized() and os.environ.get("MI_DDP_FORCE") == "1"):
             stores = [m.ensure_flat() if hasattr(m, "ensure_flat") else _cpu_store(m) for m in (self.classifier, self.feature_extractor)]
             self.reducer = ddp.GradAllReducer(stores)
-            self.reducer.broadcast_parameters(0)
+            self.reducer.broadcast_parameters(0, modules=(self.feature_extractor, self.classifier))
             if hasattr(self.feature_extractor, "sync_batchnorm") and not self.cfg.MODEL.FREEZE_BN:
                 self.feature_extractor.sync_batchnorm(True)          # train_distill.py:53 convert_sync_batchnorm
 

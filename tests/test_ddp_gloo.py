@@ -286,6 +286,50 @@ def test_two_rank_gloo_overlapped_bucket_exchange_and_bf16_payload(tmp_path):
         assert err < 2.0 ** -7, err                                         # two bf16 roundings of an fp32 average
 
 
+def _bf16_rs_worker(rank, world, port, tmpdir):
+    """MI_DDP_PAYLOAD=bf16 as reduce-scatter (all_to_all_single) + all-gather over `world` ranks, bucket sizes that do not divide by it."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    try:
+        params = [("p%d" % i, torch.nn.Parameter(torch.zeros(n))) for i, n in enumerate((1000, 67, 5003, 301, 7001, 13))]
+        st = engine.FlatStore(params, torch.device("cpu"))
+        red = ddp.GradAllReducer([st], bucket_bytes=4 * 3000, payload="bf16")
+        assert len(red.buckets[id(st)]) >= 3 and red.diag["ranks"] == world and red.diag["payload"] == "bf16"
+        assert red.diag["wire_bytes_per_rank_per_step"] == int(2 * (world - 1) / world * st.total * 2)
+        g = torch.Generator().manual_seed(100 + rank)
+        for step in range(2):                                    # twice: the per-bucket staging buffers are reused
+            local = torch.randn(st.total, generator=g) * (1.0 + step)
+            st.grad.copy_(local)
+            red.finish()
+            torch.save({"local": local, "avg": st.grad.clone()}, os.path.join(tmpdir, "rs_%d_%d.pt" % (step, rank)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _check_bf16_rs(tmp_path, world):
+    for step in range(2):
+        res = [torch.load(tmp_path / ("rs_%d_%d.pt" % (step, r))) for r in range(world)]
+        acc = res[0]["local"].to(torch.bfloat16).float()
+        for r in range(1, world):
+            acc = acc + res[r]["local"].to(torch.bfloat16).float()           # fp32 sum in rank order
+        exp = (acc / world).to(torch.bfloat16).float()                        # one rounding of the average
+        for r in range(world):
+            assert torch.equal(res[r]["avg"], exp), (step, r)
+
+
+def test_four_rank_gloo_bf16_payload_reduce_scatter_all_gather(tmp_path):
+    port = _free_port()
+    mp.spawn(_bf16_rs_worker, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+    _check_bf16_rs(tmp_path, 4)
+
+
+def test_two_rank_gloo_bf16_payload_reduce_scatter_all_gather(tmp_path):
+    port = _free_port()
+    mp.spawn(_bf16_rs_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    _check_bf16_rs(tmp_path, 2)
+
+
 # ------------------------------------------------------------------------------------------------ synchronised BatchNorm (host logic)
 class _TorchBnKernels:
     """Stand-ins for the BatchNorm entry points of kernels.py on CPU tensors (test infrastructure: the product path has no CPU
