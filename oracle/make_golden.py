@@ -587,8 +587,25 @@ def g_r101(ref, out, big):
              argmax_sha=sha(predt.numpy().astype(np.uint8)), stage_names=np.array(sorted(stage)),
              stage_grad_norm=np.array([stage[k] for k in sorted(stage)]),
              up_crop=up.detach().numpy()[0, :, 300:316, 500:516],
-             aspp0_bias_grad=cls.conv2d_list[0].bias.grad.numpy(), l4_2_conv3_grad_crop=fe.backbone["layer4"][2].conv3.weight.grad.numpy()[:8, :8, 0, 0], **ev)
+             aspp0_bias_grad=cls.conv2d_list[0].bias.grad.numpy(), l4_2_conv3_grad_crop=fe.backbone["layer4"][2].conv3.weight.grad.numpy()[:8, :8, 0, 0],
+             **_grad_samples(dict(list(fe.named_parameters()) + list(cls.named_parameters()))), **ev)
         save(out, "g6_r101_769_pred", pred=predt.numpy().astype(np.uint8))
+
+
+GRAD_SAMPLE_KEYS = ("backbone.layer1.0.conv1.weight", "backbone.layer2.3.conv2.weight", "backbone.layer3.22.conv2.weight", "backbone.layer4.2.conv3.weight",
+                    "conv2d_list.3.weight")
+
+
+def _grad_samples(named):
+    """Direction pins for the R101 training step: for a weight of each stage, every stride-th element of the reference's gradient (at most
+    65 536 values, fp32) - enough for a cosine to three digits, without a 2 MB tensor per layer in the fixture."""
+    out = {}
+    for k in GRAD_SAMPLE_KEYS:
+        g = named[k].grad.detach().reshape(-1)
+        stride = max(1, -(-g.numel() // 65536))
+        out["gsample_" + k.replace(".", "_")] = g[::stride].numpy().copy()
+        out["gstride_" + k.replace(".", "_")] = np.int64(stride)
+    return out
 
 
 # ------------------------------------------------------------------ G7 metrics, LR, SGD, misc utils

@@ -255,6 +255,17 @@ def test_r101_769_bf16_training_step_vs_reference_golden():
     # measured: loss 2.0e-4, logits 1.1e-2, norms within 0.9 %, bias gradient 3.6e-3; bars = 3x
     assert e_loss < 6e-4 and e_low < 3.4e-2
     assert np.all(np.abs(ratios - 1) < 0.027) and e_bias < 1.1e-2
+    # direction, not only length: a weight of every stage against the reference's gradient (every stride-th element, g6 `gsample_*`)
+    named = dict(list(fe.named_parameters()) + list(cls.named_parameters()))
+    worst = {}
+    for key in [k for k in g.files if k.startswith("gsample_")]:
+        name = next(n for n in named if n.replace(".", "_") == key[len("gsample_"):])
+        ours = named[name].grad.detach().reshape(-1)[::int(g["gstride_" + key[len("gsample_"):]])].double().cpu().numpy()
+        want = g[key].astype(np.float64)
+        assert ours.shape == want.shape
+        worst[name] = 1.0 - float(ours @ want / (np.linalg.norm(ours) * np.linalg.norm(want)))
+    print("bf16 r101@769 gradient directions, 1 - cos: %s" % {k: "%.2e" % v for k, v in worst.items()})
+    assert len(worst) == 5 and max(worst.values()) < 2e-2, worst          # bar: 3x the worst measured value (see the printed table)
 
 
 def test_r101_129_bf16_engine_vs_reference_under_cpu_autocast():

@@ -263,6 +263,14 @@ def test_r101_769_forward_backward_config1_geometry():
     names = [str(n) for n in g["stage_names"]]
     assert np.allclose([stage[n] for n in names], g["stage_grad_norm"], rtol=2e-4)
     assert rel(getattr(cls.conv2d_list, "0").bias.grad.numpy(), g["aspp0_bias_grad"]) < 1e-4
+    # gradient directions: every stride-th element of a weight gradient of each stage (the pins the GPU test's cosines are taken against)
+    named = dict(list(fe.named_parameters()) + list(cls.named_parameters()))
+    samples = [k for k in g.files if k.startswith("gsample_")]
+    assert len(samples) == 5
+    for key in samples:
+        name = next(n for n in named if n.replace(".", "_") == key[len("gsample_"):])
+        ours = named[name].grad.reshape(-1)[::int(g["gstride_" + key[len("gsample_"):]])].numpy()
+        assert rel(ours, g[key]) < 2e-4, name
     pred = up.argmax(1).numpy().astype(np.uint8)
     assert (pred != gp).mean() < 1e-4
     # the evaluation record (the reference's own intersectionAndUnion / confusion_matrix outputs) from the oracle's mask
