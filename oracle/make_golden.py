@@ -10,6 +10,7 @@ Unavailable third-party packages are replaced by in-memory stubs (ours, below):
   mmcv.runner.load_checkpoint                        (resnet.py:2, never reached: pretrained=False)
   torchvision.transforms                              (utility.py:14, unused on this path)
   thop.profile / clever_format                        (core/utils/utils.py:3, pulled in by pranet_trainer.py:9, unused)
+  inplace_abn, termcolor                              (gcpacc/contextagg/ccnet.py:17, cgnonlocal.py:17: see import_gald)
 Network-fetching loaders (MODEL.WEIGHTS URL) are never called: models are built
 with pretrained_backbone=False and filled with formula weights
 (rnd_semantic_segmentation_amd/host/synth.py), which the tests regenerate.
@@ -491,6 +492,97 @@ def g_pranet(ref, out):
     save(out, "g12_pranet_96", **full)
 
 
+def import_gald():
+    """The reference's GALD / GCPA modules: core/models/classifiers/gcpacc/gcpa_cc2.py (GCPAEncoder / GCPADecoder),
+    encoders/hardnet_68.py, contextagg/ccnet.py (CrissCrossAttention), contextagg/GALDNet.py (LocalAttenModule), gcpa_gald.py (FAM).
+    Run-time substitutions, no reference file is modified: `inplace_abn` (absent; contextagg/ccnet.py:17 builds an alias these modules never
+    use) and `termcolor` (contextagg/cgnonlocal.py:17, a print helper) are stub modules; `hardnet(arch=68)` would torch.load
+    'pretrained/hardnet68.pth', which the image lacks - the name is re-bound to the same architecture without the load; ccnet.INF puts its
+    -inf diagonal on `.cuda()` - re-bound to the same expression on the CPU."""
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+
+    class _ABN(nn.BatchNorm2d):
+        def __init__(self, n, activation="identity", **kw):
+            super().__init__(n)
+    mod("inplace_abn", InPlaceABN=_ABN, InPlaceABNSync=_ABN)
+    mod("termcolor", cprint=print)
+    from core.models.classifiers.gcpacc import gcpa_cc2 as G
+    from core.models.classifiers.gcpacc import gcpa_gald as A
+    import importlib
+    L = importlib.import_module("core.models.classifiers.gcpacc.contextagg.GALDNet")      # (the package re-exports a CLASS of the same name)
+    C = importlib.import_module("core.models.classifiers.gcpacc.contextagg.ccnet")
+    H = importlib.import_module("core.models.classifiers.gcpacc.encoders.hardnet_68")
+    G.hardnet = lambda arch=68, pretrained=False, **kw: H.HarDNet(arch=68)
+    C.INF = lambda B, Hh, W: -torch.diag(torch.tensor(float("inf")).repeat(Hh), 0).unsqueeze(0).repeat(B * W, 1, 1)
+    return types.SimpleNamespace(G=G, A=A, L=L, C=C, H=H)
+
+
+def g_gald(ref, out):
+    """G13 (oracle first): module-level fixtures of the GALD / GCPA path with formula weights - CrissCrossAttention
+    (ccnet.py:37-127: affinities along the column and the row through bmm, -inf on the column's own position, ONE softmax over both,
+    gamma * aggregation + x), LocalAttenModule (GALDNet.py:124-157: two depthwise 3x3 stride-2 convs without padding + BatchNorm + ReLU,
+    bilinear align_corners=True back to the input size, sigmoid gate, x * gate + x), FAM (gcpa_gald.py:47-107), a HarDBlock
+    (hardnet_68.py:83-160) - and the whole GCPAEncoder + GCPADecoder at 2 x 3 x 224 x 224 with the four deep-supervision cross-entropy
+    losses weighted 1 / 0.8 / 0.6 / 0.4 (gald_trainer.py:66-84): outputs, losses, every parameter-gradient norm, state_dict keys."""
+    R = import_gald()
+    arrays = {}
+
+    def run(tag, mod, inputs):
+        synth.load_formula_weights(mod, prefix=tag + ".")
+        mod.train()
+        xs = [t(a).requires_grad_(True) for a in inputs]
+        y = mod(*xs)
+        (y.square().mean() + y.mean()).backward()
+        arrays[tag + "_out"] = y.detach().numpy()
+        for i, x in enumerate(xs):
+            arrays["%s_dx%d" % (tag, i)] = x.grad.numpy()
+        gn = _grad_norms(mod)
+        arrays[tag + "_pnames"] = np.array(sorted(gn))
+        arrays[tag + "_pgrad"] = np.array([gn[k] for k in sorted(gn)])
+        mod.eval()
+        with torch.no_grad():
+            arrays[tag + "_out_eval"] = mod(*[t(a) for a in inputs]).numpy()
+
+    u = lambda name, shape, s=1.0: (synth.uniform("gald." + name, shape) * s).astype(np.float32)
+    run("cca", R.C.CrissCrossAttention(64), [u("cca.x", (2, 64, 5, 7), 3)])
+    run("lam", R.L.LocalAttenModule(32), [u("lam.x", (2, 32, 19, 17), 3)])
+    run("fam", R.A.FAM(24, 32, 32, 32), [u("fam.left", (2, 24, 12, 12), 2), u("fam.down", (2, 32, 6, 6), 2), u("fam.right", (2, 32, 6, 6), 2)])
+    run("hdb", R.H.HarDBlock(64, 14, 1.7, 8), [np.maximum(u("hdb.x", (2, 64, 12, 12), 3), 0)])
+    save(out, "g13_gald_modules", **arrays)
+
+    # ---- the whole net
+    torch.manual_seed(0)
+    enc, dec = R.G.GCPAEncoder(), R.G.GCPADecoder()
+    synth.load_formula_weights(enc, prefix="gald.enc.")
+    synth.load_formula_weights(dec, prefix="gald.dec.")
+    with open(os.path.join(out, "g8_gald_keys.json"), "w") as f:
+        json.dump({"encoder": list(enc.state_dict().keys()), "decoder": list(dec.state_dict().keys()),
+                   "n_enc": sum(p.numel() for p in enc.parameters()), "n_dec": sum(p.numel() for p in dec.parameters())}, f)
+    B, S = 2, 224
+    x = synth.synth_image(B, S, S, seed=51)
+    lab = synth.synth_label(B, S, S, 19, seed=51)
+    enc.train()
+    dec.train()
+    feats = enc(t(x))
+    outs = dec(t(x), feats)                                                  # out5, out4, out3, out2
+    crit = nn.CrossEntropyLoss(ignore_index=255)
+    losses = [crit(o, t(lab).long()) for o in outs]
+    loss = losses[3] * 1 + losses[2] * 0.8 + losses[1] * 0.6 + losses[0] * 0.4      # gald_trainer.py:84
+    loss.backward()
+    full = dict(x_seed=51, feat_shapes=np.array([list(f.shape) for f in feats]), losses=np.array([l.item() for l in losses]), loss=np.float64(loss.item()))
+    for i, o in enumerate(outs):
+        full["out%d_crop" % i] = o.detach().numpy()[:, :, ::16, ::16].copy()
+    for i, f in enumerate(feats):
+        full["feat%d_norm" % i] = np.float64(f.detach().double().norm())
+    ge, gd = _grad_norms(enc), _grad_norms(dec)
+    full["enc_pnames"], full["enc_pgrad"] = np.array(sorted(ge)), np.array([ge[k] for k in sorted(ge)])
+    full["dec_pnames"], full["dec_pgrad"] = np.array(sorted(gd)), np.array([gd[k] for k in sorted(gd)])
+    save(out, "g13_gald_224", **full)
+
+
 def eval_record(ref, probs, pred, lab):
     """What ASPPTester.test (aspp_tester.py:47-83) accumulates for one image, by the reference's own functions: the
     per-class intersection / union / target / prediction areas (utility.py:133-145, the numpy twin of :148-161), the
@@ -737,7 +829,7 @@ def main():
     torch.set_num_threads(8)
     ref = import_reference()
     jobs = dict(conv=lambda: g_conv(ref, args.out), aspp=lambda: g_aspp(ref, args.out),
-                frozenbn=lambda: g_frozenbn(ref, args.out), tinynet=lambda: g_tinynet(ref, args.out), tinynet_bn=lambda: g_tinynet_bn(ref, args.out), structure_loss=lambda: g_structure_loss(ref, args.out), pranet=lambda: g_pranet(ref, args.out),
+                frozenbn=lambda: g_frozenbn(ref, args.out), tinynet=lambda: g_tinynet(ref, args.out), tinynet_bn=lambda: g_tinynet_bn(ref, args.out), structure_loss=lambda: g_structure_loss(ref, args.out), pranet=lambda: g_pranet(ref, args.out), gald=lambda: g_gald(ref, args.out),
                 r101=lambda: g_r101(ref, args.out, not args.skip_big), metrics=lambda: g_metrics(ref, args.out),
                 fada=lambda: g_fada(ref, args.out))
     for name, fn in jobs.items():

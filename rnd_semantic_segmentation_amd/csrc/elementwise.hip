@@ -1,5 +1,7 @@
 // Small HBM-bound kernels: fused SGD step on flat buffers, ReLU-backward mask, FrozenBN fold, error plumbing.
 #include "mi_common.h"
+#include <mutex>
+#include <stdlib.h>
 #include <string.h>
 
 static thread_local char g_err[512] = "";
@@ -10,6 +12,35 @@ int mi_set_error(int code, const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return code;
+}
+
+const MiSwitches& mi_sw() {
+    static MiSwitches sw;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        auto env = [](const char* name, int dflt) {
+            const char* e = getenv(name);
+            return e ? atoi(e) : dflt;
+        };
+        sw.igemm_staged = env("MI_IGEMM_STAGED", 1);
+        sw.igemm_pp = env("MI_IGEMM_PP", 1);
+        sw.igemm_pp_mink = env("MI_IGEMM_PP_MINK", 512);
+        sw.igemm_mt = env("MI_IGEMM_MT", 0);
+        sw.igemm_bn = env("MI_IGEMM_BN", 0);
+        sw.igemm_pref = env("MI_IGEMM_PREF", 1);
+        sw.pp_korder = env("MI_IGEMM_PP_KORDER", 1);
+        sw.igemm_pw = env("MI_IGEMM_PW", 0);
+        sw.wgrad_s4_slots = env("MI_WGRAD_S4_SLOTS", 512);
+        if (sw.wgrad_s4_slots < 64) sw.wgrad_s4_slots = 512;
+        sw.wgrad_ti256 = env("MI_WGRAD_TI256", -1);
+        sw.wgrad_p3 = env("MI_WGRAD_P3", 0);
+        sw.wgrad_q3 = env("MI_WGRAD_Q3", 1);
+        sw.wgrad_s4 = env("MI_WGRAD_S4", 1);
+        sw.gconv_bn128 = env("MI_GCONV_BN128", 0);
+        sw.p3_dbg = env("MI_P3_DBG", 0);
+        sw.pp_trace_wg = env("MI_PP_TRACE_WG", 0);
+    });
+    return sw;
 }
 
 extern "C" int mi_version(void) { return MI355SEG_VERSION; }

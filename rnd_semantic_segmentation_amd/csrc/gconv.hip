@@ -616,7 +616,7 @@ int mi_gconv(const void* a, long lda, const void* wp, void* out, long ldo, int B
         glaunch_k<32>(p, avec, 1, true, s);
     } else if (N <= 32) glaunch_k<32>(p, avec, ovec, false, s);
     else if (mt * ((N + 63) / 64) < 256) glaunch_k<32>(p, avec, ovec, false, s);          // few pixels (1/32 resolution): narrower tiles, more workgroups
-    else if (N <= 64 || N % 128 == 64 || mt * ((N + 127) / 128) < 512 || getenv("MI_GCONV_BN128") == nullptr) glaunch_k<64>(p, avec, ovec, false, s);
+    else if (N <= 64 || N % 128 == 64 || mt * ((N + 127) / 128) < 512 || !mi_sw().gconv_bn128) glaunch_k<64>(p, avec, ovec, false, s);
     else glaunch_k<128>(p, avec, ovec, false, s);
     MI_CHECK_LAUNCH("gconv_kernel");
     return MI_OK;

@@ -295,14 +295,7 @@ __global__ __launch_bounds__((Geo<MT, BKT, NWN>::NW * 64), (Geo<MT, BKT, NWN>::O
     igemm_epilogue<MT, EPI>(p, acc, m0, n0, wm, wn, frow, fq, pres, pbits);
 }
 
-inline bool staged_on() {        // MI_IGEMM_STAGED=0: MFMA-layout loads / stores straight from registers
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("MI_IGEMM_STAGED");
-        v = e ? atoi(e) : 1;
-    }
-    return v != 0;
-}
+inline bool staged_on() { return mi_sw().igemm_staged != 0; }        // MI_IGEMM_STAGED=0: MFMA-layout loads / stores straight from registers
 
 template <int MT, bool UNIT, bool PREF, int BKT, int EPI, int NWN, bool STG = false>
 void launch_one(dim3 grid, hipStream_t stream, const IgemmParams& p) {
@@ -344,16 +337,8 @@ extern "C" int mi_conv_gemm_pp(const void* a, const void* wp, void* out, int B, 
 
 // 1 = the launch goes to the wide-tile ping-pong main loop (igemm_pp_kernel), 0 = to igemm_nt_kernel
 extern "C" int mi_conv_gemm_route(int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N, int ksize, int stride, int flags) {
-    static int pp_on = -1;
-    if (pp_on < 0) {
-        const char* e = getenv("MI_IGEMM_PP");
-        pp_on = e ? atoi(e) : 1;
-    }
-    static int min_k = -1;
-    if (min_k < 0) {
-        const char* e = getenv("MI_IGEMM_PP_MINK");
-        min_k = e ? atoi(e) : 512;         // in the step: 704 -> 2048 (ASPP data gradient) 246 vs 280 us, 512 -> 1024 101 vs 116; K = 256: no difference
-    }
+    const int pp_on = mi_sw().igemm_pp;
+    const int min_k = mi_sw().igemm_pp_mink;         // 512: in the step 704 -> 2048 (ASPP data gradient) 246 vs 280 us, 512 -> 1024 101 vs 116; K = 256: no difference
     const long M = (long)B * Ho * Wo;
     // igemm_pp_kernel addresses its operands with 32-bit buffer offsets: 2 GiB tensors stay on the pointer-arithmetic kernel
     const long a_bytes = (long)B * Ha * Wa * Ca * 2 + 64L * (Wa + 1) * Ca * 2, w_bytes = (long)ksize * ksize * N * Ca * 2;
@@ -422,15 +407,7 @@ extern "C" int mi_conv_gemm(const void* a, const void* wp, void* out, int B, int
     p.zgw = zgw > 0 ? zgw : 4;
     p.alpha = alpha;
     const bool unit = stride == 1 && Ha == Ho && Wa == Wo && ksize * ksize <= 9;
-    static int force_mt = -1, force_bn = -1, pref_on = -1;
-    if (force_mt < 0) {
-        const char* e = getenv("MI_IGEMM_MT");
-        force_mt = e ? atoi(e) : 0;
-        e = getenv("MI_IGEMM_BN");
-        force_bn = e ? atoi(e) : 0;
-        e = getenv("MI_IGEMM_PREF");
-        pref_on = e ? atoi(e) : 1;
-    }
+    const int force_mt = mi_sw().igemm_mt, force_bn = mi_sw().igemm_bn, pref_on = mi_sw().igemm_pref;
     // Modelled time of one launch with tile bm x bn: rounds on the resident-workgroup slots x workgroups sharing a CU x per-K-step
     // tile time, where a CU's share of the L2 request rate serves (bm+bn)*128 B per step (~47.6 GB/s per CU measured) and its
     // MFMA pipes need bm*bn*128 FLOP at ~9.8 TFLOP/s per CU; the two overlap imperfectly (20 % of the shorter one is exposed).
@@ -445,7 +422,12 @@ extern "C" int mi_conv_gemm(const void* a, const void* wp, void* out, int B, int
     // vmcnt(0) drain per K-step) it measured 2-8 % slower than the 128-wide tiles on every shape of the network (bench 216 vs
     // 223.5 images/s) although it moves 30 % fewer L2 bytes - the single resident workgroup has nothing to overlap its drains
     // with.  It is the geometry a deeper-pipelined schedule (counted vmcnt, prefetch in flight across barriers) needs.
+#ifdef MI_EXPERIMENTS
     const bool wide_ok = unit && N % 256 == 0 && !(flags & MI_EPI_ZSPLIT) && force_bn == 256;
+#else
+    const bool wide_ok = false;                          // the 256-wide tile is compiled into experiment builds only
+    (void)force_bn;
+#endif
     int mt_sel = 4, bn = 128;
     double best = cost(128, 128);
     for (int mt = 5; mt <= 6; ++mt)
@@ -469,12 +451,14 @@ extern "C" int mi_conv_gemm(const void* a, const void* wp, void* out, int B, int
     const hipStream_t st = (hipStream_t)stream;
     if (!unit)
         launch_variant<4, false, false, 64, 2>(grid, st, p);
+#ifdef MI_EXPERIMENTS
     else if (bn == 256 && mt_sel == 6)
         launch_variant<6, true, false, 64, 4>(grid, st, p);
     else if (bn == 256 && mt_sel == 5)
         launch_variant<5, true, false, 64, 4>(grid, st, p);
     else if (bn == 256)
         launch_variant<4, true, false, 64, 4>(grid, st, p);
+#endif
     else if (pref && mt_sel == 5)
         launch_variant<5, true, true, 64, 2>(grid, st, p);
     else if (pref)

@@ -349,6 +349,7 @@ template <int MTG> struct PWGeo {
     static_assert(BM + 16 <= WROWS, "window too small");
 };
 
+#ifdef MI_EXPERIMENTS   // opt-in kernel that does not win: experiment builds only, not part of libmi355seg.so
 template <int MTG, int EPI>
 __global__ __launch_bounds__(512, 1) void igemm_pw_kernel(IgemmParams p) {
     using G = PWGeo<MTG>;
@@ -543,6 +544,7 @@ void launch_pw(dim3 grid, hipStream_t stream, const IgemmParams& p) {
     mi_allow_dynamic_lds((const void*)kern, lds, attr_done);
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p);
 }
+#endif  // MI_EXPERIMENTS
 
 template <int MTG, int EPI>
 void launch_pp(dim3 grid, hipStream_t stream, const IgemmParams& p) {
@@ -623,23 +625,15 @@ extern "C" int mi_conv_gemm_pp(const void* a, const void* wp, void* out, int B, 
     p.flags = flags;
     p.zgw = zgw > 0 ? zgw : 4;
     p.alpha = alpha;
-    static int korder = -1;              // MI_IGEMM_PP_KORDER=0: tap-major contraction (the order of igemm_nt_kernel; bit-equal to it)
-    if (korder < 0) {
-        const char* e = getenv("MI_IGEMM_PP_KORDER");
-        korder = e ? atoi(e) : 1;
-    }
-    p.korder = ksize > 1 ? korder : 0;
+    p.korder = ksize > 1 ? mi_sw().pp_korder : 0;              // MI_IGEMM_PP_KORDER=0: tap-major contraction (the order of igemm_nt_kernel; bit-equal to it)
 #ifdef MI_PP_TRACE
-    if (const char* e = getenv("MI_PP_TRACE_WG")) p.korder |= atoi(e) << 8;
+    p.korder |= mi_sw().pp_trace_wg << 8;
 #endif
     // 3x3 with the hot epilogues: the shared-window kernel (mtg == 0 only: an explicit 8 / 10 selects igemm_pp_kernel).
     // MI_IGEMM_PW: 0 = off (default: measured 90 vs 85 us at 3x3 256, 311 vs 290 at 3x3 512 - see DESIGN.md section 8), 1 = by rule,
     // 2 = always when the geometry allows (tests on tiny shapes)
-    static int pw_mode = -1;
-    if (pw_mode < 0) {
-        const char* e = getenv("MI_IGEMM_PW");
-        pw_mode = e ? atoi(e) : 0;
-    }
+#ifdef MI_EXPERIMENTS
+    const int pw_mode = mi_sw().igemm_pw;
     const int WPad = Wa + 2 * dil;
     const long Qp = (long)B * Ha * WPad;
     if ((mtg == 3 || (mtg == 0 && pw_mode)) && ksize == 3 && pad == dil && dil <= 8 && WPad >= 16 && (flags == 69 || flags == 128) && Qp < (1L << 31) &&
@@ -654,7 +648,8 @@ extern "C" int mi_conv_gemm_pp(const void* a, const void* wp, void* out, int B, 
         MI_CHECK_LAUNCH("mi_conv_gemm_pp (shared window)");
         return MI_OK;
     }
-    if (mtg == 3) return mi_set_error(MI_EINVAL, "mi_conv_gemm_pp: mtg 3 (shared-window kernel) needs a 3x3 conv with pad == dil <= 8 and flags 69 or 128");
+#endif
+    if (mtg == 3) return mi_set_error(MI_EINVAL, "mi_conv_gemm_pp: mtg 3 (shared-window kernel, experiment builds only) needs a 3x3 conv with pad == dil <= 8 and flags 69 or 128");
     {   // 32-bit buffer offsets (bit 31 marks a padded chunk): operands and the largest tap excursion must stay below 2 GiB
         const long a_bytes = (long)B * Ha * Wa * Ca * 2 + 2L * ((long)(ksize - 1) * dil + pad) * (Wa + 1) * Ca * 2;
         const long w_bytes = (long)ksize * ksize * N * Ca * 2;

@@ -541,12 +541,7 @@ int pick_splits256(long M, int tiles) {
 // (256 <-> 1024: 64.7 vs 70.0 us; the class 3.72 vs 4.02 ms single-stream), but the two-stream step is not (278.9 vs 280.0 images/s): a
 // launch that fills every CU's slot leaves the data-gradient chain beside it nothing to overlap with.
 int pick_splits_s4(long M, int tiles) {
-    static int slots = -1;
-    if (slots < 0) {
-        const char* e = getenv("MI_WGRAD_S4_SLOTS");
-        slots = e ? atoi(e) : 512;
-        if (slots < 64) slots = 512;
-    }
+    const int slots = mi_sw().wgrad_s4_slots;
     const long steps = (M + 31) / 32;
     int best = 1;
     double best_cost = 1e30;
@@ -564,18 +559,14 @@ int pick_splits_s4(long M, int tiles) {
 }
 
 inline bool use_tn256(int O, int I, int ksize, int pad, int stride, int Ha, int Ho, int Wa, int Wo) {
-    static int mode = -2;
-    if (mode == -2) {
-        // MI_WGRAD_TI256: unset = by rule, 0 = never, 1 = every stride-1 conv with I >= 256 (tests).
-        // Warm (operands in the Infinity Cache from the previous iteration of a timing loop) this kernel is SLOWER than the 128 x 128
-        // ones (B = 8, 97 x 97: 1x1 256 <-> 1024 71 us vs 58 us, 3x3 256 144 vs 129, 3x3 512 397 vs 406).  In the training step, with
-        // cold operands, the big 1x1 launches are HBM-latency-bound: the L2 -> LDS fill rate is (bytes in flight) / (HBM round trip),
-        // equal for both kernels, and this tile turns it into 1.33x the unique bytes (dy is read once instead of twice).  In-step:
-        // 512 -> 2048 172 vs 199 us, 2048 -> 512 162 vs 197, 1024 -> 2048 264 vs 374, 512 <-> 1024 98 vs 105; 256 <-> 1024 72 vs 70
-        // (the slab traffic of the larger split count eats the gain there), hence the size rule.
-        const char* e = getenv("MI_WGRAD_TI256");
-        mode = e ? atoi(e) : -1;
-    }
+    // MI_WGRAD_TI256: unset = by rule, 0 = never, 1 = every stride-1 conv with I >= 256 (tests).
+    // Warm (operands in the Infinity Cache from the previous iteration of a timing loop) this kernel is SLOWER than the 128 x 128
+    // ones (B = 8, 97 x 97: 1x1 256 <-> 1024 71 us vs 58 us, 3x3 256 144 vs 129, 3x3 512 397 vs 406).  In the training step, with
+    // cold operands, the big 1x1 launches are HBM-latency-bound: the L2 -> LDS fill rate is (bytes in flight) / (HBM round trip),
+    // equal for both kernels, and this tile turns it into 1.33x the unique bytes (dy is read once instead of twice).  In-step:
+    // 512 -> 2048 172 vs 199 us, 2048 -> 512 162 vs 197, 1024 -> 2048 264 vs 374, 512 <-> 1024 98 vs 105; 256 <-> 1024 72 vs 70
+    // (the slab traffic of the larger split count eats the gain there), hence the size rule.
+    const int mode = mi_sw().wgrad_ti256;
     if (mode == 0 || I < 256 || stride != 1 || Ha != Ho || Wa != Wo) return false;
     if (mode > 0) return true;
     return ksize == 1 && pad == 0 && (long)O * I >= 512L * 1024;
@@ -660,6 +651,7 @@ struct WgradP3Params {
     int dbg;             // experiment toggles (MI_P3_DBG): 1 no DMA in the loop, 2 no LDS reads, 4 no MFMAs, 8 no partial-plane stores
 };
 
+#ifdef MI_EXPERIMENTS   // opt-in kernel that does not win: built by tools/experiments/build.sh only, not part of libmi355seg.so
 __global__ __launch_bounds__(512, 1) void wgrad_p3_kernel(WgradP3Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -865,6 +857,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_p3_kernel(WgradP3Params p) {
         }
     }
 }
+#endif  // MI_EXPERIMENTS
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // wgrad_q3_kernel: the fused-row idea in the structure that the per-tap kernel has proven - 4 waves, TWO workgroups per CU that
@@ -1170,34 +1163,39 @@ static int launch_p3(const void* dy, const void* x, float* ws, int H, int W, int
     q.slabs_per_split = pl.slabs_per_split;
     q.o_tiles = pl.o_tiles;
     q.i_tiles = pl.i_tiles;
-    const char* dbg = getenv("MI_P3_DBG");
-    q.dbg = dbg ? atoi(dbg) : 0;
+    q.dbg = mi_sw().p3_dbg;
     if (q3) {
         static std::atomic<uint64_t> attrq{0};
         mi_allow_dynamic_lds((const void*)wgrad_q3_kernel, Q3_LDS, attrq);
         hipLaunchKernelGGL(wgrad_q3_kernel, dim3((unsigned)(pl.o_tiles * pl.i_tiles * 3 * pl.S)), dim3(256), Q3_LDS, st, q);
         return 0;
     }
+#ifdef MI_EXPERIMENTS
     static std::atomic<uint64_t> attr{0};
     mi_allow_dynamic_lds((const void*)wgrad_p3_kernel, P3_LDS, attr);
     hipLaunchKernelGGL(wgrad_p3_kernel, dim3((unsigned)(pl.o_tiles * pl.i_tiles * 3 * pl.S)), dim3(512), P3_LDS, st, q);
     return 0;
+#else
+    return -1;
+#endif
 }
 
 // which kernel mi_conv_wgrad launches for a shape: 0 wgrad_tn_kernel (128 x 128 per tap), 1 wgrad_tn256_kernel, 2 wgrad_p3_kernel,
 // 3 wgrad_q3_kernel, 4 wgrad_s4_kernel (measurement tools; same rules as the dispatch below)
 extern "C" int mi_conv_wgrad_route(int B, int Ha, int Wa, int I, int Ho, int Wo, int O, int ksize, int stride, int pad, int dil, int out_map) {
-    const char* e3 = getenv("MI_WGRAD_P3");
-    const char* eq = getenv("MI_WGRAD_Q3");
-    const int p3_mode = e3 ? atoi(e3) : 0, q3_mode = eq ? atoi(eq) : 1;
+#ifdef MI_EXPERIMENTS
+    const int p3_mode = mi_sw().wgrad_p3;
+#else
+    const int p3_mode = 0;                       // the 8-wave fused-row kernel is not in the product library
+#endif
+    const int q3_mode = mi_sw().wgrad_q3;
     const bool fused_ok = out_map == 0 && ksize == 3 && stride == 1 && Ha == Ho && Wa == Wo && pad == dil;
     P3Plan pl;
     if (fused_ok && q3_mode && !p3_mode && p3_plan(B, Ho, Wo, O, I, dil, q3_mode == 2, pl, true)) return 3;
     if (fused_ok && p3_mode && p3_plan(B, Ho, Wo, O, I, dil, p3_mode == 2, pl)) return 2;
     if (use_tn256(O, I, ksize, pad, stride, Ha, Ho, Wa, Wo)) return 1;
-    const char* e4 = getenv("MI_WGRAD_S4");
     const long M = (long)B * Ho * Wo;
-    if ((e4 ? atoi(e4) : 1) && ksize == 1 && pad == 0 && stride == 1 && Ha == Ho && Wa == Wo && M * (O > I ? O : I) * 2 < (1L << 31)) return 4;
+    if (mi_sw().wgrad_s4 && ksize == 1 && pad == 0 && stride == 1 && Ha == Ho && Wa == Wo && M * (O > I ? O : I) * 2 < (1L << 31)) return 4;
     return 0;
 }
 
@@ -1229,17 +1227,13 @@ extern "C" int mi_conv_wgrad(const void* dy, const void* x, float* dw, int B, in
     // reaches 120 GB/s from the L2, tools/micro/l2lds.hip, so the DMA issue beside the partner's MFMAs is what was measured) -,
     // partial-plane stores 14 us, slab reducer 23 us.  With the DMA at 115 % of the MFMA time the ping-pong's read segments
     // (which carry the DMA issue) outlast the MFMA segments and the two hardly overlap (main loop 80 us).
-    static int p3_mode = -1;
-    if (p3_mode < 0) {
-        const char* e = getenv("MI_WGRAD_P3");
-        p3_mode = e ? atoi(e) : 0;
-    }
+#ifdef MI_EXPERIMENTS
+    const int p3_mode = mi_sw().wgrad_p3;
+#else
+    const int p3_mode = 0;
+#endif
     // the 4-wave fused-row kernel: MI_WGRAD_Q3 0 = never, 1 = by the plan's rule (default), 2 = whenever the geometry allows (tests)
-    static int q3_mode = -1;
-    if (q3_mode < 0) {
-        const char* e = getenv("MI_WGRAD_Q3");
-        q3_mode = e ? atoi(e) : 1;
-    }
+    const int q3_mode = mi_sw().wgrad_q3;
     if (q3_mode && !p3_mode && out_map == 0 && ksize == 3 && stride == 1 && Ha == Ho && Wa == Wo && pad == dil) {
         P3Plan pl;
         if (p3_plan(B, Ho, Wo, O, I, dil, q3_mode == 2, pl, true) && (size_t)pl.S * 9 * O * I * sizeof(float) <= workspace_bytes) {
@@ -1295,11 +1289,7 @@ extern "C" int mi_conv_wgrad(const void* dy, const void* x, float* dw, int B, in
             hipLaunchKernelGGL(wgrad_tn256_kernel<1>, dim3(nb), dim3(256), LDS2_BYTES, (hipStream_t)stream, p);
         MI_CHECK_LAUNCH("mi_conv_wgrad (128 x 256 tile)");
     }
-    static int s4_mode = -1;                 // MI_WGRAD_S4=0: the 64-pixel double-buffer kernel for the 1x1 / stride-1 weight gradients too
-    if (s4_mode < 0) {
-        const char* e = getenv("MI_WGRAD_S4");
-        s4_mode = e ? atoi(e) : 1;
-    }
+    const int s4_mode = mi_sw().wgrad_s4;                 // MI_WGRAD_S4=0: the 64-pixel double-buffer kernel for the 1x1 / stride-1 weight gradients too
     const bool deep = !wide && s4_mode && ksize == 1 && pad == 0 && stride == 1 && Ha == Ho && Wa == Wo && (long)M * (O > I ? O : I) * 2 < (1L << 31);
     if (deep) {
         p.i_tiles = (I + TI - 1) / TI;

@@ -17,6 +17,29 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 int mi_set_error(int code, const char* fmt, ...);
 
+// Every tuning / measurement switch of the library (MI_* environment variables), read ONCE per process under std::call_once
+// (csrc/elementwise.hip): no getenv on a launch path, no unsynchronised static caches - mi355seg.h promises re-entrancy.
+// Defaults are the product configuration; the switches exist for tools/ (A/B measurements) and for tests that force a kernel.
+struct MiSwitches {
+    int igemm_staged;      // MI_IGEMM_STAGED     1: residual / output tiles through LDS with row-contiguous lanes (igemm_nt)
+    int igemm_pp;          // MI_IGEMM_PP         1: long contractions take the wide-tile ping-pong loop (igemm_pp)
+    int igemm_pp_mink;     // MI_IGEMM_PP_MINK    512: smallest 1x1 contraction routed there
+    int igemm_mt;          // MI_IGEMM_MT         0: tile height chosen by the cost model (else 4..6 x 32 rows)
+    int igemm_bn;          // MI_IGEMM_BN         0: 128-wide tiles (256: the experiment tile, builds with -DMI_EXPERIMENTS only)
+    int igemm_pref;        // MI_IGEMM_PREF       1: epilogue operands prefetched before the main loop
+    int pp_korder;         // MI_IGEMM_PP_KORDER  1: channel-chunk-major contraction of a 3x3 (0: tap-major, bit-equal to igemm_nt)
+    int igemm_pw;          // MI_IGEMM_PW         0: shared-window 3x3 kernel off (-DMI_EXPERIMENTS builds only)
+    int wgrad_s4_slots;    // MI_WGRAD_S4_SLOTS   512: workgroup slots the 1x1 weight-gradient split picker plans for
+    int wgrad_ti256;       // MI_WGRAD_TI256      -1: 128 x 256 weight-gradient tile by rule (0 never, 1 always)
+    int wgrad_p3;          // MI_WGRAD_P3         0: 8-wave fused-row 3x3 weight gradient off (-DMI_EXPERIMENTS builds only)
+    int wgrad_q3;          // MI_WGRAD_Q3         1: 4-wave fused-row 3x3 weight gradient by rule (0 never, 2 whenever possible)
+    int wgrad_s4;          // MI_WGRAD_S4         1: deep-stream 1x1 weight gradient
+    int gconv_bn128;       // MI_GCONV_BN128      0: general conv keeps 64-wide tiles (1: 128-wide where they fit)
+    int p3_dbg;            // MI_P3_DBG           0 (-DMI_EXPERIMENTS builds only)
+    int pp_trace_wg;       // MI_PP_TRACE_WG      0 (-DMI_PP_TRACE builds only)
+};
+const MiSwitches& mi_sw();
+
 #define MI_REQUIRE(cond, ...)                         \
     do {                                              \
         if (!(cond)) return mi_set_error(MI_EINVAL, __VA_ARGS__); \

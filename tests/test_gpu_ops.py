@@ -165,7 +165,7 @@ def test_pointwise_wide_conv_all_hot_epilogues_vs_torch(ci, co, B, H, W):
 
 
 @pytest.mark.parametrize("B,H,W,ci,co,k,d", [(2, 13, 11, 64, 256, 3, 2), (1, 19, 23, 96, 288, 3, 4), (3, 9, 10, 128, 512, 1, 1), (2, 7, 5, 32, 64, 3, 1)])
-@pytest.mark.parametrize("mtg", [8, 10, 3])
+@pytest.mark.parametrize("mtg", [8, 10])
 def test_wide_tile_ping_pong_main_loop_vs_oracle_and_128_wide_kernel(B, H, W, ci, co, k, d, mtg):
     """csrc/igemm_pp.hip called directly on small / ragged shapes (M and N tails inside one 320 x 256 tile, a single slab, taps
     that fall into the padding): forward and data-gradient gathers with the epilogues the network launches.  The oracle pins the

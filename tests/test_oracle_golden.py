@@ -416,3 +416,71 @@ def test_pranet_whole_net_restatement_vs_reference_golden(golden_dir):
     for i, m in enumerate(maps):
         assert rel(m.numpy()[:, :, ::4, ::4], g["eval_map%d_crop" % i]) < 1e-3, i
 
+
+
+# ------------------------------------------------------------------------------------------------ GALD / GCPA
+def _gald_uniform(name, shape, s=1.0):
+    return (synth.uniform("gald." + name, shape) * s).astype(np.float32)
+
+
+def test_gald_modules_restatement_vs_reference_golden():
+    """oracle/ref_gald.py building blocks against the reference's own modules (g13_gald_modules): criss-cross attention, the local
+    attention module (depthwise stride-2 convs), FAM, a HarDBlock - train-mode output, input gradients, parameter-gradient norms, eval output."""
+    from oracle import ref_gald as rg
+    g = _cases.load("g13_gald_modules")
+    cases = [("cca", rg.CrissCross(64), [_gald_uniform("cca.x", (2, 64, 5, 7), 3)]),
+             ("lam", rg.LocalAtten(32), [_gald_uniform("lam.x", (2, 32, 19, 17), 3)]),
+             ("fam", rg.FAM(24, 32, 32, 32), [_gald_uniform("fam.left", (2, 24, 12, 12), 2), _gald_uniform("fam.down", (2, 32, 6, 6), 2), _gald_uniform("fam.right", (2, 32, 6, 6), 2)]),
+             ("hdb", rg.HarDBlock(64, 14, 1.7, 8), [np.maximum(_gald_uniform("hdb.x", (2, 64, 12, 12), 3), 0)])]
+    for tag, mod, inputs in cases:
+        synth.load_formula_weights(mod, prefix=tag + ".")
+        mod.train()
+        xs = [torch.from_numpy(a).requires_grad_(True) for a in inputs]
+        y = mod(*xs)
+        (y.square().mean() + y.mean()).backward()
+        assert rel(y.detach().numpy(), g[tag + "_out"]) < 2e-5, tag
+        for i, x in enumerate(xs):
+            assert rel(x.grad.numpy(), g["%s_dx%d" % (tag, i)]) < 2e-4, (tag, i)
+        gn = {k: float(p.grad.double().norm()) for k, p in mod.named_parameters() if p.grad is not None}
+        names = [str(n) for n in g[tag + "_pnames"]]
+        assert sorted(gn) == names, tag
+        assert np.allclose([gn[k] for k in names], g[tag + "_pgrad"], rtol=2e-3, atol=1e-7), tag
+        if np.isfinite(g[tag + "_out_eval"]).all():      # (the formula gives `dconvN.1.running_var` - not BatchNorm by name - negative entries:
+            mod.eval()                                   # the reference's own eval output of the local attention module is NaN)
+            with torch.no_grad():
+                assert rel(mod(*[torch.from_numpy(a) for a in inputs]).numpy(), g[tag + "_out_eval"]) < 2e-5, tag
+
+
+def test_gald_whole_net_restatement_vs_reference_golden(golden_dir):
+    """oracle GCPAEncoder (HarDNet-68) + GCPADecoder against the reference's own run at 2 x 3 x 224 x 224 (g13_gald_224): state_dict keys and
+    parameter counts, feature shapes / norms, the four outputs, the four cross-entropies and their weighted sum (gald_trainer.py:66-84),
+    every parameter-gradient norm."""
+    from oracle import ref_gald as rg
+    keys = json.load(open(os.path.join(golden_dir, "g8_gald_keys.json")))
+    enc, dec = rg.GCPAEncoder(), rg.GCPADecoder()
+    assert list(enc.state_dict().keys()) == keys["encoder"] and list(dec.state_dict().keys()) == keys["decoder"]
+    assert sum(p.numel() for p in enc.parameters()) == keys["n_enc"] and sum(p.numel() for p in dec.parameters()) == keys["n_dec"]
+    g = _cases.load("g13_gald_224")
+    synth.load_formula_weights(enc, prefix="gald.enc.")
+    synth.load_formula_weights(dec, prefix="gald.dec.")
+    x = torch.from_numpy(synth.synth_image(2, 224, 224, seed=51))
+    lab = torch.from_numpy(synth.synth_label(2, 224, 224, 19, seed=51)).long()
+    enc.train()
+    dec.train()
+    feats = enc(x)
+    assert [list(f.shape) for f in feats] == g["feat_shapes"].tolist()
+    for i, f in enumerate(feats):
+        assert abs(float(f.detach().double().norm()) / float(g["feat%d_norm" % i]) - 1) < 1e-5
+    outs = dec(x, feats)
+    losses, loss = rg.gald_losses(outs, lab)
+    loss.backward()
+    assert np.allclose([l.item() for l in losses], g["losses"], rtol=2e-5) and abs(loss.item() - float(g["loss"])) < 2e-5 * float(g["loss"])
+    for i, o in enumerate(outs):
+        assert rel(o.detach().numpy()[:, :, ::16, ::16], g["out%d_crop" % i]) < 1e-4, i
+    for tag, mod in (("enc", enc), ("dec", dec)):
+        gn = {k: float(p.grad.double().norm()) for k, p in mod.named_parameters() if p.grad is not None}
+        names = [str(n) for n in g[tag + "_pnames"]]
+        assert sorted(gn) == names, tag
+        want = g[tag + "_pgrad"]
+        big = want > 1e-6 * want.max()
+        assert np.abs(np.array([gn[k] for k in names])[big] / want[big] - 1).max() < 5e-3, tag
