@@ -348,6 +348,29 @@ int mi_gresize(const void* x, long ldx, void* out, long ldo, int f32, int B, int
 int mi_gra_fwd(const float* gate, const void* feat, long ldfeat, void* out, long ldo, long M, int C, void* stream);
 int mi_gra_bwd(const float* gate, const void* feat, long ldfeat, const void* dy, long lddy, void* dfeat, long lddf, float* dgate, long M, int C, void* stream);
 
+/* ---- GALD / GCPA path, first kernels (csrc/gald.hip) -----------------------------------------------------------------
+ * Depthwise 3x3 convolution with bias on NHWC bf16 views: Conv2d(C, C, 3, groups=C, stride, padding) of LocalAttenModule
+ * (core/models/classifiers/gcpacc/contextagg/GALDNet.py:127-141: stride 2, no padding).  w fp32 [C][3][3] (torch's [C,1,3,3]), bias fp32 [C] or NULL.
+ * stats (optional): per-128-pixel-tile column sums / sums of squares of the rounded outputs, the layout mi_gbn_finalize takes. */
+size_t mi_gdwconv_stats_elems(int B, int Ho, int Wo, int C);
+int mi_gdwconv(const void* x, long ldx, const float* w, const float* bias, void* out, long ldo, int B, int H, int W, int C, int Ho, int Wo, int stride, int pad,
+               float* stats, void* stream);
+int mi_gdwconv_dgrad(const void* dy, long ldy, const float* w, void* dx, long lddx, int B, int H, int W, int C, int Ho, int Wo, int stride, int pad, void* stream);
+size_t mi_gdwconv_wgrad_workspace(int B, int Ho, int Wo, int C);
+int mi_gdwconv_wgrad(const void* dy, long ldy, const void* x, long ldx, float* dw, float* dbias, int B, int H, int W, int C, int Ho, int Wo, int stride, int pad,
+                     int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* Criss-cross attention core (contextagg/ccnet.py:56-127) on the projected q, k [B][H][W][Cq] and v [B][H][W][C]: for every pixel the affinities
+ * with its column (own position masked with -inf) and its row, ONE softmax over the H + W candidates (att, fp32 [B][H][W][H+W], kept for the
+ * backward pass) and agg = sum_j att_j v_j.  The module's output is gamma * agg + x (mi_gbn_apply with scale = gamma).  H + W <= 512.
+ * backward: dagg -> dq, dk, dv; de_ws: float[B*H*W*(H+W)] scratch. */
+int mi_gcca_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, float* att, void* agg, long ldo, int B, int H, int W, int Cq, int C,
+                void* stream);
+int mi_gcca_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const float* att, const void* dagg, long lddagg, float* de_ws, void* dq,
+                long lddq, void* dk, long lddk, void* dv, long lddv, int B, int H, int W, int Cq, int C, void* stream);
+/* Sigmoid gate of the local attention module (GALDNet.py:150-157).  dout == NULL: o1 = x + x * sigmoid(g).  Otherwise the backward:
+ * o1 = d loss / d x = dout * (1 + s), o2 = d loss / d g = dout * x * s * (1 - s). */
+int mi_ggate(const void* x, long ldx, const void* g, long ldg, const void* dout, long lddo, void* o1, long ld1, void* o2, long ld2, long M, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

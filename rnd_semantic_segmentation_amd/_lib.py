@@ -88,6 +88,14 @@ SIGNATURES = {
     "mi_gresize": (I, [P, L, P, L, I] + [I] * 7 + [F, F, I, P]),
     "mi_gra_fwd": (I, [P, P, L, P, L, L, I, P]),
     "mi_gra_bwd": (I, [P, P, L, P, L, P, L, P, L, I, P]),
+    "mi_gdwconv_stats_elems": (Z, [I] * 4),
+    "mi_gdwconv": (I, [P, L, P, P, P, L] + [I] * 8 + [P, P]),
+    "mi_gdwconv_dgrad": (I, [P, L, P, P, L] + [I] * 8 + [P]),
+    "mi_gdwconv_wgrad_workspace": (Z, [I] * 4),
+    "mi_gdwconv_wgrad": (I, [P, L, P, L, P, P] + [I] * 9 + [P, Z, P]),
+    "mi_gcca_fwd": (I, [P, L, P, L, P, L, P, P, L] + [I] * 5 + [P]),
+    "mi_gcca_bwd": (I, [P, L, P, L, P, L, P, P, L, P, P, L, P, L, P, L] + [I] * 5 + [P]),
+    "mi_ggate": (I, [P, L, P, L, P, L, P, L, P, L, L, I, P]),
 }
 
 _lib = None

@@ -255,3 +255,74 @@ def gra_bwd(gate, feat, dy):
     po, ldo = view(dfeat, torch.bfloat16)
     check(_lib.lib().mi_gra_bwd(_p(gate), pf, ldf, pd, ldd, po, ldo, _p(dgate), B * H * W, C, _stream()), "mi_gra_bwd")
     return dfeat, dgate
+
+
+# ---------------------------------------------------------------------------------------------- GALD / GCPA path, first kernels (csrc/gald.hip)
+def gdwconv(x, w, bias, stride, pad, out=None, stats=False):
+    """Depthwise 3x3 conv with bias: x [B,H,W,C] bf16 view, w fp32 [C,1,3,3], bias fp32 [C] or None -> (out [B,Ho,Wo,C], tile statistics or None)."""
+    B, H, W, C = x.shape
+    Ho, Wo = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
+    if out is None:
+        out = new(B, Ho, Wo, C, x.device)
+    px, ldx = view(x, torch.bfloat16)
+    po, ldo = view(out, torch.bfloat16)
+    L = _lib.lib()
+    st = torch.empty(int(L.mi_gdwconv_stats_elems(B, Ho, Wo, C)), dtype=torch.float32, device=x.device) if stats else None
+    check(L.mi_gdwconv(px, ldx, _p(w), _p(bias), po, ldo, B, H, W, C, Ho, Wo, stride, pad, _p(st), _stream()), "mi_gdwconv")
+    return out, st
+
+
+def gdwconv_backward(dy, x, w, dw, dbias, stride, pad, need_dx=True, accumulate=False):
+    """dw [C,1,3,3] / dbias [C] fp32 slots written (or accumulated into); returns d loss / d x (bf16) or None."""
+    B, H, W, C = x.shape
+    _, Ho, Wo, _ = dy.shape
+    py, ldy = view(dy, torch.bfloat16)
+    px, ldx = view(x, torch.bfloat16)
+    L = _lib.lib()
+    ws = _workspace(L.mi_gdwconv_wgrad_workspace(B, Ho, Wo, C), x.device, "gdw")
+    check(L.mi_gdwconv_wgrad(py, ldy, px, ldx, _p(dw), _p(dbias), B, H, W, C, Ho, Wo, stride, pad, int(accumulate), _p(ws), ws.numel(), _stream()), "mi_gdwconv_wgrad")
+    if not need_dx:
+        return None
+    dx = new(B, H, W, C, x.device)
+    pd, ldd = view(dx, torch.bfloat16)
+    check(L.mi_gdwconv_dgrad(py, ldy, _p(w), pd, ldd, B, H, W, C, Ho, Wo, stride, pad, _stream()), "mi_gdwconv_dgrad")
+    return dx
+
+
+def gcca_fwd(q, k, v):
+    """Criss-cross attention core: q, k [B,H,W,Cq], v [B,H,W,C] bf16 views -> (agg [B,H,W,C] bf16, att fp32 [B,H,W,H+W])."""
+    B, H, W, Cq = q.shape
+    C = v.shape[-1]
+    att = torch.empty((B, H, W, H + W), dtype=torch.float32, device=q.device)
+    agg = new(B, H, W, C, q.device)
+    (pq, ldq), (pk, ldk), (pv, ldv), (po, ldo) = view(q, torch.bfloat16), view(k, torch.bfloat16), view(v, torch.bfloat16), view(agg, torch.bfloat16)
+    check(_lib.lib().mi_gcca_fwd(pq, ldq, pk, ldk, pv, ldv, _p(att), po, ldo, B, H, W, Cq, C, _stream()), "mi_gcca_fwd")
+    return agg, att
+
+
+def gcca_bwd(q, k, v, att, dagg):
+    B, H, W, Cq = q.shape
+    C = v.shape[-1]
+    dq, dk, dv = new(B, H, W, Cq, q.device), new(B, H, W, Cq, q.device), new(B, H, W, C, q.device)
+    de = torch.empty_like(att)
+    (pq, ldq), (pk, ldk), (pv, ldv), (pg, ldg) = view(q, torch.bfloat16), view(k, torch.bfloat16), view(v, torch.bfloat16), view(dagg, torch.bfloat16)
+    (p1, l1), (p2, l2), (p3, l3) = view(dq), view(dk), view(dv)
+    check(_lib.lib().mi_gcca_bwd(pq, ldq, pk, ldk, pv, ldv, _p(att), pg, ldg, _p(de), p1, l1, p2, l2, p3, l3, B, H, W, Cq, C, _stream()), "mi_gcca_bwd")
+    return dq, dk, dv
+
+
+def ggate(x, g):
+    """x + x * sigmoid(g)"""
+    B, H, W, C = x.shape
+    out = new(B, H, W, C, x.device)
+    (px, ldx), (pg, ldg), (po, ldo) = view(x, torch.bfloat16), view(g, torch.bfloat16), view(out)
+    check(_lib.lib().mi_ggate(px, ldx, pg, ldg, None, 0, po, ldo, None, 0, B * H * W, C, _stream()), "mi_ggate")
+    return out
+
+
+def ggate_bwd(x, g, dout):
+    B, H, W, C = x.shape
+    dx, dg = new(B, H, W, C, x.device), new(B, H, W, C, x.device)
+    (px, ldx), (pg, ldg), (pd, ldd), (p1, l1), (p2, l2) = view(x, torch.bfloat16), view(g, torch.bfloat16), view(dout, torch.bfloat16), view(dx), view(dg)
+    check(_lib.lib().mi_ggate(px, ldx, pg, ldg, pd, ldd, p1, l1, p2, l2, B * H * W, C, _stream()), "mi_ggate(bwd)")
+    return dx, dg
