@@ -319,11 +319,12 @@ int mi_gbn_finalize(const float* partials, int tiles, int C, long count, const f
 /* eval(): scale = gamma * rsqrt(running_var + eps), shift = beta - running_mean * scale */
 int mi_gbn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, float* scale, float* shift, int C,
                 void* stream);
-/* out = relu?(y * scale[c] + shift[c] (+ add)); out bf16, or fp32 when out_f32 */
+/* out = act(y * scale[c] + shift[c] (+ add)); relu: 0 none, 1 ReLU, 2 ReLU6 (hardnet_68.py:78); out bf16, or fp32 when out_f32 */
 int mi_gbn_apply(const void* y, long ldy, const float* scale, const float* shift, const void* add, long ldadd, void* out, long ldo, int out_f32, long M, int C,
                  int relu, void* stream);
 /* dbeta[c] (+)= sum_m g'[m][c], dgamma[c] (+)= sum_m g'[m][c] * (y[m][c] - mean[c]) * invstd[c]; g' = g where mask > 0 (mask: the layer's
- * ReLU output, or NULL); y NULL: dbeta only (a conv bias gradient).  g / mask fp32 when the flags say so. */
+ * ReLU output, or NULL); y NULL: dbeta only (a conv bias gradient).  g fp32 when g_f32; mask_f32 is a flag word: bit 0 = the mask is fp32,
+ * bit 1 = the mask is a ReLU6 output (the gradient passes where 0 < mask < 6).  The same flags in mi_gbn_bwd_apply. */
 size_t mi_gcolsum_workspace(long M, int C);
 int mi_gbn_bwd_sums(const void* g, long ldg, int g_f32, const void* y, long ldy, const void* mask, long ldm, int mask_f32, const float* mean,
                     const float* invstd, long M, int C, float* dbeta, float* dgamma, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
@@ -332,12 +333,22 @@ int mi_gbn_bwd_apply(const void* g, long ldg, int g_f32, const void* y, long ldy
                      const float* invstd, const float* gamma, const float* dbeta, const float* dgamma, float inv_count, void* dy, long lddy, long M, int C,
                      void* stream);
 /* out = a op b on views.  op: 0 add (sp + spx[i], Res2Net_v1b.py:72; x + crop, PraNet_Res2Net.py:140), 1 mul (partial decoder, :81-83),
- * 2 copy, 3 a where b > 0 else 0 (ReLU backward).  dtype: 0 bf16, 1 fp32, 2 copy fp32 -> bf16, 3 copy bf16 -> fp32. */
+ * 2 copy, 3 a where b > 0 else 0 (ReLU backward), 4 relu(a * b) (the gated products of FAM, gcpa_gald.py:88-101; bf16 only).
+ * dtype: 0 bf16, 1 fp32, 2 copy fp32 -> bf16, 3 copy bf16 -> fp32. */
 int mi_gbinary(int op, int dtype, const void* a, long lda, const void* b, long ldb, void* out, long ldo, long M, int C, void* stream);
 /* AvgPool2d(k, stride, pad) with count_include_pad=True (include_pad != 0; Res2Net_v1b.py:40) or AvgPool2d(stride, stride, ceil_mode=True,
  * count_include_pad=False) (include_pad == 0; Res2Net_v1b.py:122-123).  backward != 0: x is d loss / d input (written), out is d loss / d output. */
 int mi_gavgpool(const void* x, long ldx, void* out, long ldo, int B, int H, int W, int C, int Ho, int Wo, int k, int stride, int pad, int include_pad,
                 int backward, void* stream);
+/* MaxPool2d(k, stride, pad) on NHWC bf16 views (hardnet_68.py:213,233); idx: one byte per output element, the winning tap (first maximum in
+ * scan order).  backward != 0: x is d loss / d input (written), out is d loss / d output, idx as written by the forward. */
+int mi_gmaxpool(const void* x, long ldx, void* out, long ldo, uint8_t* idx, int B, int H, int W, int C, int Ho, int Wo, int k, int stride, int pad, int backward,
+                void* stream);
+/* CrossEntropyLoss(ignore_index) on NHWC fp32 logits [M][K] (view, K <= 32), labels int64 [M] (gald_trainer.py:66-84).  loss_out: four floats as
+ * mi_softmax_ce_fwd (mean over valid pixels, n_valid, out-of-range labels, -).  dlogits (optional, same layout) = d loss / d logits * grad_scale. */
+size_t mi_gce_workspace(long M);
+int mi_gce(const float* logits, long ld, const int64_t* labels, long M, int K, int ignore_index, float* loss_out, float* dlogits, long ldd, float grad_scale,
+           void* workspace, size_t workspace_bytes, void* stream);
 /* F.interpolate / nn.Upsample, mode='bilinear' (PraNet_Res2Net.py:67,127-177): src = align_corners ? scale * dst : max(scale * (dst + 0.5) - 0.5, 0).
  * scale_h / scale_w as ATen computes them: align_corners: (in - 1) / (out - 1); otherwise 1 / scale_factor when the caller gave a
  * scale_factor, in / out when it gave a size.  backward != 0: x is d loss / d input (written), out is d loss / d output (gather form,

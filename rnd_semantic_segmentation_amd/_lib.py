@@ -85,6 +85,9 @@ SIGNATURES = {
     "mi_gbn_bwd_apply": (I, [P, L, I, P, L, P, L, I, P, P, P, P, P, F, P, L, L, I, P]),
     "mi_gbinary": (I, [I, I, P, L, P, L, P, L, L, I, P]),
     "mi_gavgpool": (I, [P, L, P, L] + [I] * 11 + [P]),
+    "mi_gmaxpool": (I, [P, L, P, L, P] + [I] * 10 + [P]),
+    "mi_gce_workspace": (Z, [L]),
+    "mi_gce": (I, [P, L, P, L, I, I, P, P, L, F, P, Z, P]),
     "mi_gresize": (I, [P, L, P, L, I] + [I] * 7 + [F, F, I, P]),
     "mi_gra_fwd": (I, [P, P, L, P, L, L, I, P]),
     "mi_gra_bwd": (I, [P, P, L, P, L, P, L, P, L, I, P]),

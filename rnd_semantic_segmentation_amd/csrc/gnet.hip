@@ -161,9 +161,9 @@ __global__ __launch_bounds__(256) void gbn_apply_kernel(const __bf16* y, long ld
 #pragma unroll
             for (int j = 0; j < VEC; ++j) v[j] += a[j];
         }
-        if (relu) {
+        if (relu) {                                   // 1: ReLU, 2: ReLU6 (hardnet_68.py:78)
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) v[j] = fmaxf(v[j], 0.f);
+            for (int j = 0; j < VEC; ++j) v[j] = relu == 2 ? fminf(fmaxf(v[j], 0.f), 6.f) : fmaxf(v[j], 0.f);
         }
         stv<VEC>(out + m * ldo + c0, v);
     }
@@ -195,7 +195,7 @@ inline ColsumPlan colsum_plan(long M, int C, int vec) {
 }
 template <int VEC, typename TG, typename TM>
 __global__ __launch_bounds__(256) void gcolsum_partial_kernel(const TG* g, long ldg, const __bf16* y, long ldy, const TM* mask, long ldm, const float* mean,
-                                                              const float* invstd, long M, int C, float* partial, int tx_n, int rows_per_block) {
+                                                              const float* invstd, long M, int C, float* partial, int tx_n, int rows_per_block, float hi) {
     __shared__ float red[2][256][VEC];
     const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n, ty_n = 256 / tx_n;
     float s1[VEC], s2[VEC];
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void gcolsum_partial_kernel(const TG* g, long 
                 ldv<VEC>(mask + m * ldm + c0, mv);
 #pragma unroll
                 for (int j = 0; j < VEC; ++j)
-                    if (!(mv[j] > 0.f)) gv[j] = 0.f;
+                    if (!(mv[j] > 0.f && mv[j] < hi)) gv[j] = 0.f;
             }
 #pragma unroll
             for (int j = 0; j < VEC; ++j) s1[j] += gv[j];
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void gcolsum_final_kernel(const float* partial
 template <int VEC, typename TG, typename TM>
 __global__ __launch_bounds__(256) void gbn_bwd_apply_kernel(const TG* g, long ldg, const __bf16* y, long ldy, const TM* mask, long ldm, const float* mean,
                                                             const float* invstd, const float* gamma, const float* dbeta, const float* dgamma,
-                                                            float inv_count, __bf16* dy, long lddy, long M, int C) {
+                                                            float inv_count, __bf16* dy, long lddy, long M, int C, float hi) {
     const int cv = C / VEC;
     const long n = M * cv;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void gbn_bwd_apply_kernel(const TG* g, long ld
             ldv<VEC>(mask + m * ldm + c0, mv);
 #pragma unroll
             for (int j = 0; j < VEC; ++j)
-                if (!(mv[j] > 0.f)) gv[j] = 0.f;
+                if (!(mv[j] > 0.f && mv[j] < hi)) gv[j] = 0.f;
         }
         float is[VEC], mu[VEC], ga[VEC], db[VEC], dg[VEC];
         ldp<VEC>(invstd + c0, is);
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void gbn_bwd_apply_kernel(const TG* g, long ld
 }
 
 // ------------------------------------------------------------------------------------------------ elementwise on views
-enum { OP_ADD = 0, OP_MUL = 1, OP_COPY = 2, OP_RELU_MASK = 3 /* a where b > 0 else 0 */ };
+enum { OP_ADD = 0, OP_MUL = 1, OP_COPY = 2, OP_RELU_MASK = 3 /* a where b > 0 else 0 */, OP_MULRELU = 4 /* relu(a * b) */ };
 template <int OP, int VEC, typename TA, typename TB, typename TO>
 __global__ __launch_bounds__(256) void gbinary_kernel(const TA* a, long lda, const TB* b, long ldb, TO* out, long ldo, long M, int C) {
     const int cv = C / VEC;
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void gbinary_kernel(const TA* a, long lda, con
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             if constexpr (OP == OP_COPY) r[j] = av[j];
-            else r[j] = OP == OP_ADD ? av[j] + bv[j] : (OP == OP_MUL ? av[j] * bv[j] : (bv[j] > 0.f ? av[j] : 0.f));
+            else r[j] = OP == OP_ADD ? av[j] + bv[j] : (OP == OP_MUL ? av[j] * bv[j] : (OP == OP_MULRELU ? fmaxf(av[j] * bv[j], 0.f) : (bv[j] > 0.f ? av[j] : 0.f)));
         }
         stv<VEC>(out + m * ldo + c0, r);
     }
@@ -390,6 +390,139 @@ __global__ __launch_bounds__(256) void gavgpool_bwd_kernel(const __bf16* dout, _
             }
         }
         dx[m * q.ldx + c] = (__bf16)s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ max pools (NHWC bf16 views)
+// MaxPool2d(k, s, p) of HarDNet (hardnet_68.py:213,233: 3/2/1 after the stem, 2/2 after the transitions): out + the winning tap (first
+// maximum in scan order, like ATen) as one byte per element; backward routes dout to that tap (gather form, fixed order).
+__global__ __launch_bounds__(256) void gmaxpool_fwd_kernel(const __bf16* x, __bf16* out, uint8_t* idx, PoolP q) {
+    const long n = (long)q.B * q.Ho * q.Wo * q.C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % q.C);
+        long m = e / q.C;
+        const int ow = (int)(m % q.Wo);
+        const long t = m / q.Wo;
+        const int oh = (int)(t % q.Ho), b = (int)(t / q.Ho);
+        float best = -INFINITY;
+        int arg = 255;
+        for (int ky = 0; ky < q.k; ++ky) {
+            const int ih = oh * q.s - q.p + ky;
+            if ((unsigned)ih >= (unsigned)q.H) continue;
+            for (int kx = 0; kx < q.k; ++kx) {
+                const int iw = ow * q.s - q.p + kx;
+                if ((unsigned)iw >= (unsigned)q.W) continue;
+                const float v = (float)x[(((long)b * q.H + ih) * q.W + iw) * q.ldx + c];
+                if (v > best || arg == 255) {
+                    best = v;
+                    arg = ky * q.k + kx;
+                }
+            }
+        }
+        out[m * q.ldo + c] = (__bf16)best;
+        idx[m * q.C + c] = (uint8_t)arg;
+    }
+}
+__global__ __launch_bounds__(256) void gmaxpool_bwd_kernel(const __bf16* dout, const uint8_t* idx, __bf16* dx, PoolP q) {
+    const long n = (long)q.B * q.H * q.W * q.C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % q.C);
+        long m = e / q.C;
+        const int iw = (int)(m % q.W);
+        const long t = m / q.W;
+        const int ih = (int)(t % q.H), b = (int)(t / q.H);
+        float s = 0.f;
+        for (int ky = 0; ky < q.k; ++ky) {
+            const int nh = ih + q.p - ky;
+            if (nh < 0 || nh % q.s) continue;
+            const int oh = nh / q.s;
+            if (oh >= q.Ho) continue;
+            for (int kx = 0; kx < q.k; ++kx) {
+                const int nw = iw + q.p - kx;
+                if (nw < 0 || nw % q.s) continue;
+                const int ow = nw / q.s;
+                if (ow >= q.Wo) continue;
+                const long mo = ((long)b * q.Ho + oh) * q.Wo + ow;
+                if (idx[mo * q.C + c] == ky * q.k + kx) s += (float)dout[mo * q.ldo + c];
+            }
+        }
+        dx[m * q.ldx + c] = (__bf16)s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ cross-entropy on NHWC fp32 logits
+// CrossEntropyLoss(ignore_index) (gald_trainer.py:66-84, one per deep-supervision head) on logits [M][K] (view, K <= 32), labels int64 [M].
+// Two levels, fixed order: per-block (loss, valid, out-of-range) partials, then one block sums them into loss_out[0..2].
+constexpr int CE_ROWS = 1024;
+__global__ __launch_bounds__(256) void gce_partial_kernel(const float* logits, long ld, const long* labels, int ignore, long M, int K, float* partial) {
+    __shared__ float red[3][256];
+    float loss = 0.f, cnt = 0.f, bad = 0.f;
+    const long r0 = (long)blockIdx.x * CE_ROWS;
+    for (int r = threadIdx.x; r < CE_ROWS; r += 256) {
+        const long m = r0 + r;
+        if (m >= M) break;
+        const long y = labels[m];
+        if (y == ignore) continue;
+        if (y < 0 || y >= K) {
+            bad += 1.f;
+            continue;
+        }
+        const float* z = logits + m * ld;
+        float mx = z[0];
+        for (int k = 1; k < K; ++k) mx = fmaxf(mx, z[k]);
+        float se = 0.f;
+        for (int k = 0; k < K; ++k) se += __expf(z[k] - mx);
+        loss += __logf(se) - (z[y] - mx);
+        cnt += 1.f;
+    }
+    red[0][threadIdx.x] = loss;
+    red[1][threadIdx.x] = cnt;
+    red[2][threadIdx.x] = bad;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s)
+            for (int a = 0; a < 3; ++a) red[a][threadIdx.x] += red[a][threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) partial[(long)blockIdx.x * 3 + threadIdx.x] = red[threadIdx.x][0];
+}
+__global__ __launch_bounds__(256) void gce_final_kernel(const float* partial, int blocks, float* loss_out) {
+    __shared__ double red[3][256];
+    double a[3] = {0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < blocks; b += 256)
+        for (int k = 0; k < 3; ++k) a[k] += (double)partial[(long)b * 3 + k];
+    for (int k = 0; k < 3; ++k) red[k][threadIdx.x] = a[k];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s)
+            for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        loss_out[0] = red[1][0] > 0.0 ? (float)(red[0][0] / red[1][0]) : NAN;       // mean over the valid pixels (nan if none, like torch)
+        loss_out[1] = (float)red[1][0];
+        loss_out[2] = (float)red[2][0];
+        loss_out[3] = 0.f;
+    }
+}
+// dlogits = (softmax - onehot) * valid / n_valid * grad_scale, n_valid read from loss_out[1] on the device
+__global__ __launch_bounds__(256) void gce_bwd_kernel(const float* logits, long ld, const long* labels, int ignore, long M, int K, const float* loss_out, float grad_scale,
+                                                      float* dlogits, long ldd) {
+    const float inv = loss_out[1] > 0.f ? grad_scale / loss_out[1] : 0.f;
+    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
+        const long y = labels[m];
+        float* d = dlogits + m * ldd;
+        if (y == ignore || y < 0 || y >= K) {
+            for (int k = 0; k < K; ++k) d[k] = 0.f;
+            continue;
+        }
+        const float* z = logits + m * ld;
+        float mx = z[0];
+        for (int k = 1; k < K; ++k) mx = fmaxf(mx, z[k]);
+        float se = 0.f;
+        for (int k = 0; k < K; ++k) se += __expf(z[k] - mx);
+        const float r = inv / se;
+        for (int k = 0; k < K; ++k) d[k] = __expf(z[k] - mx) * r - (k == y ? inv : 0.f);
     }
 }
 
@@ -621,6 +754,8 @@ int mi_gbn_bwd_sums(const void* g, long ldg, int g_f32, const void* y, long ldy,
     MI_REQUIRE(g && workspace && (dbeta || dgamma), "mi_gbn_bwd_sums: null operand");
     MI_REQUIRE(M > 0 && C > 0 && ldg >= C, "mi_gbn_bwd_sums: bad shape");
     MI_REQUIRE(!y || (mean && invstd && ldy >= C), "mi_gbn_bwd_sums: y needs mean / invstd");
+    const float hi = (mask_f32 & 2) ? 6.f : INFINITY;      // bit 1 of the mask flags: the mask is a ReLU6 output (gradient only where 0 < out < 6)
+    mask_f32 &= 1;
     MI_REQUIRE(g_f32 || !mask_f32, "mi_gbn_bwd_sums: an fp32 mask goes with an fp32 gradient");
     if (workspace_bytes < mi_gcolsum_workspace(M, C)) return mi_set_error(MI_ENOMEM, "mi_gbn_bwd_sums: workspace too small");
     hipStream_t s = (hipStream_t)stream;
@@ -630,7 +765,7 @@ int mi_gbn_bwd_sums(const void* g, long ldg, int g_f32, const void* y, long ldy,
     const ColsumPlan q = colsum_plan(M, C, vec);
     const int blocks = q.blocks;
     const dim3 grid(blocks, ((C + vec - 1) / vec + q.tx - 1) / q.tx);
-#define CSK(V, TG, TM) hipLaunchKernelGGL((gcolsum_partial_kernel<V, TG, TM>), grid, dim3(256), 0, s, (const TG*)g, ldg, yy, ldy, (const TM*)mask, ldm, mean, invstd, M, C, part, q.tx, q.rows_per_block)
+#define CSK(V, TG, TM) hipLaunchKernelGGL((gcolsum_partial_kernel<V, TG, TM>), grid, dim3(256), 0, s, (const TG*)g, ldg, yy, ldy, (const TM*)mask, ldm, mean, invstd, M, C, part, q.tx, q.rows_per_block, hi)
     if (g_f32 && mask_f32) CSK(1, float, float);
     else if (g_f32) CSK(1, float, __bf16);
     else if (vec == 8) CSK(8, __bf16, __bf16);
@@ -648,6 +783,8 @@ int mi_gbn_bwd_apply(const void* g, long ldg, int g_f32, const void* y, long ldy
                      void* stream) {
     MI_REQUIRE(g && y && mean && invstd && dbeta && dgamma && dy, "mi_gbn_bwd_apply: null operand");
     MI_REQUIRE(M > 0 && C > 0 && ldg >= C && ldy >= C && lddy >= C, "mi_gbn_bwd_apply: bad shape");
+    const float hi = (mask_f32 & 2) ? 6.f : INFINITY;
+    mask_f32 &= 1;
     MI_REQUIRE(g_f32 || !mask_f32, "mi_gbn_bwd_apply: an fp32 mask goes with an fp32 gradient");
     hipStream_t s = (hipStream_t)stream;
     const __bf16* yy = (const __bf16*)y;
@@ -655,7 +792,7 @@ int mi_gbn_bwd_apply(const void* g, long ldg, int g_f32, const void* y, long ldy
     if (vec == 8 && ((reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(invstd) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(dbeta) |
                       reinterpret_cast<uintptr_t>(dgamma)) & 15)) vec = 2;
     const dim3 grid(grid_for(M * C / vec));
-#define BAK(V, TG, TM) hipLaunchKernelGGL((gbn_bwd_apply_kernel<V, TG, TM>), grid, dim3(256), 0, s, (const TG*)g, ldg, yy, ldy, (const TM*)mask, ldm, mean, invstd, gamma, dbeta, dgamma, inv_count, (__bf16*)dy, lddy, M, C)
+#define BAK(V, TG, TM) hipLaunchKernelGGL((gbn_bwd_apply_kernel<V, TG, TM>), grid, dim3(256), 0, s, (const TG*)g, ldg, yy, ldy, (const TM*)mask, ldm, mean, invstd, gamma, dbeta, dgamma, inv_count, (__bf16*)dy, lddy, M, C, hi)
     if (g_f32 && mask_f32) BAK(1, float, float);
     else if (g_f32) BAK(1, float, __bf16);
     else if (vec == 8) BAK(8, __bf16, __bf16);
@@ -671,7 +808,7 @@ int mi_gbn_bwd_apply(const void* g, long ldg, int g_f32, const void* y, long ldy
 int mi_gbinary(int op, int dtype, const void* a, long lda, const void* b, long ldb, void* out, long ldo, long M, int C, void* stream) {
     MI_REQUIRE(a && out && (b || op == OP_COPY), "mi_gbinary: null operand");
     MI_REQUIRE(M > 0 && C > 0 && lda >= C && ldo >= C && (op == OP_COPY || ldb >= C), "mi_gbinary: bad shape");
-    MI_REQUIRE(op >= 0 && op <= 3 && dtype >= 0 && dtype <= 3 && (dtype < 2 || op == OP_COPY), "mi_gbinary: op %d / dtype %d", op, dtype);
+    MI_REQUIRE(op >= 0 && op <= 4 && dtype >= 0 && dtype <= 3 && (dtype < 2 || op == OP_COPY) && (op != OP_MULRELU || dtype == 0), "mi_gbinary: op %d / dtype %d", op, dtype);
     hipStream_t s = (hipStream_t)stream;
     const int vec = dtype == 0 ? common_vec(C, {{a, lda}, {out, ldo}, {op == OP_COPY ? nullptr : b, ldb}}) : 1;
     const dim3 grid(grid_for(M * C / vec));
@@ -686,6 +823,7 @@ int mi_gbinary(int op, int dtype, const void* a, long lda, const void* b, long l
         if (op == OP_ADD) GBV(OP_ADD);
         else if (op == OP_MUL) GBV(OP_MUL);
         else if (op == OP_COPY) GBV(OP_COPY);
+        else if (op == OP_MULRELU) GBV(OP_MULRELU);
         else GBV(OP_RELU_MASK);
     } else if (dtype == 1) {
         if (op == OP_ADD) GB(OP_ADD, 1, float, float, float);
@@ -710,6 +848,39 @@ int mi_gavgpool(const void* x, long ldx, void* out, long ldo, int B, int H, int 
     if (!backward) hipLaunchKernelGGL(gavgpool_fwd_kernel, dim3(grid_for((long)B * Ho * Wo * C)), dim3(256), 0, s, (const __bf16*)x, (__bf16*)out, q);
     else hipLaunchKernelGGL(gavgpool_bwd_kernel, dim3(grid_for((long)B * H * W * C)), dim3(256), 0, s, (const __bf16*)out, (__bf16*)const_cast<void*>(x), q);
     MI_CHECK_LAUNCH("gavgpool_kernel");
+    return MI_OK;
+}
+
+int mi_gmaxpool(const void* x, long ldx, void* out, long ldo, uint8_t* idx, int B, int H, int W, int C, int Ho, int Wo, int k, int stride, int pad, int backward,
+                void* stream) {
+    MI_REQUIRE(x && out && idx, "mi_gmaxpool: null operand");
+    MI_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && k > 0 && k <= 15 && stride > 0 && pad >= 0 && ldx >= C && ldo >= C, "mi_gmaxpool: bad shape");
+    MI_REQUIRE((H + 2 * pad - k) / stride + 1 == Ho && (W + 2 * pad - k) / stride + 1 == Wo && Ho > 0 && Wo > 0, "mi_gmaxpool: output %dx%d does not follow from input %dx%d", Ho, Wo, H, W);
+    PoolP q{B, H, W, C, Ho, Wo, k, stride, pad, 0, ldx, ldo};
+    hipStream_t s = (hipStream_t)stream;
+    if (!backward) hipLaunchKernelGGL(gmaxpool_fwd_kernel, dim3(grid_for((long)B * Ho * Wo * C)), dim3(256), 0, s, (const __bf16*)x, (__bf16*)out, idx, q);
+    else hipLaunchKernelGGL(gmaxpool_bwd_kernel, dim3(grid_for((long)B * H * W * C)), dim3(256), 0, s, (const __bf16*)out, (const uint8_t*)idx, (__bf16*)const_cast<void*>(x), q);
+    MI_CHECK_LAUNCH("gmaxpool_kernel");
+    return MI_OK;
+}
+
+size_t mi_gce_workspace(long M) { return (size_t)((M + CE_ROWS - 1) / CE_ROWS) * 3 * sizeof(float); }
+
+int mi_gce(const float* logits, long ld, const int64_t* labels, long M, int K, int ignore_index, float* loss_out, float* dlogits, long ldd, float grad_scale,
+           void* workspace, size_t workspace_bytes, void* stream) {
+    MI_REQUIRE(logits && labels && loss_out && workspace, "mi_gce: null operand");
+    MI_REQUIRE(M > 0 && K > 0 && K <= 32 && ld >= K && (!dlogits || ldd >= K), "mi_gce: bad shape (K <= 32)");
+    if (workspace_bytes < mi_gce_workspace(M)) return mi_set_error(MI_ENOMEM, "mi_gce: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = (int)((M + CE_ROWS - 1) / CE_ROWS);
+    hipLaunchKernelGGL(gce_partial_kernel, dim3(blocks), dim3(256), 0, s, logits, ld, (const long*)labels, ignore_index, M, K, (float*)workspace);
+    MI_CHECK_LAUNCH("gce_partial_kernel");
+    hipLaunchKernelGGL(gce_final_kernel, dim3(1), dim3(256), 0, s, (const float*)workspace, blocks, loss_out);
+    MI_CHECK_LAUNCH("gce_final_kernel");
+    if (dlogits) {
+        hipLaunchKernelGGL(gce_bwd_kernel, dim3(grid_for(M)), dim3(256), 0, s, logits, ld, (const long*)labels, ignore_index, M, K, (const float*)loss_out, grad_scale, dlogits, ldd);
+        MI_CHECK_LAUNCH("gce_bwd_kernel");
+    }
     return MI_OK;
 }
 

@@ -11,7 +11,7 @@ from . import _lib
 from ._lib import check
 from .kernels import _p, _stream, _workspace, GATHER_FWD, GATHER_DGRAD  # noqa: F401
 
-OP_ADD, OP_MUL, OP_COPY, OP_RELU_MASK = 0, 1, 2, 3
+OP_ADD, OP_MUL, OP_COPY, OP_RELU_MASK, OP_MULRELU = 0, 1, 2, 3, 4
 
 
 def view(t, dtype=None):
@@ -126,20 +126,20 @@ def gbn_apply(y, scale, shift, relu, add=None, out=None, out_f32=False):
     return out
 
 
-def _gm(g, mask):
+def _gm(g, mask, relu6=False):
     pg, ldg = view(g)
     gf = g.dtype == torch.float32
     if mask is None:
         return pg, ldg, int(gf), None, 0, 0
     pm, ldm = view(mask)
-    return pg, ldg, int(gf), pm, ldm, int(mask.dtype == torch.float32)
+    return pg, ldg, int(gf), pm, ldm, int(mask.dtype == torch.float32) | (2 if relu6 else 0)      # flag word: bit 0 fp32 mask, bit 1 ReLU6 mask
 
 
-def gbn_bwd_sums(g, y, mask, mean, invstd, dbeta, dgamma, accumulate=False):
-    """dbeta / dgamma: fp32 [C] slots written (or accumulated into); y None: dbeta only."""
+def gbn_bwd_sums(g, y, mask, mean, invstd, dbeta, dgamma, accumulate=False, relu6=False):
+    """dbeta / dgamma: fp32 [C] slots written (or accumulated into); y None: dbeta only.  relu6: the mask is a ReLU6 output."""
     B, H, W, C = g.shape
     M = B * H * W
-    pg, ldg, gf, pm, ldm, mf = _gm(g, mask)
+    pg, ldg, gf, pm, ldm, mf = _gm(g, mask, relu6)
     py, ldy = view(y, torch.bfloat16) if y is not None else (None, 0)
     L = _lib.lib()
     ws = _workspace(L.mi_gcolsum_workspace(M, C), g.device, "gcolsum")
@@ -147,11 +147,11 @@ def gbn_bwd_sums(g, y, mask, mean, invstd, dbeta, dgamma, accumulate=False):
                             _stream()), "mi_gbn_bwd_sums")
 
 
-def gbn_bwd_apply(g, y, mask, mean, invstd, gamma, dbeta, dgamma, count, out=None):
+def gbn_bwd_apply(g, y, mask, mean, invstd, gamma, dbeta, dgamma, count, out=None, relu6=False):
     B, H, W, C = g.shape
     if out is None:
         out = new(B, H, W, C, g.device)
-    pg, ldg, gf, pm, ldm, mf = _gm(g, mask)
+    pg, ldg, gf, pm, ldm, mf = _gm(g, mask, relu6)
     py, ldy = view(y, torch.bfloat16)
     po, ldo = view(out, torch.bfloat16)
     check(_lib.lib().mi_gbn_bwd_apply(pg, ldg, gf, py, ldy, pm, ldm, mf, _p(mean), _p(invstd), _p(gamma), _p(dbeta), _p(dgamma), ctypes.c_float(1.0 / count),
@@ -326,3 +326,38 @@ def ggate_bwd(x, g, dout):
     (px, ldx), (pg, ldg), (pd, ldd), (p1, l1), (p2, l2) = view(x, torch.bfloat16), view(g, torch.bfloat16), view(dout, torch.bfloat16), view(dx), view(dg)
     check(_lib.lib().mi_ggate(px, ldx, pg, ldg, pd, ldd, p1, l1, p2, l2, B * H * W, C, _stream()), "mi_ggate(bwd)")
     return dx, dg
+
+
+def gmaxpool(x, k, stride, pad):
+    """MaxPool2d(k, stride, pad) on a bf16 NHWC view -> (out, idx uint8 [B,Ho,Wo,C])"""
+    B, H, W, C = x.shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    out = new(B, Ho, Wo, C, x.device)
+    idx = torch.empty((B, Ho, Wo, C), dtype=torch.uint8, device=x.device)
+    (px, ldx), (po, ldo) = view(x, torch.bfloat16), view(out)
+    check(_lib.lib().mi_gmaxpool(px, ldx, po, ldo, _p(idx), B, H, W, C, Ho, Wo, k, stride, pad, 0, _stream()), "mi_gmaxpool")
+    return out, idx
+
+
+def gmaxpool_bwd(dout, idx, in_hw, k, stride, pad, dx=None):
+    B, Ho, Wo, C = dout.shape
+    H, W = in_hw
+    if dx is None:
+        dx = new(B, H, W, C, dout.device)
+    (px, ldx), (po, ldo) = view(dx, torch.bfloat16), view(dout, torch.bfloat16)
+    check(_lib.lib().mi_gmaxpool(px, ldx, po, ldo, _p(idx), B, H, W, C, Ho, Wo, k, stride, pad, 1, _stream()), "mi_gmaxpool(bwd)")
+    return dx
+
+
+def gce(logits, labels, ignore_index=255, want_grad=True, grad_scale=1.0):
+    """CrossEntropyLoss(ignore_index) on NHWC fp32 logits [B,H,W,K] (view), labels int64 [B,H,W] -> (loss_out[4], dlogits or None)."""
+    B, H, W, Kc = logits.shape
+    pl, ld = view(logits, torch.float32)
+    if not (labels.dtype == torch.int64 and labels.is_contiguous() and labels.numel() == B * H * W):
+        raise _lib.MiError("gce: labels must be contiguous int64 [B,H,W]")
+    L = _lib.lib()
+    ws = _workspace(L.mi_gce_workspace(B * H * W), logits.device, "gce")
+    out = torch.empty(4, dtype=torch.float32, device=logits.device)
+    d = torch.empty((B, H, W, Kc), dtype=torch.float32, device=logits.device) if want_grad else None
+    check(L.mi_gce(pl, ld, _p(labels), B * H * W, Kc, int(ignore_index), _p(out), _p(d), Kc, ctypes.c_float(grad_scale), _p(ws), ws.numel(), _stream()), "mi_gce")
+    return out, d

@@ -1,0 +1,417 @@
+"""The GALD / GCPA path on the MI355X engine: HarDNet-68 encoder, criss-cross attention, local attention modules, feature
+aggregation modules, four deep-supervision heads - forward AND backward as a tape of C-ABI launches (csrc/gconv.hip, gnet.hip, gald.hip).
+
+  GCPAEncoder, GCPADecoder     reference core/models/classifiers/gcpacc/gcpa_cc2.py:16-83 (state_dict keys: 404 + 186)
+  HarDNet-68                   reference core/models/classifiers/gcpacc/encoders/hardnet_68.py:56-262
+  CrissCrossAttention          reference core/models/classifiers/gcpacc/contextagg/ccnet.py:37-127
+  LocalAttenModule             reference core/models/classifiers/gcpacc/contextagg/GALDNet.py:124-157
+  FAM                          reference core/models/classifiers/gcpacc/gcpa_gald.py:47-107
+  GALDTrainer                  reference core/trainers/gald_trainer.py:13-112
+
+Same engine as host/pranet.py (NHWC bf16 activations, concatenations as channel-slice views where the link pattern allows, BatchNorm2d on
+batch statistics from the conv's tile sums, one flat fp32 parameter / gradient buffer per module, Adam in one launch).  What is new here:
+ReLU6, max pools with a stored argmax, the depthwise stride-2 convs, the attention core (one workgroup per pixel instead of the reference's
+permute / contiguous / bmm chain), parameters shared between two applications of a module (the criss-cross module runs twice: gradients
+accumulate in its slots), class-logit heads upsampled with align_corners=False and a cross-entropy kernel on NHWC logits.
+"""
+import os
+from datetime import datetime
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .. import gk
+from . import arch
+from .metrics import adjust_learning_rate, dump_json
+from .plugin import BaseTrainer
+from .pranet import FlatAdam, _acc, _Engine, _grad_target, _Run, _Unit
+
+
+class _GaldRun(_Run):
+    def maxpool(self, x, k, stride, pad):
+        H, W = x.t.shape[1], x.t.shape[2]
+        o, idx = gk.gmaxpool(x.t, k, stride, pad)
+        ov = self.var(o)
+
+        def back():
+            if ov.g is not None:
+                _acc(x, gk.gmaxpool_bwd(ov.g, idx, (H, W), k, stride, pad, dx=_grad_target(x)), True)
+                ov.g = None
+        self.record(back)
+        return ov
+
+    def dw_bn_relu(self, x, u):
+        """Conv2d(C, C, 3, groups=C, stride=2) with bias -> BatchNorm2d -> ReLU (GALDNet.py:127-136); u.weight is [C,1,3,3]."""
+        net, bn = self.net, u.bn
+        C = u.cout
+        if not self.train:
+            y, _ = gk.gdwconv(x.t, u.weight.detach(), u.bias.detach(), 2, 0)
+            sc, sh = net._eval_fold(u)
+            return self.var(gk.gbn_apply(y, sc, sh, 1), False)
+        y, st = gk.gdwconv(x.t, u.weight.detach(), u.bias.detach(), 2, 0, stats=True)
+        M = y.shape[0] * y.shape[1] * y.shape[2]
+        fin = gk.gbn_finalize(st, C, M, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+        o = gk.gbn_apply(y, fin[2], fin[3], 1)
+        ov = self.var(o)
+
+        def back():
+            g = ov.g
+            ov.g = None
+            if g is None:
+                return
+            dbeta, dgamma = net._grad_of(bn.bias), net._grad_of(bn.weight)
+            gk.gbn_bwd_sums(g, y, o, fin[0], fin[1], dbeta, dgamma)
+            dy = gk.gbn_bwd_apply(g, y, o, fin[0], fin[1], bn.weight, dbeta, dgamma, M)
+            dx = gk.gdwconv_backward(dy, x.t, u.weight.detach(), net._grad_of(u.weight), net._grad_of(u.bias), 2, 0, need_dx=x.needs)
+            if dx is not None:
+                _acc(x, dx, True)
+        self.record(back)
+        return ov
+
+    def gate(self, x, g):
+        """x + x * sigmoid(g) (GALDNet.py:150-157)"""
+        ov = self.var(gk.ggate(x.t, g.t))
+
+        def back():
+            if ov.g is None:
+                return
+            dx, dg = gk.ggate_bwd(x.t, g.t, ov.g)
+            ov.g = None
+            _acc(x, dx, True)
+            _acc(g, dg, True)
+        self.record(back)
+        return ov
+
+    def mulrelu(self, a, b, out=None):
+        """relu(a * b) (gcpa_gald.py:88-101)"""
+        o = gk.gbinary(gk.OP_MULRELU, a.t, b.t, out=out)
+        ov = self.var(o)
+
+        def back():
+            g = ov.g
+            ov.g = None
+            if g is None:
+                return
+            gm = gk.gbinary(gk.OP_RELU_MASK, g, o)
+            _acc(a, gk.gbinary(gk.OP_MUL, gm, b.t), True)
+            _acc(b, gk.gbinary(gk.OP_MUL, gm, a.t), True)
+        self.record(back)
+        return ov
+
+    def criss_cross(self, x, uq, uk, uv, gamma):
+        """CrissCrossAttention.forward (ccnet.py:56-127): gamma * aggregate + x."""
+        net = self.net
+        q, k, v = self.conv_bias(x, uq, out_f32=False), self.conv_bias(x, uk, out_f32=False), self.conv_bias(x, uv, out_f32=False)
+        agg, att = gk.gcca_fwd(q.t, k.t, v.t)
+        C = agg.shape[-1]
+        gvec = gamma.detach().expand(C).contiguous()
+        zero = net._zeros(C)
+        ov = self.var(gk.gbn_apply(agg, gvec, zero, 0, add=x.t))
+
+        def back():
+            g = ov.g
+            ov.g = None
+            if g is None:
+                return
+            _acc(x, g, False)                                              # the residual
+            dagg = gk.gbn_apply(g, gvec, zero, 0)
+            per_c = torch.empty(C, dtype=torch.float32, device=g.device)
+            gk.gbn_bwd_sums(g, agg, None, zero, net._ones(C), torch.empty_like(per_c), per_c)      # sum_m g[m][c] * agg[m][c]
+            slot, acc = net._grad_slot(gamma)
+            s = per_c.sum().reshape(1)
+            slot.add_(s) if acc else slot.copy_(s)
+            dq, dk, dv = gk.gcca_bwd(q.t, k.t, v.t, att, dagg)
+            _acc(q, dq, True)
+            _acc(k, dk, True)
+            _acc(v, dv, True)
+        self.record(back)
+        return ov
+
+
+# ------------------------------------------------------------------------------------------------ HarDNet-68
+def _hard_link(layer, base_ch, growth, mul):
+    """Harmonic dense links (hardnet_68.py:84-102): layer n reads layers n - 2^i for every 2^i that divides n; width growth * mul^(links - 1),
+    rounded to even.  -> (out channels, in channels, links)"""
+    if layer == 0:
+        return base_ch, 0, []
+    links, width = [], float(growth)
+    for i in range(10):
+        if layer % (1 << i) == 0:
+            links.append(layer - (1 << i))
+            if i:
+                width *= mul
+    return int(int(width + 1) / 2) * 2, sum(_hard_link(j, base_ch, growth, mul)[0] for j in links), links
+
+
+def _conv_layer(name, cin, cout, k=3, stride=1):
+    return _Unit(name + ".conv", name + ".norm", cin, cout, k, stride, k // 2)
+
+
+class GCPAEncoder(_Engine):
+    """HarDNet-68 trunk (gcpa_cc2.py:16-23); forward(x [B,3,H,W]) -> the four features at 1/4 (128), 1/8 (320), 1/16 (640), 1/32 (1024),
+    bf16, NCHW-shaped views of NHWC memory.  The reference loads 'pretrained/hardnet68.pth', which the image lacks: weights keep the module
+    defaults unless a checkpoint is loaded."""
+    RUN = _GaldRun
+
+    def __init__(self):
+        super().__init__()
+        p = "hardnet.base."
+        order = [_conv_layer(p + "0", 3, 32, 3, 2), _conv_layer(p + "1", 32, 64, 3)]
+        self._seq = [("conv", order[0]), ("conv", order[1]), ("pool3", None)]
+        ch, idx = 64, 3
+        for width, growth, n, down in zip((128, 256, 320, 640, 1024), (14, 16, 20, 40, 160), (8, 16, 16, 16, 4), (1, 0, 1, 1, 0)):
+            layers, links, out_ch = [], [], 0
+            for i in range(n):
+                oc, ic, lk = _hard_link(i + 1, ch, growth, 1.7)
+                layers.append(_conv_layer("%s%d.layers.%d" % (p, idx, i), ic, oc))
+                links.append(lk)
+                if i % 2 == 0 or i == n - 1:
+                    out_ch += oc
+            order += layers
+            self._seq.append(("block", (layers, links, out_ch)))
+            trans = _conv_layer(p + str(idx + 1), out_ch, width, 1)
+            order.append(trans)
+            self._seq.append(("conv_tap" if width != 256 else "conv", trans))
+            idx += 2
+            ch = width
+            if down:
+                self._seq.append(("pool2", None))
+                idx += 1
+        self._head_key = p + str(idx) + ".3"
+        order += [(self._head_key + ".weight", torch.empty(1000, 1024).uniform_(-1, 1) / 32.0),          # the ImageNet head: in the reference's
+                  (self._head_key + ".bias", torch.empty(1000).uniform_(-1, 1) / 32.0)]                    # state_dict, never run
+        self._register(order)
+
+    def _block(self, run, x, layers, links, out_ch):
+        """HarDBlock.forward (hardnet_68.py:137-160): the layers that make up the block's output (the odd ones and the last) write straight
+        into their channel range of the output buffer; a layer with several links reads a gathered copy."""
+        B, H, W, _ = x.t.shape
+        n = len(layers)
+        keep = [i for i in range(1, n + 1) if i == n or i % 2 == 1]                 # indices into outs (0 = the block input)
+        offs, off = {}, 0
+        for i in keep:
+            offs[i] = off
+            off += layers[i - 1].cout
+        outbuf = gk.new(B, H, W, out_ch, x.t.device)
+        outs = [x]
+        for li, (u, lk) in enumerate(zip(layers, links), 1):
+            if len(lk) > 1:
+                cin = sum(outs[j].t.shape[-1] for j in lk)
+                buf = gk.new(B, H, W, cin, x.t.device)
+                pieces, o = [], 0
+                for j in lk:
+                    c = outs[j].t.shape[-1]
+                    pieces.append(run.copy_into(outs[j], buf[..., o:o + c]))
+                    o += c
+                inp = run.cat(buf, pieces)
+            else:
+                inp = outs[lk[0]]
+            dst = outbuf[..., offs[li]:offs[li] + u.cout] if li in offs else None
+            outs.append(run.conv_bn(inp, u, 6, out=dst))
+        return run.cat(outbuf, [outs[i] for i in keep])
+
+    def _graph(self, run, x):
+        feats, y = [], x
+        for kind, arg in self._seq:
+            if kind in ("conv", "conv_tap"):
+                y = run.conv_bn(y, arg, 6)
+                if kind == "conv_tap":
+                    feats.append(y)
+            elif kind == "pool3":
+                y = run.maxpool(y, 3, 2, 1)
+            elif kind == "pool2":
+                y = run.maxpool(y, 2, 2, 0)
+            else:
+                y = self._block(run, y, *arg)
+        return feats
+
+
+def _fam_units(name, c_left, c_down, c_right, c):
+    u = dict(conv0=_Unit(name + ".conv0", name + ".bn0", c_left, c, 3, 1, 1), conv1=_Unit(name + ".conv1", name + ".bn1", c_down, c, 3, 1, 1),
+             conv2=_Unit(name + ".conv2", name + ".bn2", c_right, c, 3, 1, 1), conv_d1=_Unit(name + ".conv_d1", None, c, c, 3, 1, 1),
+             conv_d2=_Unit(name + ".conv_d2", None, c, c, 3, 1, 1), conv_l=_Unit(name + ".conv_l", None, c, c, 3, 1, 1),
+             conv3=_Unit(name + ".conv3", name + ".bn3", 3 * c, c, 3, 1, 1))
+    for k in ("conv0", "conv1", "conv2", "conv3"):
+        u[k].bias = True                                     # nn.Conv2d default: these convs carry a bias in front of their BatchNorm
+    return u, [u[k] for k in ("conv0", "conv1", "conv2", "conv_d1", "conv_d2", "conv_l", "conv3")]
+
+
+class GCPADecoder(_Engine):
+    """gcpa_cc2.py:25-83.  forward(x, feats) -> (out5, out4, out3, out2): class logits [B,19,H,W] fp32 (NCHW-shaped views of NHWC memory)."""
+    RUN = _GaldRun
+
+    def __init__(self, num_classes=19, c=256):
+        super().__init__()
+        self.num_classes, self._c = num_classes, c
+        order, self._fam = [], {}
+        for name, cl in (("fam45", 640), ("fam34", 320), ("fam23", 128)):
+            self._fam[name], flat = _fam_units(name, cl, c, c, c)
+            order += flat
+        self._lin = {i: _Unit("linear%d" % i, None, c, num_classes, 3, 1, 1) for i in (5, 4, 3, 2)}
+        order += [self._lin[i] for i in (5, 4, 3, 2)]
+        self._conva = _Unit("conva.0", "conva.1", 1024, c, 3, 1, 1)
+        order.append(self._conva)
+        self._cca = [_Unit("long_relation.query_conv", None, c, c // 8, 1), _Unit("long_relation.key_conv", None, c, c // 8, 1),
+                     _Unit("long_relation.value_conv", None, c, c, 1)]
+        order.append(("long_relation.gamma", torch.zeros(1)))          # (a module's own parameters precede its children's in the state_dict)
+        order += self._cca
+        self._lam = {}
+        for i in (4, 3, 2):
+            name = "local_attention_%d" % i
+            self._lam[i] = [_Unit("%s.dconv%d.0" % (name, j), "%s.dconv%d.1" % (name, j), c, c, 3, 2, 0) for j in (1, 2, 3)]
+            for u in self._lam[i]:
+                u.bias, u.depthwise = True, True
+            order += self._lam[i]
+        self._register(order)
+
+    def _fam_block(self, run, U, left, down, right):
+        """FAM.forward (gcpa_gald.py:83-107)."""
+        c = self._c
+        left = run.conv_bn(left, U["conv0"], True)
+        down = run.conv_bn(down, U["conv1"], True)
+        right = run.conv_bn(right, U["conv2"], True)
+        size = (left.t.shape[1], left.t.shape[2])
+        fit = lambda v: v if (v.t.shape[1], v.t.shape[2]) == size else run.resize(v, None, False, size=size)
+        B = left.t.shape[0]
+        cat = gk.new(B, size[0], size[1], 3 * c, left.t.device)
+        z1 = run.mulrelu(run.conv_bias(left, U["conv_l"], out_f32=False), fit(down), out=cat[..., :c])
+        z2 = run.mulrelu(fit(run.conv_bias(down, U["conv_d1"], out_f32=False)), left, out=cat[..., c:2 * c])
+        z3 = run.mulrelu(fit(run.conv_bias(right, U["conv_d2"], out_f32=False)), left, out=cat[..., 2 * c:])
+        return run.conv_bn(run.cat(cat, [z1, z2, z3]), U["conv3"], True)
+
+    def _local_attention(self, run, x, units):
+        """LocalAttenModule.forward (GALDNet.py:143-157); dconv3 is never run."""
+        g = run.dw_bn_relu(run.dw_bn_relu(x, units[0]), units[1])
+        return run.gate(x, run.resize(g, None, True, size=(x.t.shape[1], x.t.shape[2])))
+
+    def _graph(self, run, x, f2, f3, f4, f5):
+        top = run.conv_bn(f5, self._conva, True)
+        gamma = arch.node_at(self, "long_relation").gamma
+        ctx = run.criss_cross(run.criss_cross(top, *self._cca, gamma), *self._cca, gamma)        # the same module twice (gcpa_cc2.py:56-57)
+        o4 = self._fam_block(run, self._fam["fam45"], f4, top, self._local_attention(run, ctx, self._lam[4]))
+        o3 = self._fam_block(run, self._fam["fam34"], f3, o4, self._local_attention(run, ctx, self._lam[3]))
+        o2 = self._fam_block(run, self._fam["fam23"], f2, o3, self._local_attention(run, ctx, self._lam[2]))
+        size = (x.t.shape[1], x.t.shape[2])
+        up = lambda v: run.resize(v, None, False, size=size)                                   # F.interpolate(..., size=x.size()[2:], mode="bilinear")
+        return [up(run.conv_bias(top, self._lin[5])), up(run.conv_bias(o4, self._lin[4])), up(run.conv_bias(o3, self._lin[3])), up(run.conv_bias(o2, self._lin[2]))]
+
+    def forward(self, x, feats):
+        return super().forward(x, *feats)
+
+
+class _NhwcCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits_nchw, labels, ignore_index):
+        nhwc = logits_nchw.permute(0, 2, 3, 1)                                     # the decoder's outputs ARE NHWC memory: a free view
+        if not nhwc.is_contiguous():
+            nhwc = nhwc.contiguous()
+        out, d = gk.gce(nhwc, labels.contiguous(), ignore_index, want_grad=logits_nchw.requires_grad)
+        ctx.d = d
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        d = ctx.d
+        ctx.d = None
+        return (d * gout).permute(0, 3, 1, 2), None, None
+
+
+class CrossEntropyNHWC(nn.Module):
+    """torch.nn.CrossEntropyLoss(ignore_index=255) of gald_trainer.py:107 on the HIP kernel (logits [B,K,H,W] fp32, labels [B,H,W] int64)."""
+
+    def __init__(self, ignore_index=255):
+        super().__init__()
+        self.ignore_index = ignore_index
+
+    def forward(self, logits, target):
+        if not logits.is_cuda:
+            raise _lib.MiError("CrossEntropyNHWC runs on the MI355X only")
+        return _NhwcCEFn.apply(logits.float(), target.long(), self.ignore_index)
+
+
+class GALDTrainer(BaseTrainer):
+    """gald_trainer.py:13-112: Adam for the encoder (BASE_LR) and the decoder (10 x), poly learning rate per iteration, four cross-entropies
+    weighted 1 / 0.8 / 0.6 / 0.4 (out2 .. out5), checkpoint {'epoch', 'iteration', 'encoder', 'decoder', 'optimizer_enc', 'optimizer_dec'} as
+    Gald-<epoch>.pth."""
+
+    def __init__(self, name, cfg, train_loader, local_rank, logger=None):
+        super().__init__(name, cfg, train_loader, local_rank, logger)
+
+    def init_params(self):
+        self.encoder = GCPAEncoder().to(self.device)
+        self.decoder = GCPADecoder(self.cfg.MODEL.NUM_CLASSES).to(self.device)
+        self.encoder.ensure_flat()
+        self.decoder.ensure_flat()
+        self.optimizer_enc = FlatAdam(self.encoder, self.cfg.SOLVER.BASE_LR)
+        self.optimizer_dec = FlatAdam(self.decoder, self.cfg.SOLVER.BASE_LR * 10)
+        self.iteration = 0
+        self.criterion = CrossEntropyNHWC(ignore_index=255)
+
+    def _save_checkpoint(self, epoch, save_path):
+        torch.save({"epoch": epoch, "iteration": self.iteration, "encoder": self.encoder.state_dict(), "decoder": self.decoder.state_dict(),
+                    "optimizer_enc": self.optimizer_enc.state_dict(), "optimizer_dec": self.optimizer_dec.state_dict()}, save_path)
+
+    def _load_checkpoint(self):
+        self.checkpoint = torch.load(self.cfg.resume, map_location=self.device)
+        self.encoder.load_state_dict(self.checkpoint["encoder"])
+        self.decoder.load_state_dict(self.checkpoint["decoder"])
+        for key, opt in (("optimizer_enc", self.optimizer_enc), ("optimizer_dec", self.optimizer_dec)):
+            if key in self.checkpoint:
+                self.logger.info("Loading %s from %s" % (key.replace("_", " "), self.cfg.resume))
+                opt.load_state_dict(self.checkpoint[key])
+                opt._m = None
+                opt._ensure_moments()
+        if "iteration" in self.checkpoint:
+            self.iteration = self.checkpoint["iteration"]
+        if "epoch" in self.checkpoint:
+            self.start_epoch = self.checkpoint["epoch"] + 1
+
+    def train_step(self, src_input, src_label, max_iter):
+        """gald_trainer.py:54-90 for one minibatch; returns (weighted loss, learning rate)."""
+        lr = adjust_learning_rate(self.cfg.SOLVER.LR_METHOD, self.cfg.SOLVER.BASE_LR, self.iteration, max_iter, power=self.cfg.SOLVER.LR_POWER)
+        for g in self.optimizer_enc.param_groups:
+            g["lr"] = lr
+        for g in self.optimizer_dec.param_groups:
+            g["lr"] = lr * 10
+        self.optimizer_enc.zero_grad()
+        self.optimizer_dec.zero_grad()
+        src_input = src_input.to(self.device, non_blocking=True)
+        src_label = src_label.to(self.device, non_blocking=True).long()
+        out5, out4, out3, out2 = self.decoder(src_input, self.encoder(src_input))
+        loss5, loss4, loss3, loss2 = (self.criterion(o, src_label) for o in (out5, out4, out3, out2))
+        loss = loss2 * 1 + loss3 * 0.8 + loss4 * 0.6 + loss5 * 0.4
+        loss.backward()
+        self.optimizer_enc.step()
+        self.optimizer_dec.step()
+        self.iteration += 1
+        return loss.detach(), lr
+
+    def _train_epoch(self, epoch):
+        n = len(self.train_loader)
+        max_iter = self.cfg.SOLVER.EPOCHS * n
+        for i, (src_input, src_label, _) in enumerate(self.train_loader):
+            loss, _ = self.train_step(src_input, src_label, max_iter)
+            self.lr_data.append(self.optimizer_enc.param_groups[0]["lr"])
+            self.loss_data.append(loss.item())
+            if i % 20 == 0 or i == n:
+                self.logger.info("{} Epoch [{:03d}/{:03d}], Step [{:04d}/{:04d}], loss: [{:0.4f}], encode_learning_rate: [{:0.8f}], decode_learning_rate: [{:0.8f}]".format(
+                    datetime.now(), epoch, self.cfg.SOLVER.EPOCHS, i, n, self.loss_data[-1], self.optimizer_enc.param_groups[0]["lr"], self.optimizer_dec.param_groups[0]["lr"]))
+        save_path = self.cfg.OUTPUT_DIR
+        os.makedirs(save_path, exist_ok=True)
+        if epoch % self.cfg.SOLVER.CHECKPOINT_PERIOD == 0:
+            self._save_checkpoint(epoch, os.path.join(save_path, "Gald-%d.pth" % epoch))
+            self.logger.info("[Saving Snapshot:] " + save_path + "Gald-{}.pth".format(epoch))
+
+    def _val_epoch(self, epoch):
+        raise NotImplementedError("the reference's GALDTrainer has no validation epoch")
+
+    def train(self):
+        self.iteration = (self.start_epoch - 1) * len(self.train_loader)
+        self.logger.info("#" * 20 + " Start Gald Training " + "#" * 20)
+        self.encoder.train()
+        self.decoder.train()
+        for epoch in range(self.start_epoch, self.cfg.SOLVER.EPOCHS + 1):
+            self._train_epoch(epoch)
+        if self.local_rank == 0:
+            dump_json(os.path.join(self.cfg.OUTPUT_DIR, "gald_chart_params.json"), {"learning rate": self.lr_data, "loss": self.loss_data})

@@ -53,7 +53,7 @@ def structure_loss(pred, mask):
 # ------------------------------------------------------------------------------------------------ architecture table
 class _Unit:
     """One conv (+ its BatchNorm2d): parameter handles, geometry (kh, kw, sh, sw, ph, pw, dh, dw), packed-operand views."""
-    __slots__ = ("key", "bnkey", "cin", "cout", "geom", "weight", "bn", "bias", "wp", "wpt")
+    __slots__ = ("key", "bnkey", "cin", "cout", "geom", "weight", "bn", "bias", "wp", "wpt", "depthwise")
 
     def __init__(self, key, bnkey, cin, cout, k, stride=1, pad=0, dil=1):
         kh, kw = (k, k) if isinstance(k, int) else k
@@ -61,6 +61,7 @@ class _Unit:
         self.key, self.bnkey, self.cin, self.cout = key, bnkey, cin, cout
         self.geom = (kh, kw, stride, stride, ph, pw, dil, dil)
         self.weight = self.bn = self.bias = self.wp = self.wpt = None
+        self.depthwise = False          # bias: None, or True before registration = "this conv carries a bias" (set by the architecture tables)
 
 
 def _res2net_units(layers=(3, 4, 6, 3), base_width=26, scale=4):
@@ -158,17 +159,20 @@ class _Run:
             taps[name] = v
         return v
 
-    # ---- conv + BatchNorm2d (+ add) (+ ReLU): BasicConv2d of PraNet_Res2Net.py:7-20 and the conv/bn pairs of Res2Net_v1b.py
+    # ---- conv (+ bias) + BatchNorm2d (+ add) (+ ReLU | ReLU6): BasicConv2d of PraNet_Res2Net.py:7-20, the conv/bn pairs of Res2Net_v1b.py,
+    #      ConvLayer of hardnet_68.py:56-80 (relu=6), the conv(bias)-bn-relu stems of FAM (gcpa_gald.py:84-86)
     def conv_bn(self, x, u, relu, add=None, out=None, out_f32=False):
         net, bn = self.net, u.bn
+        act = 2 if relu == 6 else int(bool(relu))
+        bias = None if u.bias is None else u.bias.detach()
         if not self.train:
-            y, _ = gk.gconv(x.t, u.wp, u.cout, u.geom)
+            y, _ = gk.gconv(x.t, u.wp, u.cout, u.geom, bias=bias)
             sc, sh = net._eval_fold(u)
-            return self.var(gk.gbn_apply(y, sc, sh, relu, add=None if add is None else add.t, out=out, out_f32=out_f32), False)
-        y, st = gk.gconv(x.t, u.wp, u.cout, u.geom, stats=True)
+            return self.var(gk.gbn_apply(y, sc, sh, act, add=None if add is None else add.t, out=out, out_f32=out_f32), False)
+        y, st = gk.gconv(x.t, u.wp, u.cout, u.geom, bias=bias, stats=True)
         M = y.shape[0] * y.shape[1] * y.shape[2]
         fin = gk.gbn_finalize(st, u.cout, M, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)      # mean, invstd, scale, shift
-        o = gk.gbn_apply(y, fin[2], fin[3], relu, add=None if add is None else add.t, out=out, out_f32=out_f32)
+        o = gk.gbn_apply(y, fin[2], fin[3], act, add=None if add is None else add.t, out=out, out_f32=out_f32)
         ov = self.var(o)
 
         def back():
@@ -178,20 +182,31 @@ class _Run:
                 return
             mask = None
             if add is not None:
-                if relu:
+                if act:
                     g = gk.gbinary(gk.OP_RELU_MASK, g, o)
                 _acc(add, g, False)
-            elif relu:
+            elif act:
                 mask = o
-            dbeta, dgamma = net._grad_of(bn.bias), net._grad_of(bn.weight)
-            gk.gbn_bwd_sums(g, y, mask, fin[0], fin[1], dbeta, dgamma)
-            dy = gk.gbn_bwd_apply(g, y, mask, fin[0], fin[1], bn.weight, dbeta, dgamma, M)
+            (dbeta, a1), (dgamma, a2) = net._grad_slot(bn.bias), net._grad_slot(bn.weight)
+            if a1 != a2:
+                raise _lib.MiError("BatchNorm weight / bias gradient slots out of step")
+            gk.gbn_bwd_sums(g, y, mask, fin[0], fin[1], dbeta, dgamma, accumulate=a1, relu6=act == 2)
+            if a1:          # a module applied twice (shared parameters): this application's own sums, not the accumulated ones, enter its dy
+                db1, dg1 = torch.empty_like(dbeta), torch.empty_like(dgamma)
+                gk.gbn_bwd_sums(g, y, mask, fin[0], fin[1], db1, dg1, relu6=act == 2)
+            else:
+                db1, dg1 = dbeta, dgamma
+            dy = gk.gbn_bwd_apply(g, y, mask, fin[0], fin[1], bn.weight, db1, dg1, M, relu6=act == 2)
+            if u.bias is not None:
+                slot, acc = net._grad_slot(u.bias)
+                gk.gbn_bwd_sums(dy, None, None, None, None, slot, None, accumulate=acc)
             self._conv_backward(x, u, dy)
         self.record(back)
         return ov
 
     def _conv_backward(self, x, u, dy):
-        gk.gconv_wgrad(dy, x.t, self.net._grad_of(u.weight), u.geom)
+        slot, acc = self.net._grad_slot(u.weight)
+        gk.gconv_wgrad(dy, x.t, slot, u.geom, accumulate=acc)
         if x.needs:
             dx, _ = gk.gconv(dy, u.wpt, u.cin, u.geom, out=_grad_target(x), mode=gk.GATHER_DGRAD, out_hw=(x.t.shape[1], x.t.shape[2]))
             _acc(x, dx, True)
@@ -220,16 +235,20 @@ class _Run:
         self.record(back)
         return ov
 
-    def conv_bias(self, x, u):
-        """nn.Conv2d with bias and no BatchNorm (agg1.conv5, PraNet_Res2Net.py:77): fp32 one-channel output."""
-        o, _ = gk.gconv(x.t, u.wp, u.cout, u.geom, bias=u.bias.detach(), out_f32=True)
+    def conv_bias(self, x, u, out_f32=True):
+        """nn.Conv2d with bias and no BatchNorm: the one-channel / class-logit heads in fp32 (agg1.conv5, PraNet_Res2Net.py:77; linear2..5,
+        gcpa_cc2.py:37-40) or a bf16 feature conv (conv_d1 / conv_d2 / conv_l of FAM, gcpa_gald.py:66-74; the q / k / v projections of ccnet.py:43-51)."""
+        o, _ = gk.gconv(x.t, u.wp, u.cout, u.geom, bias=u.bias.detach(), out_f32=out_f32)
         ov = self.var(o)
 
         def back():
             g = ov.g
             ov.g = None
-            gk.gbn_bwd_sums(g, None, None, None, None, self.net._grad_of(u.bias), None)
-            self._conv_backward(x, u, gk.gbinary(gk.OP_COPY, g, out_dtype=torch.bfloat16))
+            if g is None:
+                return
+            slot, acc = self.net._grad_slot(u.bias)
+            gk.gbn_bwd_sums(g, None, None, None, None, slot, None, accumulate=acc)
+            self._conv_backward(x, u, g if g.dtype == torch.bfloat16 else gk.gbinary(gk.OP_COPY, g, out_dtype=torch.bfloat16))
         self.record(back)
         return ov
 
@@ -275,9 +294,13 @@ class _Run:
         self.record(back)
         return ov
 
-    def resize(self, x, factor, align):
+    def resize(self, x, factor, align, size=None):
+        """F.interpolate(x, scale_factor=factor) or, with `size`, F.interpolate(x, size=size) (factor ignored), mode='bilinear'."""
         H, W = x.t.shape[1], x.t.shape[2]
-        ov = self.var(gk.gresize(x.t, (int(math.floor(H * factor)), int(math.floor(W * factor))), align, factor))
+        if size is not None:
+            factor = None
+        out_hw = tuple(size) if size is not None else (int(math.floor(H * factor)), int(math.floor(W * factor)))
+        ov = self.var(gk.gresize(x.t, out_hw, align, factor))
 
         def back():
             if ov.g is not None:
@@ -435,29 +458,32 @@ class _Engine(nn.Module):
     """Parameter storage and launch preparation shared by the modules of this file: parameters registered under the reference's names,
     one flat fp32 buffer for them and one for their gradients (engine.FlatStore), every conv's bf16 operands packed by ONE table-driven
     launch when a weight changed, BatchNorm buffers as views of one buffer."""
+    RUN = _Run          # the tape class a module's graph is written against (host/gald.py extends it)
 
     def _register(self, order):
+        """order: _Unit objects and (key, tensor) pairs (parameters that belong to no conv: an unused classifier head, a scalar gate), in the
+        reference's registration order (= state_dict order)."""
         self._units = []
         for u in order:
-            if isinstance(u, str):                     # Res2Net's classifier head: in the reference's state_dict, never run by PraNet
-                node = arch.node_at(self, u)
-                node.weight = nn.Parameter(torch.empty(1000, 2048).uniform_(-1, 1) / math.sqrt(2048))
-                node.bias = nn.Parameter(torch.empty(1000).uniform_(-1, 1) / math.sqrt(2048))
+            if isinstance(u, tuple):
+                key, value = u
+                parent, leaf = key.rsplit(".", 1)
+                setattr(arch.node_at(self, parent), leaf, nn.Parameter(value))
                 continue
             node = arch.node_at(self, u.key)
             kh, kw = u.geom[0], u.geom[1]
-            w = torch.empty(u.cout, u.cin, kh, kw)
+            w = torch.empty(u.cout, 1 if u.depthwise else u.cin, kh, kw)
             if u.key.startswith("resnet."):
                 nn.init.kaiming_normal_(w, mode="fan_out", nonlinearity="relu")          # Res2Net_v1b.py:113-115
             else:
                 nn.init.kaiming_uniform_(w, a=math.sqrt(5))                              # nn.Conv2d default
             node.weight = nn.Parameter(w)
             u.weight = node.weight
-            if u.bnkey is None:                        # a conv with bias and no BatchNorm (agg1.conv5)
-                bound = 1.0 / math.sqrt(u.cin * kh * kw)
+            if u.bnkey is None or u.bias is True:      # a conv with bias (agg1.conv5; the FAM / local-attention convs in front of their BatchNorm)
+                bound = 1.0 / math.sqrt((1 if u.depthwise else u.cin) * kh * kw)
                 node.bias = nn.Parameter(torch.empty(u.cout).uniform_(-bound, bound))
                 u.bias = node.bias
-            else:
+            if u.bnkey is not None:
                 parent, leaf = u.bnkey.rsplit(".", 1) if "." in u.bnkey else ("", u.bnkey)
                 (arch.node_at(self, parent) if parent else self).add_module(leaf, nn.BatchNorm2d(u.cout))
                 u.bn = arch.node_at(self, u.bnkey)
@@ -509,7 +535,8 @@ class _Engine(nn.Module):
 
     def _build_pack_plan(self, dev):
         rows, off, blk = [], 0, 0
-        for u in self._units:
+        packed = [u for u in self._units if not u.depthwise]          # depthwise kernels read the fp32 [C,1,3,3] weights directly
+        for u in packed:
             kh, kw = u.geom[0], u.geom[1]
             n = gk.pack_elems(u.cout, u.cin, kh, kw)
             rows.append([u.weight._mi_off, off, off, u.cout, u.cin, kh * kw, blk, 0])
@@ -517,33 +544,52 @@ class _Engine(nn.Module):
             off += n
         self._wp_flat = torch.empty(off, dtype=torch.bfloat16, device=dev)
         self._wpt_flat = torch.empty(off, dtype=torch.bfloat16, device=dev)
-        for u, r in zip(self._units, rows):
+        for u, r in zip(packed, rows):
             n = gk.pack_elems(u.cout, u.cin, u.geom[0], u.geom[1])
             u.wp = self._wp_flat[r[1]:r[1] + n]
             u.wpt = self._wpt_flat[r[2]:r[2] + n]
         self._pack_blocks = blk
+        self._pack_n = len(packed)
         self._pack_table = torch.tensor(rows, dtype=torch.int64, device=dev)
 
     def _prepare(self):
         st = self.ensure_flat()
         sig = (st.generation, sum(u.weight._version for u in self._units), st.data.data_ptr())
         if sig != self._pack_sig:
-            gk.gconv_pack_multi(st.data, self._wp_flat, self._wpt_flat, self._pack_table, len(self._units), self._pack_blocks)
+            gk.gconv_pack_multi(st.data, self._wp_flat, self._wpt_flat, self._pack_table, self._pack_n, self._pack_blocks)
             self._pack_sig = sig
         return st
 
-    def _grad_of(self, p):
+    def _grad_slot(self, p):
+        """(where d loss / d p is written, whether to accumulate: True from the second write of a backward pass on - shared parameters)."""
         st = self._store
+        acc = id(p) in st.written
         st.written.add(id(p))
         g = st.grad[p._mi_off:p._mi_off + p.numel()].view_as(p)
         if p.grad is None or p.grad.data_ptr() != g.data_ptr():      # a zero_grad(set_to_none=True) dropped the view
             p.grad = g
-        return g
+        return g, acc
+
+    def _grad_of(self, p):
+        return self._grad_slot(p)[0]
+
+    def zero_grad(self, set_to_none=True):
+        """Gradient slots are overwritten by the next backward pass: forget which ones were written instead of clearing 100+ MB."""
+        if self._store is not None:
+            self._store.written.clear()
+        else:
+            super().zero_grad(set_to_none)
 
     def _ones(self, c):
         t = self._ones_cache.get(c)
         if t is None or t.device != self._store.data.device:
             t = self._ones_cache[c] = torch.ones(c, dtype=torch.float32, device=self._store.data.device)
+        return t
+
+    def _zeros(self, c):
+        t = self._ones_cache.get(-c)
+        if t is None or t.device != self._store.data.device:
+            t = self._ones_cache[-c] = torch.zeros(c, dtype=torch.float32, device=self._store.data.device)
         return t
 
     def _eval_fold(self, u):
@@ -564,7 +610,7 @@ class _Engine(nn.Module):
                 raise _lib.MiError("%s runs on the MI355X only (got a %s tensor); the CPU restatement is oracle/ref_pranet.py, test infrastructure"
                                    % (type(self).__name__, x.device))
         self._prepare()
-        run = _Run(self, self.training, rec)
+        run = self.RUN(self, self.training, rec)
         ins = [run.var(x.detach().permute(0, 2, 3, 1).to(torch.bfloat16).contiguous(), need) for x, need in zip(xs, in_needs)]      # NHWC bf16
         outs = self._graph(run, *ins)
         if self.training:
@@ -668,8 +714,8 @@ class PraNet(_Engine):
         trunk, self._blocks = _res2net_units()
         self._stem = trunk[:3]
         self._rfb = {}
-        order = list(trunk)
-        order.append("resnet.fc")
+        order = list(trunk)          # then Res2Net's classifier head: in the reference's state_dict, never run by PraNet
+        order += [("resnet.fc.weight", torch.empty(1000, 2048).uniform_(-1, 1) / math.sqrt(2048)), ("resnet.fc.bias", torch.empty(1000).uniform_(-1, 1) / math.sqrt(2048))]
         for name, cin in (("rfb2_1", 512), ("rfb3_1", 1024), ("rfb4_1", 2048)):
             self._rfb[name], flat = _rfb_units(name, cin, c)
             order += flat

@@ -196,3 +196,80 @@ def test_local_attention_module_composed_from_kernels_vs_reference_golden(gk):
     e_norm = max(abs(float(grads[k].double().norm()) / float(rg_[k].double().norm()) - 1) for k in live)
     print("\n[lam] out %.2e  dx %.2e  |grad| %.2e  1-cos %.2e" % (e_out, e_dx, e_norm, worst))
     assert e_out < 1.5e-2 and e_dx < 6e-2 and e_norm < 0.1 and worst < 2e-2
+
+
+# ------------------------------------------------------------------------------------------------ the whole network on the HIP engine
+def _deviation(got, want):
+    o, pg = got
+    o0, pg0 = want
+    gmax = max(np.linalg.norm(v) for v in pg0.values())
+    big = [k for k, v in pg0.items() if np.linalg.norm(v) > 1e-3 * gmax]
+    return dict(out=max(rel2(a, b) for a, b in zip(o, o0)), norm=max(abs(np.linalg.norm(pg[k]) / np.linalg.norm(pg0[k]) - 1) for k in big),
+                cos=max(1 - _cos(pg[k], pg0[k]) for k in big), cos_median=float(np.median([1 - _cos(pg[k], pg0[k]) for k in big])))
+
+
+def test_gald_whole_net_224_vs_reference_golden(golden_dir):
+    """GCPAEncoder (HarDNet-68) + GCPADecoder on the HIP engine at 2 x 3 x 224 x 224 against the reference's own run (g13_gald_224): state_dict
+    keys, feature shapes, the four class-logit outputs, the four cross-entropies and their weighted sum (gald_trainer.py:66-84), every
+    parameter gradient (norm and direction against the oracle's tensors) - with the reference's own bf16-autocast run as the yardstick for
+    the bf16 regime (tests/test_gpu_pranet.py explains why): the engine may deviate from the fp32 reference at most 2x as far as that run does."""
+    import json
+    import os
+    from oracle import ref_gald as rg
+    from rnd_semantic_segmentation_amd.host import gald
+    keys = json.load(open(os.path.join(golden_dir, "g8_gald_keys.json")))
+    enc, dec = gald.GCPAEncoder(), gald.GCPADecoder()
+    renc, rdec = rg.GCPAEncoder(), rg.GCPADecoder()
+    assert list(enc.state_dict().keys()) == keys["encoder"] and list(dec.state_dict().keys()) == keys["decoder"]
+    for m, r, pre in ((enc, renc, "gald.enc."), (dec, rdec, "gald.dec.")):
+        synth.load_formula_weights(m, prefix=pre)
+        synth.load_formula_weights(r, prefix=pre)
+        m.cuda().train()
+        r.train()
+    g = _cases.load("g13_gald_224")
+    x = torch.from_numpy(synth.synth_image(2, 224, 224, seed=51))
+    lab = torch.from_numpy(synth.synth_label(2, 224, 224, 19, seed=51)).long()
+    # engine
+    crit = gald.CrossEntropyNHWC(255)
+    feats = enc(x.cuda())
+    assert [list(f.shape) for f in feats] == g["feat_shapes"].tolist()
+    outs = dec(x.cuda(), feats)
+    ls = [crit(o, lab.cuda()) for o in outs]
+    (ls[3] * 1 + ls[2] * 0.8 + ls[1] * 0.6 + ls[0] * 0.4).backward()
+    torch.cuda.synchronize()
+    ours = ([o.detach().float().cpu().numpy() for o in outs],
+            {pre + k: p.grad.detach().cpu().numpy().copy() for pre, m in (("e.", enc), ("d.", dec)) for k, p in m.named_parameters() if p.grad is not None})
+    e_loss = float(np.abs(np.array([float(l) for l in ls]) / g["losses"] - 1).max())
+
+    def oracle(autocast):
+        for m in (renc, rdec):
+            m.zero_grad()
+        sd = [{k: v.clone() for k, v in m.state_dict().items()} for m in (renc, rdec)]
+        if autocast:
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                o = rdec(x, renc(x))
+        else:
+            o = rdec(x, renc(x))
+        o = [t.float() for t in o]
+        losses, loss = rg.gald_losses(o, lab)
+        loss.backward()
+        res = ([t.detach().numpy() for t in o], {pre + k: p.grad.numpy().copy() for pre, m in (("e.", renc), ("d.", rdec)) for k, p in m.named_parameters() if p.grad is not None})
+        for m, s in zip((renc, rdec), sd):
+            m.load_state_dict(s)
+        return res, [float(l) for l in losses]
+    want, l32 = oracle(False)
+    auto, l16 = oracle(True)
+    assert np.allclose(l32, g["losses"], rtol=2e-5)                                      # the oracle's fp32 run IS the reference's
+    for i in range(4):
+        assert rel(want[0][i][:, :, ::16, ::16], g["out%d_crop" % i]) < 1e-4
+    y_loss = float(np.abs(np.array(l16) / g["losses"] - 1).max())
+    unused = [k for k in want[1] if k not in ours[1]]
+    assert not unused, unused[:5]
+    dev, yard = _deviation(ours, want), _deviation(auto, want)
+    print("\n[gald 224] losses: engine %.2e, autocast %.2e\n[gald 224] engine   out %.2e |grad| %.2e 1-cos %.2e (median %.2e)\n[gald 224] autocast out %.2e |grad| %.2e 1-cos %.2e (median %.2e)" % (
+        e_loss, y_loss, dev["out"], dev["norm"], dev["cos"], dev["cos_median"], yard["out"], yard["norm"], yard["cos"], yard["cos_median"]))
+    assert e_loss <= max(2 * y_loss, 2e-2)
+    for k, floor in (("out", 2e-2), ("norm", 3e-2), ("cos", 2e-3), ("cos_median", 1e-3)):
+        assert dev[k] <= max(2 * yard[k], floor), (k, dev[k], yard[k])
+    # dconv3 of the local attention modules and the ImageNet head are never run: no gradient in either implementation
+    assert float(dec.local_attention_4.dconv3._modules["0"].weight.grad.abs().max() if dec.local_attention_4.dconv3._modules["0"].weight.grad is not None else 0.0) == 0.0

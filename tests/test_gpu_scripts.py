@@ -164,3 +164,18 @@ def test_pranet_train_src_then_test_py_roundtrip(tmp_path):
              "INPUT.INPUT_SIZE_TEST", "(96, 96)"], {"MI_SYNTH_LEN": "3"})
     assert r.returncode == 0, r.stderr[-3000:]
     assert "Micro metric, val result: mIoU/mF1" in r.stderr + r.stdout
+
+
+def test_gald_train_src_roundtrip(tmp_path):
+    """`train_src.py --model gald -cfg configs/gald_src.yaml` (reference train_src.py:33-34, the model run.sh launches): HarDNet-68 + GCPA decoder
+    trained on synthetic crops, poly learning rate, Gald-<epoch>.pth with the reference's checkpoint keys, gald_chart_params.json."""
+    out = str(tmp_path / "gald")
+    r = run(["train_src.py", "--model", "gald", "-cfg", "configs/gald_src.yaml", "OUTPUT_DIR", out, "SOLVER.EPOCHS", "1", "SOLVER.CHECKPOINT_PERIOD", "1",
+             "SOLVER.BATCH_SIZE", "2", "INPUT.SOURCE_INPUT_SIZE_TRAIN", "(256, 224)"], {"MI_SYNTH_LEN": "6"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    chart = json.load(open(os.path.join(out, "gald_chart_params.json")))
+    assert len(chart["loss"]) == 3 and all(0 < v < 20 for v in chart["loss"]) and chart["learning rate"][0] == 1e-4
+    ck = torch.load(os.path.join(out, "Gald-1.pth"), map_location="cpu")
+    assert set(ck) == {"epoch", "iteration", "encoder", "decoder", "optimizer_enc", "optimizer_dec"} and ck["iteration"] == 3
+    assert len(ck["encoder"]) == 404 and len(ck["decoder"]) == 186
+    assert int(ck["encoder"]["hardnet.base.0.norm.num_batches_tracked"]) == 3

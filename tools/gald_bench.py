@@ -1,0 +1,55 @@
+"""GALD (HarDNet-68 + GCPA decoder; configs/gald_src.yaml: batch 6, 1280 x 720 crops) training-step throughput on one MI355X: encoder + decoder forward,
+four cross-entropies, backward, both Adam steps.  `python tools/gald_bench.py [--batch 6] [--height 720] [--width 1280] [--steps 10]`."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rnd_semantic_segmentation_amd.host import gald, pranet, synth  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=6)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    a = ap.parse_args()
+    torch.manual_seed(0)
+    enc, dec = gald.GCPAEncoder().cuda().train(), gald.GCPADecoder().cuda().train()
+    enc.ensure_flat()
+    dec.ensure_flat()
+    oe, od = pranet.FlatAdam(enc, 1e-4), pranet.FlatAdam(dec, 1e-3)
+    crit = gald.CrossEntropyNHWC(255)
+    x = torch.from_numpy(synth.synth_image(a.batch, a.height, a.width, seed=9)).cuda()
+    lab = torch.from_numpy(synth.synth_label(a.batch, a.height, a.width, 19, seed=9)).cuda().long()
+
+    def step():
+        oe.zero_grad()
+        od.zero_grad()
+        o5, o4, o3, o2 = dec(x, enc(x))
+        loss = crit(o2, lab) * 1 + crit(o3, lab) * 0.8 + crit(o4, lab) * 0.6 + crit(o5, lab) * 0.4
+        loss.backward()
+        oe.step()
+        od.step()
+        return loss
+
+    for _ in range(a.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    print(json.dumps({"metric": "GALD train images/s", "value": round(a.batch / dt, 2), "ms_per_step": round(dt * 1e3, 2), "batch": a.batch, "size": [a.height, a.width],
+                      "loss": round(float(loss), 4), "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}))
+
+
+if __name__ == "__main__":
+    main()

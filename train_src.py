@@ -24,8 +24,11 @@ def main(name, cfg, local_rank):
     elif name == "pranet":                                   # reference train_src.py:29-30
         from core.trainers.pranet_trainer import PraNetTrainer
         PraNetTrainer(name, cfg, loader, local_rank).train()
+    elif name == "gald":                                     # reference train_src.py:33-34 (what run.sh launches)
+        from core.trainers.gald_trainer import GALDTrainer
+        GALDTrainer(name, cfg, loader, local_rank).train()
     else:
-        raise NotImplementedError("model %r: 'aspp' (DeepLabV2-ResNet + ASPP) and 'pranet' are on the MI355X engine" % name)
+        raise NotImplementedError("model %r: 'aspp' (DeepLabV2-ResNet + ASPP), 'pranet' and 'gald' are on the MI355X engine" % name)
 
 
 if __name__ == "__main__":
