@@ -505,24 +505,45 @@ __global__ __launch_bounds__(256) void gce_final_kernel(const float* partial, in
         loss_out[3] = 0.f;
     }
 }
-// dlogits = (softmax - onehot) * valid / n_valid * grad_scale, n_valid read from loss_out[1] on the device
+// dlogits = (softmax - onehot) * valid / n_valid * grad_scale, n_valid read from loss_out[1] on the device.  A block owns 256 pixels: each
+// thread reduces its pixel's K logits to (max, 1 / sum), then the block walks the 256 x K elements linearly (coalesced reads and writes when
+// the rows are dense).
 __global__ __launch_bounds__(256) void gce_bwd_kernel(const float* logits, long ld, const long* labels, int ignore, long M, int K, const float* loss_out, float grad_scale,
                                                       float* dlogits, long ldd) {
+    __shared__ float smx[256], sinv[256];
+    __shared__ int slab[256];
     const float inv = loss_out[1] > 0.f ? grad_scale / loss_out[1] : 0.f;
-    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
-        const long y = labels[m];
-        float* d = dlogits + m * ldd;
-        if (y == ignore || y < 0 || y >= K) {
-            for (int k = 0; k < K; ++k) d[k] = 0.f;
-            continue;
+    const long m0 = (long)blockIdx.x * 256;
+    {
+        const long m = m0 + threadIdx.x;
+        float mx = 0.f, r = 0.f;
+        int y = -1;
+        if (m < M) {
+            const long yy = labels[m];
+            if (yy != ignore && yy >= 0 && yy < K) {
+                y = (int)yy;
+                const float* z = logits + m * ld;
+                mx = z[0];
+                for (int k = 1; k < K; ++k) mx = fmaxf(mx, z[k]);
+                float se = 0.f;
+                for (int k = 0; k < K; ++k) se += __expf(z[k] - mx);
+                r = inv / se;
+            }
         }
-        const float* z = logits + m * ld;
-        float mx = z[0];
-        for (int k = 1; k < K; ++k) mx = fmaxf(mx, z[k]);
-        float se = 0.f;
-        for (int k = 0; k < K; ++k) se += __expf(z[k] - mx);
-        const float r = inv / se;
-        for (int k = 0; k < K; ++k) d[k] = __expf(z[k] - mx) * r - (k == y ? inv : 0.f);
+        smx[threadIdx.x] = mx;
+        sinv[threadIdx.x] = r;
+        slab[threadIdx.x] = y;
+    }
+    __syncthreads();
+    const int n = 256 * K;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int p = e / K, k = e - p * K;
+        const long m = m0 + p;
+        if (m >= M) break;
+        const int y = slab[p];
+        float d = 0.f;
+        if (y >= 0) d = __expf(logits[m * ld + k] - smx[p]) * sinv[p] - (k == y ? inv : 0.f);
+        dlogits[m * ldd + k] = d;
     }
 }
 
@@ -670,6 +691,58 @@ __global__ __launch_bounds__(256) void gresize_bwd_wave_kernel(const T* dout, T*
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     if (lane == 0) stf(dx + m * q.ldx + c, s);
+}
+
+// The same sum for feature maps (C >= 8): one wave per source PIXEL, lanes over its channels (coalesced reads of the destination pixels'
+// channel vectors), every lane walks the candidate rectangle in ascending order - no cross-lane reduction at all.
+template <typename T>
+__global__ __launch_bounds__(256) void gresize_bwd_pix_kernel(const T* dout, T* dx, ResizeP q) {
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= (long)q.B * q.H * q.W) return;
+    const int iw = (int)(m % q.W);
+    const long t = m / q.W;
+    const int ih = (int)(t % q.H), b = (int)(t / q.H);
+    auto range = [&](int i, float scale, int out, int& lo, int& hi) {
+        if (scale <= 0.f) {
+            lo = 0;
+            hi = out - 1;
+            return;
+        }
+        const float off = q.align ? 0.f : 0.5f;
+        lo = (int)floorf(((float)(i - 1) + off) / scale - off) - 2;
+        hi = (int)ceilf(((float)(i + 1) + off) / scale - off) + 2;
+        if (lo < 0) lo = 0;
+        if (hi > out - 1) hi = out - 1;
+    };
+    int hlo, hhi, wlo, whi;
+    range(ih, q.sh, q.Ho, hlo, hhi);
+    range(iw, q.sw, q.Wo, wlo, whi);
+    for (int c = lane; c < q.C; c += 64) {
+        float s = 0.f;
+        for (int oh = hlo; oh <= hhi; ++oh) {
+            int h0, hp;
+            float hl;
+            rs_src(oh, q.sh, q.align, q.H, h0, hp, hl);
+            float wh = 0.f;
+            if (h0 == ih) wh += 1.f - hl;
+            if (h0 + hp == ih) wh += hl;
+            if (wh == 0.f) continue;
+            float rsum = 0.f;
+            const T* drow = dout + (((long)b * q.Ho + oh) * q.Wo) * q.ldo + c;
+            for (int ow = wlo; ow <= whi; ++ow) {
+                int w0, wp;
+                float wl;
+                rs_src(ow, q.sw, q.align, q.W, w0, wp, wl);
+                float ww = 0.f;
+                if (w0 == iw) ww += 1.f - wl;
+                if (w0 + wp == iw) ww += wl;
+                if (ww != 0.f) rsum += ww * ldf(drow + (long)ow * q.ldo);
+            }
+            s += wh * rsum;
+        }
+        stf(dx + m * q.ldx + c, s);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ reverse attention (PraNet_Res2Net.py:131-133)
@@ -878,7 +951,7 @@ int mi_gce(const float* logits, long ld, const int64_t* labels, long M, int K, i
     hipLaunchKernelGGL(gce_final_kernel, dim3(1), dim3(256), 0, s, (const float*)workspace, blocks, loss_out);
     MI_CHECK_LAUNCH("gce_final_kernel");
     if (dlogits) {
-        hipLaunchKernelGGL(gce_bwd_kernel, dim3(grid_for(M)), dim3(256), 0, s, logits, ld, (const long*)labels, ignore_index, M, K, (const float*)loss_out, grad_scale, dlogits, ldd);
+        hipLaunchKernelGGL(gce_bwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, logits, ld, (const long*)labels, ignore_index, M, K, (const float*)loss_out, grad_scale, dlogits, ldd);
         MI_CHECK_LAUNCH("gce_bwd_kernel");
     }
     return MI_OK;
@@ -897,7 +970,11 @@ int mi_gresize(const void* x, long ldx, void* out, long ldo, int f32, int B, int
     } else {       // x = dx (written), out = dout (read)
         const long nsrc = (long)B * H * W * C;
         const float mag = (scale_h > 0.f ? 1.f / scale_h : (float)Ho) * (scale_w > 0.f ? 1.f / scale_w : (float)Wo);
-        if (mag >= 16.f && nsrc <= (1L << 22)) {         // many candidates per source element, few source elements: one wave each
+        if (C >= 8 && mag >= 4.f) {                      // feature maps / class logits: one wave per source pixel, lanes over the channels
+            const dim3 grid((unsigned)(((long)B * H * W + 3) / 4));
+            if (f32) hipLaunchKernelGGL((gresize_bwd_pix_kernel<float>), grid, dim3(256), 0, s, (const float*)out, (float*)const_cast<void*>(x), q);
+            else hipLaunchKernelGGL((gresize_bwd_pix_kernel<__bf16>), grid, dim3(256), 0, s, (const __bf16*)out, (__bf16*)const_cast<void*>(x), q);
+        } else if (mag >= 16.f && nsrc <= (1L << 22)) {  // many candidates per source element, few source elements: one wave each
             const dim3 grid((unsigned)((nsrc + 3) / 4));
             if (f32) hipLaunchKernelGGL((gresize_bwd_wave_kernel<float>), grid, dim3(256), 0, s, (const float*)out, (float*)const_cast<void*>(x), q);
             else hipLaunchKernelGGL((gresize_bwd_wave_kernel<__bf16>), grid, dim3(256), 0, s, (const __bf16*)out, (__bf16*)const_cast<void*>(x), q);

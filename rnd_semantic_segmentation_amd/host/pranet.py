@@ -134,6 +134,35 @@ def _acc(v, t, own):
         v.g, v.own = gk.gbinary(gk.OP_ADD, v.g, t), True
 
 
+def _mfma_tile_ok(u, x, out=None, out_f32=False):
+    """A conv the implicit-GEMM kernels of the DeepLab path (csrc/igemm_nt.hip / igemm_pp.hip / igemm_tn.hip: 128 .. 320-row MFMA tiles, LDS-DMA
+    staging, 4x the throughput of the general kernel on large shapes) can take: square 1x1 / 3x3 taps with one stride / padding / dilation,
+    64-channel multiples on both sides (then the general kernel's padded packs ARE those kernels' operand layouts), contiguous NHWC operands,
+    enough pixels to fill the chip."""
+    kh, kw, sh, sw, ph, pw, dh, dw = u.geom
+    if out_f32 or u.depthwise or kh != kw or kh not in (1, 3) or sh != sw or ph != pw or dh != dw or u.cin % 64 or u.cout % 64:
+        return False
+    if not x.is_contiguous() or (out is not None and not out.is_contiguous()):
+        return False
+    return x.shape[0] * x.shape[1] * x.shape[2] >= 16384
+
+
+def _conv_forward(x, u, bias, stats, out=None, out_f32=False, net=None):
+    """(y, statistics partials or None): the general kernel, or the MFMA-tile kernels + one pass of column sums for the BatchNorm statistics."""
+    if not _mfma_tile_ok(u, x, out, out_f32):
+        return gk.gconv(x, u.wp, u.cout, u.geom, out=out, bias=bias, stats=stats, out_f32=out_f32)
+    k, s, p, d = u.geom[0], u.geom[2], u.geom[4], u.geom[6]
+    hw = gk.conv_out_hw(x.shape[1], x.shape[2], *u.geom)
+    wp = u.wp.view(k * k, u.cout, u.cin)
+    y = K.conv_gemm(x, wp, hw, k, s, p, d, K.GATHER_FWD, scale=None if bias is None else net._ones(u.cout), bias=bias, out=out)
+    st = None
+    if stats:                       # sum y and sum y^2 in one pass: the backward-sums kernel with g = y, mean = 0, invstd = 1
+        st = torch.empty((2, u.cout), dtype=torch.float32, device=x.device)
+        gk.gbn_bwd_sums(y, y, None, net._zeros(u.cout), net._ones(u.cout), st[0], st[1])
+        st = st.view(-1)
+    return y, st
+
+
 def _grad_target(v):
     """Where a kernel may write d loss / d v directly: the assembly slot if there is one and nothing has been written yet."""
     return v.want if (v.want is not None and v.g is None) else None
@@ -166,10 +195,10 @@ class _Run:
         act = 2 if relu == 6 else int(bool(relu))
         bias = None if u.bias is None else u.bias.detach()
         if not self.train:
-            y, _ = gk.gconv(x.t, u.wp, u.cout, u.geom, bias=bias)
+            y, _ = _conv_forward(x.t, u, bias, False, net=net)
             sc, sh = net._eval_fold(u)
             return self.var(gk.gbn_apply(y, sc, sh, act, add=None if add is None else add.t, out=out, out_f32=out_f32), False)
-        y, st = gk.gconv(x.t, u.wp, u.cout, u.geom, bias=bias, stats=True)
+        y, st = _conv_forward(x.t, u, bias, True, net=net)
         M = y.shape[0] * y.shape[1] * y.shape[2]
         fin = gk.gbn_finalize(st, u.cout, M, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)      # mean, invstd, scale, shift
         o = gk.gbn_apply(y, fin[2], fin[3], act, add=None if add is None else add.t, out=out, out_f32=out_f32)
@@ -206,6 +235,15 @@ class _Run:
 
     def _conv_backward(self, x, u, dy):
         slot, acc = self.net._grad_slot(u.weight)
+        if _mfma_tile_ok(u, x.t) and dy.is_contiguous():
+            k, s, p, d = u.geom[0], u.geom[2], u.geom[4], u.geom[6]
+            K.conv_wgrad(dy, x.t, slot, k, s, p, d, accumulate=acc)
+            if x.needs:
+                tgt = _grad_target(x)
+                dx = K.conv_gemm(dy, u.wpt.view(k * k, u.cin, u.cout), (x.t.shape[1], x.t.shape[2]), k, s, p, d, K.GATHER_DGRAD,
+                                 out=tgt if (tgt is not None and tgt.is_contiguous()) else None)
+                _acc(x, dx, True)
+            return
         gk.gconv_wgrad(dy, x.t, slot, u.geom, accumulate=acc)
         if x.needs:
             dx, _ = gk.gconv(dy, u.wpt, u.cin, u.geom, out=_grad_target(x), mode=gk.GATHER_DGRAD, out_hw=(x.t.shape[1], x.t.shape[2]))
@@ -238,7 +276,7 @@ class _Run:
     def conv_bias(self, x, u, out_f32=True):
         """nn.Conv2d with bias and no BatchNorm: the one-channel / class-logit heads in fp32 (agg1.conv5, PraNet_Res2Net.py:77; linear2..5,
         gcpa_cc2.py:37-40) or a bf16 feature conv (conv_d1 / conv_d2 / conv_l of FAM, gcpa_gald.py:66-74; the q / k / v projections of ccnet.py:43-51)."""
-        o, _ = gk.gconv(x.t, u.wp, u.cout, u.geom, bias=u.bias.detach(), out_f32=out_f32)
+        o, _ = _conv_forward(x.t, u, u.bias.detach(), False, out_f32=out_f32, net=self.net)
         ov = self.var(o)
 
         def back():
