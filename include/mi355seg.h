@@ -166,6 +166,13 @@ int mi_upsample_ce(const float* low, const int64_t* labels, float* loss_out /*[4
                    int B, int h, int w, int K, int H, int W, int ignore_index, float grad_scale,
                    void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same with either bilinear convention: align_corners != 0 as above; 0: F.interpolate(..., size=, mode="bilinear") at its default
+ * align_corners=False (source index max(in / out * (dst + 0.5) - 0.5, 0)) - the four deep-supervision heads of the GALD path
+ * (core/models/classifiers/gcpacc/gcpa_cc2.py:78-81 + core/trainers/gald_trainer.py:66-84). */
+int mi_upsample_ce_ex(const float* low, const int64_t* labels, float* loss_out /*[4]*/, float* dlow,
+                      int B, int h, int w, int K, int H, int W, int ignore_index, float grad_scale, int align_corners,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- inference tail: upsample to label size + softmax over classes (utility.py:185-186) ---------
  * probs [B][K][H][W] fp32; pred (optional, may be NULL) [B][H][W] uint8 argmax (first max wins). */
 int mi_upsample_softmax(const float* low, float* probs, uint8_t* pred, int B, int h, int w, int K, int H, int W, void* stream);

@@ -41,6 +41,7 @@ SIGNATURES = {
     "mi_softmax_ce_bwd": (I, [P, P, P, P, I, I, I, I, I, F, P]),
     "mi_upsample_ce_workspace": (Z, [I] * 6),
     "mi_upsample_ce": (I, [P, P, P, P] + [I] * 7 + [F, P, Z, P]),
+    "mi_upsample_ce_ex": (I, [P, P, P, P] + [I] * 7 + [F, I, P, Z, P]),
     "mi_upsample_softmax": (I, [P, P, P] + [I] * 6 + [P]),
     "mi_stem_pool_fwd": (I, [P, P, P, P, P] + [I] * 6 + [P]),
     "mi_stem_pool_bwd": (I, [P, P, P, P] + [I] * 6 + [P]),

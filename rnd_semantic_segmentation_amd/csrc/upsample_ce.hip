@@ -12,11 +12,15 @@ namespace {
 
 constexpr int KMAX = 32;   // classes held in registers
 
-struct Axis {              // align_corners source index exactly as ATen computes it in fp32
-    float scale;
+struct Axis {              // source index exactly as ATen computes it in fp32: align_corners (off = 0): scale * dst; otherwise (off = 0.5):
+    float scale, off;      // max(scale * (dst + 0.5) - 0.5, 0)  (adding / subtracting 0.0f is exact: the align_corners bits are unchanged)
     int n_in, n_out;
+    __device__ __forceinline__ float srcf(int dst) const {
+        const float f = scale * ((float)dst + off) - off;
+        return f < 0.f ? 0.f : f;
+    }
     __device__ __forceinline__ void src(int dst, int& i0, int& i1, float& lam) const {
-        const float f = scale * (float)dst;
+        const float f = srcf(dst);
         i0 = (int)f;
         if (i0 > n_in - 1) i0 = n_in - 1;
         i1 = (i0 < n_in - 1) ? i0 + 1 : i0;
@@ -31,7 +35,7 @@ struct Axis {              // align_corners source index exactly as ATen compute
         if (d < 0) d = 0;
         if (d > n_out) d = n_out;
         while (d < n_out) {
-            int i0 = (int)(scale * (float)d);
+            int i0 = (int)srcf(d);
             if (i0 > n_in - 1) i0 = n_in - 1;
             if (i0 >= c) break;
             ++d;
@@ -40,11 +44,12 @@ struct Axis {              // align_corners source index exactly as ATen compute
     }
 };
 
-inline Axis make_axis(int n_in, int n_out) {
+inline Axis make_axis(int n_in, int n_out, int align_corners = 1) {
     Axis a;
     a.n_in = n_in;
     a.n_out = n_out;
-    a.scale = (n_out > 1) ? (float)(n_in - 1) / (float)(n_out - 1) : 0.f;
+    a.off = align_corners ? 0.f : 0.5f;
+    a.scale = align_corners ? ((n_out > 1) ? (float)(n_in - 1) / (float)(n_out - 1) : 0.f) : (float)n_in / (float)n_out;      // (a size was given: in / out)
     return a;
 }
 
@@ -416,14 +421,22 @@ extern "C" size_t mi_upsample_ce_workspace(int B, int h, int w, int K, int H, in
     return ((partial + 255) & ~(size_t)255) + tmp;
 }
 
+extern "C" int mi_upsample_ce_ex(const float* low, const int64_t* labels, float* loss_out, float* dlow, int B, int h, int w, int K, int H, int W,
+                                 int ignore_index, float grad_scale, int align_corners, void* workspace, size_t workspace_bytes, void* stream);
+
 extern "C" int mi_upsample_ce(const float* low, const int64_t* labels, float* loss_out, float* dlow, int B, int h, int w, int K, int H, int W,
                               int ignore_index, float grad_scale, void* workspace, size_t workspace_bytes, void* stream) {
+    return mi_upsample_ce_ex(low, labels, loss_out, dlow, B, h, w, K, H, W, ignore_index, grad_scale, 1, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mi_upsample_ce_ex(const float* low, const int64_t* labels, float* loss_out, float* dlow, int B, int h, int w, int K, int H, int W,
+                                 int ignore_index, float grad_scale, int align_corners, void* workspace, size_t workspace_bytes, void* stream) {
     MI_REQUIRE(low && labels && loss_out && workspace, "mi_upsample_ce: null operand");
     MI_REQUIRE(B > 0 && h > 0 && w > 0 && H > 0 && W > 0 && K > 0 && K <= KMAX, "mi_upsample_ce: bad dimension (K <= 32)");
     MI_REQUIRE(H >= h && W >= w, "mi_upsample_ce: only upsampling (H >= h, W >= w) is supported");
     MI_REQUIRE(H <= 65535 && B <= 65535, "mi_upsample_ce: grid dimension overflow");
     if (workspace_bytes < mi_upsample_ce_workspace(B, h, w, K, H, W)) return mi_set_error(MI_ENOMEM, "mi_upsample_ce: workspace too small");
-    const Axis ay = make_axis(h, H), ax = make_axis(w, W);
+    const Axis ay = make_axis(h, H, align_corners), ax = make_axis(w, W, align_corners);
     const int tiles = (w + JT - 1) / JT;
     float* partial = (float*)workspace;
     const size_t poff = (((size_t)B * H * tiles * 2 * sizeof(float)) + 255) & ~(size_t)255;

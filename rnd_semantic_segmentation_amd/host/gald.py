@@ -22,6 +22,7 @@ import torch.nn as nn
 
 from .. import _lib
 from .. import gk
+from .. import kernels as K
 from . import arch
 from .metrics import adjust_learning_rate, dump_json
 from .plugin import BaseTrainer
@@ -96,6 +97,19 @@ class _GaldRun(_Run):
             gm = gk.gbinary(gk.OP_RELU_MASK, g, o)
             _acc(a, gk.gbinary(gk.OP_MUL, gm, b.t), True)
             _acc(b, gk.gbinary(gk.OP_MUL, gm, a.t), True)
+        self.record(back)
+        return ov
+
+    def ce_head(self, low, labels, ignore_index):
+        """criterion(F.interpolate(low, size=labels.shape[-2:], mode="bilinear"), labels) (gcpa_cc2.py:78-81 + gald_trainer.py:76-79) fused: the
+        full-resolution logits are never written; d loss / d low comes out of the same pass."""
+        loss_out, dlow = K.upsample_ce(low.t, labels, want_grad=self.rec, ignore_index=ignore_index, align_corners=False)
+        ov = self.var(loss_out[0].clone())
+
+        def back():
+            if ov.g is not None:
+                _acc(low, dlow * ov.g, True)
+                ov.g = None
         self.record(back)
         return ov
 
@@ -292,12 +306,24 @@ class GCPADecoder(_Engine):
         o4 = self._fam_block(run, self._fam["fam45"], f4, top, self._local_attention(run, ctx, self._lam[4]))
         o3 = self._fam_block(run, self._fam["fam34"], f3, o4, self._local_attention(run, ctx, self._lam[3]))
         o2 = self._fam_block(run, self._fam["fam23"], f2, o3, self._local_attention(run, ctx, self._lam[2]))
+        lows = [run.conv_bias(top, self._lin[5]), run.conv_bias(o4, self._lin[4]), run.conv_bias(o3, self._lin[3]), run.conv_bias(o2, self._lin[2])]
+        labels = self.__dict__.get("_ce_labels")
+        if labels is not None:                                                                 # the trainer's fused path: four scalar losses
+            return [run.ce_head(v, labels, self._ce_ignore) for v in lows]
         size = (x.t.shape[1], x.t.shape[2])
-        up = lambda v: run.resize(v, None, False, size=size)                                   # F.interpolate(..., size=x.size()[2:], mode="bilinear")
-        return [up(run.conv_bias(top, self._lin[5])), up(run.conv_bias(o4, self._lin[4])), up(run.conv_bias(o3, self._lin[3])), up(run.conv_bias(o2, self._lin[2]))]
+        return [run.resize(v, None, False, size=size) for v in lows]                           # F.interpolate(..., size=x.size()[2:], mode="bilinear")
 
     def forward(self, x, feats):
         return super().forward(x, *feats)
+
+    def losses(self, x, feats, labels, ignore_index=255):
+        """(loss5, loss4, loss3, loss2) = criterion(out_i, labels) of gald_trainer.py:76-79 without materialising the four [B,19,H,W] logit tensors
+        (upsample + cross-entropy fused, mi_upsample_ce_ex): what GALDTrainer.train_step calls."""
+        self._ce_labels, self._ce_ignore = labels.long().contiguous(), int(ignore_index)
+        try:
+            return super().forward(x, *feats)
+        finally:
+            self._ce_labels = None
 
 
 class _NhwcCEFn(torch.autograd.Function):
@@ -378,8 +404,7 @@ class GALDTrainer(BaseTrainer):
         self.optimizer_dec.zero_grad()
         src_input = src_input.to(self.device, non_blocking=True)
         src_label = src_label.to(self.device, non_blocking=True).long()
-        out5, out4, out3, out2 = self.decoder(src_input, self.encoder(src_input))
-        loss5, loss4, loss3, loss2 = (self.criterion(o, src_label) for o in (out5, out4, out3, out2))
+        loss5, loss4, loss3, loss2 = self.decoder.losses(src_input, self.encoder(src_input), src_label)          # = criterion(out_i, label), fused
         loss = loss2 * 1 + loss3 * 0.8 + loss4 * 0.6 + loss5 * 0.4
         loss.backward()
         self.optimizer_enc.step()

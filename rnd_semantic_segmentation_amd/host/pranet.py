@@ -672,14 +672,14 @@ class _EngineFn(torch.autograd.Function):
         rec = any(ctx.needs_input_grad[2:])
         run, ins, outs = net._run(xs, rec, in_needs)
         ctx.run, ctx.ins, ctx.outs, ctx.n_in, ctx.in_dtypes = run, ins, outs, n_in, [x.dtype for x in xs]
-        return tuple(o.t.permute(0, 3, 1, 2) for o in outs)                          # NCHW-shaped views of NHWC memory
+        return tuple(o.t.permute(0, 3, 1, 2) if o.t.dim() == 4 else o.t for o in outs)          # NCHW-shaped views of NHWC memory (or scalars: losses)
 
     @staticmethod
     def backward(ctx, *gouts):
         run = ctx.run
         for o, g in zip(ctx.outs, gouts):
             if g is not None:
-                o.g, o.own = g.permute(0, 2, 3, 1).to(o.t.dtype).contiguous(), True
+                o.g, o.own = (g.permute(0, 2, 3, 1).to(o.t.dtype).contiguous() if g.dim() == 4 else g), True
         run.backward()
         gin = [None if (v.g is None) else v.g.permute(0, 3, 1, 2).to(dt) for v, dt in zip(ctx.ins, ctx.in_dtypes)]
         ctx.run = ctx.ins = ctx.outs = None

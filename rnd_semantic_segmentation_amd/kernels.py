@@ -281,8 +281,8 @@ def softmax_ce_bwd(logits, labels, loss_out, grad_scale=1.0, ignore_index=255):
     return d
 
 
-def upsample_ce(low, labels, want_grad=True, grad_scale=1.0, ignore_index=255):
-    """Fused classifier-upsample + CrossEntropyLoss.  Returns (loss_out[4], dlow or None)."""
+def upsample_ce(low, labels, want_grad=True, grad_scale=1.0, ignore_index=255, align_corners=True):
+    """Fused classifier-upsample + CrossEntropyLoss.  Returns (loss_out[4], dlow or None).  align_corners False: F.interpolate(size=) default."""
     _chk(low, torch.float32, "low")
     _chk(labels, torch.int64, "labels")
     B, h, w, K = low.shape
@@ -291,8 +291,8 @@ def upsample_ce(low, labels, want_grad=True, grad_scale=1.0, ignore_index=255):
     ws = _workspace(L.mi_upsample_ce_workspace(B, h, w, K, H, W), low.device, "upce")
     out = torch.empty(4, dtype=torch.float32, device=low.device)
     dlow = torch.empty_like(low) if want_grad else None
-    check(L.mi_upsample_ce(_p(low), _p(labels), _p(out), _p(dlow), B, h, w, K, H, W, ignore_index, float(grad_scale),
-                           _p(ws), ws.numel(), _stream()), "mi_upsample_ce")
+    check(L.mi_upsample_ce_ex(_p(low), _p(labels), _p(out), _p(dlow), B, h, w, K, H, W, ignore_index, float(grad_scale), int(bool(align_corners)),
+                              _p(ws), ws.numel(), _stream()), "mi_upsample_ce")
     return out, dlow
 
 

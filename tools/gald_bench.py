@@ -32,8 +32,8 @@ def main():
     def step():
         oe.zero_grad()
         od.zero_grad()
-        o5, o4, o3, o2 = dec(x, enc(x))
-        loss = crit(o2, lab) * 1 + crit(o3, lab) * 0.8 + crit(o4, lab) * 0.6 + crit(o5, lab) * 0.4
+        l5, l4, l3, l2 = dec.losses(x, enc(x), lab)          # the trainer's path: upsample + cross-entropy fused
+        loss = l2 * 1 + l3 * 0.8 + l4 * 0.6 + l5 * 0.4
         loss.backward()
         oe.step()
         od.step()
