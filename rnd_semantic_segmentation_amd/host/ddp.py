@@ -33,6 +33,8 @@ class GradAllReducer:
         `diag`: what bench.py reports per rank - exposed exchange time (how long the compute stream waited at the join), payload bytes,
         bucket count, the number of ranks the process group really has."""
         self.stores = list(stores)
+        if os.environ.get("MI_DDP_BUCKET_MB"):          # tuning knob for the 8-GPU node (DESIGN.md section 6): bucket size without a code change
+            bucket_bytes = int(float(os.environ["MI_DDP_BUCKET_MB"]) * (1 << 20))
         self.payload = payload or os.environ.get("MI_DDP_PAYLOAD", "fp32")
         if self.payload not in ("fp32", "bf16"):
             raise ValueError("payload %r (fp32 | bf16)" % (self.payload,))
@@ -64,7 +66,9 @@ class GradAllReducer:
         self.diag = {"ranks": self.world, "active": bool(self.active), "payload": self.payload, "buckets": sum(len(b) for b in self.buckets.values()),
                      "payload_bytes_per_step": n_elem * (2 if self.payload == "bf16" else 4),
                      "wire_bytes_per_rank_per_step": int(2 * (self.world - 1) / max(self.world, 1) * n_elem * (2 if self.payload == "bf16" else 4)),
-                     "overlap": bool(overlap)}
+                     "overlap": bool(overlap), "bucket_bytes": int(bucket_bytes),
+                     # what bounds RCCL's footprint beside the compute kernels: its channel count = workgroups per collective (section 6)
+                     "rccl_env": {k: os.environ[k] for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "NCCL_ALGO", "NCCL_PROTO") if k in os.environ}}
 
     def _exchange(self, chunk, bucket=None):
         """Enqueue the average of `chunk` over ranks (in place); returns an async work handle or None (already complete)."""
