@@ -32,9 +32,9 @@ ALIASES = {
     "core.testers.pranet_tester": _PKG + "pranet",                    # core/testers/pranet_tester.py
     "core.models.classifiers.pranet.PraNet_Res2Net": _PKG + "pranet", # PraNet, RFB_modified, aggregation
     "core.models.classifiers.pranet.Res2Net_v1b": _PKG + "pranet",    # Bottle2neck
-    "core.utils.utils": _PKG + "pranet",
+    "core.utils.utils": _PKG + "pranet",                              # clip_gradient, AvgMeter (core/utils/utils.py:6-38)
     "core.trainers.gald_trainer": _PKG + "gald",                      # core/trainers/gald_trainer.py
-    "core.models.classifiers.gcpacc.gcpa_cc2": _PKG + "gald",         # GCPAEncoder, GCPADecoder                              # clip_gradient, AvgMeter (core/utils/utils.py:6-38)
+    "core.models.classifiers.gcpacc.gcpa_cc2": _PKG + "gald",         # GCPAEncoder, GCPADecoder
     "core.datasets.build": _PKG + "data",                             # core/datasets/build.py:5-30
     "base.base_trainer": _PKG + "plugin",                             # base/base_trainer.py
     "base.base_model": _PKG + "plugin",                               # base/base_model.py
