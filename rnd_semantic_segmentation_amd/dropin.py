@@ -68,7 +68,7 @@ class _AliasFinder(importlib.abc.MetaPathFinder):
         if name in PACKAGES:
             return importlib.machinery.ModuleSpec(name, _AliasLoader(None), is_package=True)
         if name.startswith(("core.", "base.")):
-            raise ImportError("%s is not part of the MI355X DeepLabV2 hot path (SURVEY.md 8: out of scope / next rows)" % name)
+            raise ImportError("%s is not part of the MI355X hot path (SURVEY.md 8: DeepLabV2-R101+ASPP, FADA, PraNet, GALD are; the rest is out of scope)" % name)
         return None
 
 

@@ -123,7 +123,13 @@ def test_dropin_import_surface():
     from core.utils.utility import AverageMeter, MetricLogger, inference, intersectionAndUnionGPU, setup_logger
     assert cfg is _C and issubclass(ASPPTrainer, BaseTrainer) and ASPP_Classifier_V2 is modules.ASPP_Classifier_V2
     with pytest.raises(ImportError, match="hot path"):
-        import core.trainers.pranet_trainer  # noqa: F401
+        import core.trainers.attn_trainer  # noqa: F401
+    import core.trainers.gald_trainer as gt     # rows N3 / N4 of SURVEY 8f resolve (their classes need the GPU only when instantiated)
+    import core.trainers.pranet_trainer as pt
+    from core.models.classifiers.gcpacc.gcpa_cc2 import GCPADecoder, GCPAEncoder  # noqa: F401
+    from core.models.classifiers.pranet.PraNet_Res2Net import PraNet  # noqa: F401
+    from core.utils.utils import AvgMeter, clip_gradient  # noqa: F401
+    assert issubclass(pt.PraNetTrainer, BaseTrainer) and issubclass(gt.GALDTrainer, BaseTrainer)
     g = _cases.load("g4_frozenbn")
     bn = FrozenBatchNorm2d(96)
     bn.load_state_dict({k: torch.from_numpy(g[k]) for k in ("weight", "bias", "running_mean", "running_var")})
