@@ -271,6 +271,12 @@ int mi_bn_colsum(const void* y_bf16, const float* mean, long M, int C, float* ou
 /* one pass: s1[c] = sum_m (y[m][c] - pilot[c]), s2[c] = sum_m (y[m][c] - pilot[c])^2; mean = pilot + s1/N, var = s2/N - (s1/N)^2.  The pilot
  * must be the same on every rank that shares the statistics (the running mean is). */
 int mi_bn_colsum2(const void* y_bf16, const float* pilot, long M, int C, float* s1, float* s2, void* workspace, size_t workspace_bytes, void* stream);
+/* (s1, s2) of mi_bn_colsum2 over `count` pixels (all ranks) -> out4 = [mean | invstd | gamma * invstd | beta - mean * gamma * invstd] ([4][C] fp32), in
+ * double; running_mean / running_var (both or neither) updated as torch.nn.BatchNorm2d does (momentum, unbiased variance), num_batches_tracked
+ * (optional, int64 scalar) += 1.  pilot may alias running_mean (it is read first).  Replaces the host arithmetic between statistics and normalise pass
+ * of resnet.py:84-113's BatchNorm2d in train(). */
+int mi_bn_finalize(const float* s1, const float* s2, const float* pilot, double count, const float* gamma, const float* beta, float* running_mean,
+                   float* running_var, long long* num_batches_tracked, float momentum, float eps, float* out4, int C, void* stream);
 /* out = relu?((y - mean[c]) * scale[c] + beta[c] (+ res)), scale = gamma * rsqrt(var + eps); mask_out (optional, C % 16 == 0): the
  * packed sign bits of out in the layout of MI_EPI_WRITE_MASK */
 int mi_bn_apply(const void* y_bf16, const float* mean, const float* scale, const float* beta, const void* res_bf16, void* out_bf16,

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 import torch  # noqa: F401  (first: the process must bind torch's bundled HIP runtime, not a second copy)
-from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI355SEG_LIB") or os.path.join(_HERE, "libmi355seg.so")      # override: kernel experiments (tools/)
@@ -70,6 +70,7 @@ SIGNATURES = {
     "mi_bn_colsum": (I, [P, P, L, I, P, P, Z, P]),
     "mi_bn_apply": (I, [P, P, P, P, P, P, P, I, L, I, P]),
     "mi_bn_colsum2": (I, [P, P, L, I, P, P, P, Z, P]),
+    "mi_bn_finalize": (I, [P, P, P, c_double, P, P, P, P, P, F, F, P, I, P]),
     "mi_bn_bwd_colsums": (I, [P, P, P, P, P, L, I, P, P, P, Z, P]),
     "mi_bn_bwd_apply": (I, [P, P, P, P, P, P, P, F, P, P, L, I, P]),
     "mi_gconv_pack_elems": (Z, [I] * 4),

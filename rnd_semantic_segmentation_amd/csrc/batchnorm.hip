@@ -7,6 +7,7 @@
 //                       s[c] = sum_m (y[m][c] - mean[c])^2           (two-pass variance: no cancellation)
 //   mi_bn_colsum2       s1[c] = sum_m (y - pilot[c]), s2[c] = sum_m (y - pilot[c])^2 in ONE pass: mean = pilot + s1/N,
 //                       var = s2/N - (s1/N)^2; with the pilot near the mean (the running mean) the subtraction loses 2-3 of 24 bits
+//   mi_bn_finalize      (s1, s2, pilot, count) -> mean, invstd, gamma * invstd, beta - mean * gamma * invstd; running statistics as torch updates them
 //   mi_bn_apply         out = relu?((y - mean) * scale + beta (+ res)), optional packed sign bits   scale = gamma * invstd
 //   mi_bn_bwd_colsums   dbeta[c] = sum_m g[m][c],   dgamma[c] = sum_m g[m][c] * (y[m][c] - mean[c]) * invstd[c]   (g optionally masked by the
 //                       packed ReLU sign bits of the layer's output: no separate mask pass)
@@ -189,6 +190,33 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16x8* __restr
     dy[idx] = o;
 }
 
+// One thread per channel: the pilot-form sums of mi_bn_colsum2 (after the all-reduce over ranks, when the layer is synchronised) -> batch mean,
+// invstd, the folded affine (scale = gamma * invstd, shift = beta - mean * scale) and torch's running-statistics update (biased variance for the
+// normalisation, unbiased for running_var; num_batches_tracked += 1), in double: no host arithmetic between the conv and the normalise pass.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ s1, const float* __restrict__ s2, const float* __restrict__ pilot,
+                                                          double count, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt,
+                                                          float momentum, float eps, float* __restrict__ out, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c == 0 && nbt) nbt[0] += 1;
+    if (c >= C) return;
+    const double d = (double)s1[c] / count;
+    const double mean = (double)pilot[c] + d;
+    double var = (double)s2[c] / count - d * d;
+    var = var > 0.0 ? var : 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * invstd;
+    out[c] = (float)mean;
+    out[C + c] = invstd;
+    out[2 * C + c] = sc;
+    out[3 * C + c] = beta[c] - (float)mean * sc;
+    if (running_mean) {
+        const double unb = count > 1.0 ? count / (count - 1.0) : 1.0;
+        running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+        running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * var * unb);
+    }
+}
+
 inline int pow2_at_least(int v) {
     int p = 1;
     while (p < v) p <<= 1;
@@ -247,6 +275,17 @@ extern "C" int mi_bn_colsum2(const void* y_bf16, const float* pilot, long M, int
                        (const float*)nullptr, (const uint8_t*)nullptr, partial, M, p.slots, p.cp, p.rows_per_block);
     hipLaunchKernelGGL(bn_final_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, partial, p.nblocks, C, 2, s1, s2);
     MI_CHECK_LAUNCH("mi_bn_colsum2");
+    return MI_OK;
+}
+
+extern "C" int mi_bn_finalize(const float* s1, const float* s2, const float* pilot, double count, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps, float* out4,
+                              int C, void* stream) {
+    MI_REQUIRE(s1 && s2 && pilot && gamma && beta && out4 && C > 0 && count >= 1.0, "mi_bn_finalize: null operand, C=%d, count=%g", C, count);
+    MI_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "mi_bn_finalize: running_mean and running_var go together");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, s1, s2, pilot, count, gamma, beta, running_mean,
+                       running_var, num_batches_tracked, momentum, eps, out4, C);
+    MI_CHECK_LAUNCH("mi_bn_finalize");
     return MI_OK;
 }
 

@@ -385,6 +385,80 @@ class StageEngine:
 
 
 
+    # -- trainable BatchNorm2d in train() (MODEL.FREEZE_BN False): the same schedule with the statistics between conv and normalise pass
+    @staticmethod
+    def _bn_unit(x, rt, relu, res=None):
+        """conv (plain store) -> batch statistics -> normalise (+ residual) (+ ReLU, + sign bits).  Returns (out, y, fin, count, bits)."""
+        c = rt.spec
+        y = K.conv_gemm(x, rt.wp, arch.out_hw(x.shape[1], x.shape[2], c), c.k, c.stride, c.pad, c.dil, K.GATHER_FWD)
+        fin, count = bn_batch_statistics(y, rt.bn)
+        if relu:
+            out, bits = K.bn_apply(y, fin[0], fin[2], rt.bn.bias.detach(), res=res, relu=True, want_mask=True)
+        else:
+            out, bits = K.bn_apply(y, fin[0], fin[2], rt.bn.bias.detach(), res=res, relu=False), None
+        return out, y, fin, count, bits
+
+    def forward_batchnorm(self, x):
+        """resnet.py:93-113 on batch statistics.  saved[i] = (x, bits(x) or None, [(a, y, fin, count, bits) of conv1, conv2, conv3, downsample])."""
+        saved, xbits = [], None
+        for blk, rts in self.blocks:
+            u1 = self._bn_unit(x, rts[0], True)
+            u2 = self._bn_unit(u1[0], rts[1], True)
+            ud = self._bn_unit(x, rts[3], False) if blk.down else None
+            u3 = self._bn_unit(u2[0], rts[2], True, res=ud[0] if blk.down else x)
+            saved.append((x, xbits, [u1, u2, u3, ud]))
+            x, xbits = u3[0], u3[4]
+        return x, saved, xbits
+
+    def backward_batchnorm(self, saved, fbits, dfeat, need_dx):
+        """Hand-written backward of forward_batchnorm: per block, g (already masked by the block's output ReLU) -> bn3 -> conv3 -> bn2 (+ ReLU
+        by its sign bits) -> conv2 -> bn1 -> conv1, whose data-gradient epilogue adds the skip gradient and applies the previous block's output
+        mask (no separate add or mask pass); weight gradients on the side stream."""
+        g = K.relu_mask(dfeat, fbits)
+        store = getattr(self.convs[0].weight, "_mi_store", None)
+        side = _SideStream.get(dfeat.device)
+
+        def wgrad(dy, xin, rt):
+            c = rt.spec
+
+            def go():
+                dw, acc = grad_slot(rt.weight)
+                K.conv_wgrad(dy, xin, dw, c.k, c.stride, c.pad, c.dil, accumulate=acc)
+            _off_path(side, go, dy, xin)
+
+        for bi in range(len(self.blocks) - 1, -1, -1):
+            blk, rts = self.blocks[bi]
+            x, xb, (u1, u2, u3, ud) = saved[bi]
+            first = bi == 0
+            hw_in = (x.shape[1], x.shape[2])
+            dy3 = bn_backward(g, u3[1], u3[2], u3[3], rts[2].bn)
+            wgrad(dy3, u2[0], rts[2])
+            ga2 = self._dgrad(dy3, rts[2], (u2[0].shape[1], u2[0].shape[2]))
+            dy2 = bn_backward(ga2, u2[1], u2[2], u2[3], rts[1].bn, bits=u2[4])
+            wgrad(dy2, u1[0], rts[1])
+            ga1 = self._dgrad(dy2, rts[1], (u1[0].shape[1], u1[0].shape[2]))
+            dy1 = bn_backward(ga1, u1[1], u1[2], u1[3], rts[0].bn, bits=u1[4])
+            wgrad(dy1, x, rts[0])
+            dyd = None
+            if blk.down:
+                dyd = bn_backward(g, ud[1], ud[2], ud[3], rts[3].bn)
+                wgrad(dyd, x, rts[3])
+            if first and not need_dx:
+                g = None
+            else:
+                skip = self._dgrad(dyd, rts[3], hw_in) if blk.down else g
+                g = self._dgrad(dy1, rts[0], hw_in, res=skip, bits=None if first else xb)
+            saved[bi] = None
+            if store is not None and store.grad_hooks:
+                lo, hi = store.span([p for rt in rts for p in (rt.weight, rt.bn.weight, rt.bn.bias)])
+                with torch.cuda.stream(side.stream) if side is not None else contextlib.nullcontext():
+                    for hook in store.grad_hooks:
+                        hook(store, lo, hi)
+        if side is not None:
+            side.join()
+        return g
+
+
 # ------------------------------------------------------------------------------------------------ trainable BatchNorm2d (MODEL.FREEZE_BN=False)
 def _bn_allreduce(bn, *tensors):
     """SyncBatchNorm semantics (train_distill.py:53): the raw per-channel sums of every rank are added; returns the number of ranks
@@ -401,116 +475,77 @@ def _bn_allreduce(bn, *tensors):
     return dist.get_world_size()
 
 
-class ConvFn(torch.autograd.Function):
-    """One conv of the backbone without an epilogue (its BatchNorm needs the raw output): NHWC bf16 in / out through the same
-    implicit-GEMM kernels as the FrozenBN schedule; the weight gradient is written into the parameter's gradient slot."""
+def _bn_synced(bn):
+    import torch.distributed as dist
+    return getattr(bn, "_mi_sync", False) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def bn_batch_statistics(y, bn):
+    """BatchNorm2d in train() on the raw conv output y (NHWC bf16): ([mean | invstd | gamma * invstd | beta - mean * gamma * invstd], pixel count over
+    the ranks that share the statistics).  One pass over y (sums of y - pilot and (y - pilot)^2 with the running mean as the pilot: identical on
+    every rank, and close enough to the batch mean that var = E[d^2] - E[d]^2 loses 2-3 of fp32's 24 bits), the all-reduce of the raw sums when
+    the layer is synchronised, and one finalize launch that also updates the running statistics as torch does - no host arithmetic in between."""
+    C = y.shape[-1]
+    pilot = bn.running_mean if bn.running_mean is not None else torch.zeros(C, dtype=torch.float32, device=y.device)
+    s1, s2 = K.bn_colsum2(y, pilot)
+    count = (y.numel() // C) * _bn_allreduce(bn, s1, s2)
+    return K.bn_finalize(s1, s2, pilot, count, bn), count
+
+
+def bn_backward(g, y, fin, count, bn, bits=None):
+    """dy of BatchNorm2d on batch statistics (+ the ReLU in front of g when `bits` carries its sign bits); the affine gradients - this rank's raw
+    sums, what SyncBatchNorm hands DDP as well - go into the parameters' gradient slots."""
+    (sb, ab), (sg, ag) = grad_slot(bn.bias), grad_slot(bn.weight)
+    if ab or ag:
+        dbeta, dgamma = K.bn_bwd_colsums(g, y, fin[0], fin[1], bits)
+        sb.add_(dbeta)
+        sg.add_(dgamma)
+    else:
+        dbeta, dgamma = K.bn_bwd_colsums(g, y, fin[0], fin[1], bits, out=(sb, sg))
+    if _bn_synced(bn):
+        dbeta, dgamma = dbeta.clone(), dgamma.clone()
+        _bn_allreduce(bn, dbeta, dgamma)
+    return K.bn_bwd_apply(g, y, fin[0], fin[1], bn.weight.detach(), dbeta, dgamma, count, bits)
+
+
+class BnStemFn(torch.autograd.Function):
+    """Stem with a trainable BatchNorm2d in train(): 7x7/2 conv (patch matrix + GEMM) -> batch statistics -> normalise + ReLU + 3x3/2 max-pool in ONE
+    pass (the fused FrozenBN stem kernel with the batch affine).  Backward: pooled gradient routed by the stored argmax (already ReLU-masked), the
+    BatchNorm backward, the stem weight gradient.  resnet.py:137-140, 177-180 with feature_extractor.py:37."""
 
     @staticmethod
-    def forward(ctx, x, weight, rt):
-        c = rt.spec
-        y = K.conv_gemm(x, rt.wp, arch.out_hw(x.shape[1], x.shape[2], c), c.k, c.stride, c.pad, c.dil, K.GATHER_FWD)
-        ctx.rt = rt
-        ctx.save_for_backward(x)
-        return y
+    def forward(ctx, x, weight, gamma, beta, bn):
+        y, saved = stem_conv_forward(x, weight)
+        fin, count = bn_batch_statistics(y, bn)
+        pool, idx = K.stem_pool_fwd(y, fin[2], fin[3])
+        ctx.bn, ctx.count, ctx.nsaved = bn, count, len(saved)
+        ctx.save_for_backward(y, fin, idx, *saved)
+        return pool
 
     @staticmethod
-    def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
-        rt = ctx.rt
-        c = rt.spec
-        dy = dy.contiguous()
-        dw, acc = grad_slot(rt.weight)
-        K.conv_wgrad(dy, x, dw, c.k, c.stride, c.pad, c.dil, accumulate=acc)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = K.conv_gemm(dy, rt.wpt, (x.shape[1], x.shape[2]), c.k, c.stride, c.pad, c.dil, K.GATHER_DGRAD)
-        return dx, None, None
+    def backward(ctx, dpool):
+        y, fin, idx = ctx.saved_tensors[:3]
+        ones = torch.ones(y.shape[-1], dtype=torch.float32, device=y.device)
+        g = K.stem_pool_bwd(dpool.contiguous(), idx, ones, (y.shape[1], y.shape[2]))          # d loss / d relu(bn(y))
+        dy = bn_backward(g, y, fin, ctx.count, ctx.bn)
+        return None, stem_conv_wgrad(dy, ctx.saved_tensors[3:]), None, None, None
 
 
-class BnActFn(torch.autograd.Function):
-    """relu?(BatchNorm2d(y) (+ res)) on batch statistics (torch.nn.BatchNorm2d in train(): biased variance for the normalisation,
-    unbiased for running_var, momentum 0.1, eps 1e-5 - resnet.py:84-113 with feature_extractor.py:37), NHWC bf16.  The affine
-    gradients go into the parameters' gradient slots."""
+class BnStagesFn(torch.autograd.Function):
+    """layer1..layer4 with trainable BatchNorm2d on batch statistics as ONE autograd node: StageEngine.forward_batchnorm / backward_batchnorm."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, bn, res, relu):
-        C = y.shape[-1]
-        M = y.numel() // C
-        # one pass over y: sums of (y - pilot) and (y - pilot)^2 with the running mean as the pilot (identical on every rank, and
-        # close enough to the batch mean that var = E[d^2] - E[d]^2 loses 2-3 of fp32's 24 bits); MI_BN_TWO_PASS=1: mean first, then
-        # sum (y - mean)^2 - a second read of y
-        if os.environ.get("MI_BN_TWO_PASS") == "1" or bn.running_mean is None:
-            s = K.bn_colsum(y)
-            ranks = _bn_allreduce(bn, s)
-            count = M * ranks
-            mean = s / count
-            v = K.bn_colsum(y, mean)
-            _bn_allreduce(bn, v)
-            var = v / count
-        else:
-            pilot = bn.running_mean.detach().clone()
-            s1, s2 = K.bn_colsum2(y, pilot)
-            ranks = _bn_allreduce(bn, s1, s2)
-            count = M * ranks
-            d = s1 / count
-            mean = pilot + d
-            var = (s2 / count - d * d).clamp_min_(0.0)
-        invstd = torch.rsqrt(var + bn.eps)
-        if relu:
-            out, bits = K.bn_apply(y, mean, gamma.detach() * invstd, beta.detach(), res=res, relu=True, want_mask=True)
-        else:
-            out, bits = K.bn_apply(y, mean, gamma.detach() * invstd, beta.detach(), res=res, relu=False), None
-        if bn.track_running_stats and bn.running_mean is not None:
-            if bn.momentum is None:
-                raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative average) is not used by the reference")
-            m = float(bn.momentum)
-            with torch.no_grad():
-                bn.running_mean.mul_(1.0 - m).add_(mean, alpha=m)
-                bn.running_var.mul_(1.0 - m).add_(var, alpha=m * count / max(count - 1, 1))
-                bn.num_batches_tracked += 1
-        ctx.bn, ctx.count, ctx.relu, ctx.has_res = bn, count, relu, res is not None
-        ctx.save_for_backward(y, mean, invstd, bits, gamma.detach())
-        return out
+    def forward(ctx, x, eng, *params):
+        eng.prepare(True)
+        feat, saved, fbits = eng.forward_batchnorm(x)
+        ctx.eng, ctx.saved, ctx.fbits = eng, saved, fbits
+        return feat
 
     @staticmethod
-    def backward(ctx, g):
-        y, mean, invstd, bits, gamma = ctx.saved_tensors
-        bn = ctx.bn
-        g = g.contiguous()
-        fused_mask = None
-        if ctx.relu and ctx.has_res:
-            g = K.relu_mask(g, bits)                # the skip connection needs the masked gradient as a tensor
-        elif ctx.relu:
-            fused_mask = bits                       # otherwise both backward kernels apply the sign bits on the fly
-        dbeta, dgamma = K.bn_bwd_colsums(g, y, mean, invstd, fused_mask)
-        for p, d in ((bn.weight, dgamma), (bn.bias, dbeta)):        # this rank's sums: what SyncBatchNorm hands DDP as well
-            slot, acc = grad_slot(p)
-            slot.add_(d) if acc else slot.copy_(d)
-        if getattr(bn, "_mi_sync", False):
-            dbeta, dgamma = dbeta.clone(), dgamma.clone()
-            _bn_allreduce(bn, dbeta, dgamma)
-        dy = K.bn_bwd_apply(g, y, mean, invstd, gamma, dbeta, dgamma, ctx.count, fused_mask)
-        return dy, None, None, None, (g if ctx.has_res else None), None
-
-
-def batchnorm_stages(x, eng):
-    """layer1..layer4 with trainable BatchNorm2d on batch statistics: the graph of resnet.py:93-113 composed from ConvFn / BnActFn
-    (torch autograd orders the backward; the FrozenBN schedule's fused epilogues and hand-written backward do not apply)."""
-    for blk, rts in eng.blocks:
-        def unit(inp, rt, res, relu):
-            return BnActFn.apply(ConvFn.apply(inp, rt.weight, rt), rt.bn.weight, rt.bn.bias, rt.bn, res, relu)
-        a1 = unit(x, rts[0], None, True)
-        a2 = unit(a1, rts[1], None, True)
-        idn = unit(x, rts[3], None, False) if blk.down else x
-        x = unit(a2, rts[2], idn, True)
-    return x
-
-
-def batchnorm_stem(x, conv_weight, bn):
-    """7x7/2 conv (PyTorch-ROCm library op) -> BatchNorm2d on batch statistics + ReLU (HIP) -> 3x3/2 max-pool."""
-    a = BnActFn.apply(StemConvFn.apply(x, conv_weight), bn.weight, bn.bias, bn, None, True)
-    p = torch.nn.functional.max_pool2d(a.permute(0, 3, 1, 2), 3, 2, 1)
-    return p.permute(0, 2, 3, 1).contiguous()
+    def backward(ctx, dfeat):
+        dx = ctx.eng.backward_batchnorm(ctx.saved, ctx.fbits, dfeat.contiguous(), ctx.needs_input_grad[0])
+        ctx.saved = ctx.fbits = None
+        return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 # ------------------------------------------------------------------------------------------------ exact-fp32 evaluation
 class Fp32Backbone:

@@ -149,10 +149,11 @@ class resnet_feature_extractor(nn.Module):
         xb = x.to(dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
         self._engine.batch_stats = (not self.freeze_bn) and self.training
         if self._engine.batch_stats:
-            # trainable BatchNorm2d in train(): batch statistics, composed from ConvFn / BnActFn (engine.batchnorm_stages)
-            self._engine.prepare(True)
-            y = engine.batchnorm_stem(xb, bb.conv1.weight, bb.bn1)
-            return engine.batchnorm_stages(y, self._engine).permute(0, 3, 1, 2)
+            # trainable BatchNorm2d in train(): batch statistics between each conv and its normalise pass, two autograd nodes with hand-written
+            # backward (engine.BnStemFn, engine.BnStagesFn)
+            y = engine.BnStemFn.apply(xb, bb.conv1.weight, bb.bn1.weight, bb.bn1.bias, bb.bn1)
+            params = [p for rt in self._engine.convs for p in (rt.weight, rt.bn.weight, rt.bn.bias)]
+            return engine.BnStagesFn.apply(y, self._engine, *params).permute(0, 3, 1, 2)
         # stem: 7x7/2 conv as patch matrix + GEMM (engine.stem_conv_forward), then FrozenBN + ReLU + 3x3/2 max-pool in one HIP kernel
         scale, shift = self._stem_fold()
         y = engine.StemFn.apply(xb, bb.conv1.weight, scale, shift)                       # [B,Hp,Wp,64] bf16 NHWC

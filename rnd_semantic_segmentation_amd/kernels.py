@@ -497,16 +497,30 @@ def bn_colsum(y, mean=None):
 
 
 def bn_colsum2(y, pilot):
-    """One pass: raw (sum (y - pilot), sum (y - pilot)^2) per channel."""
+    """One pass: raw (sum (y - pilot), sum (y - pilot)^2) per channel - two rows of one [2, C] buffer (one all-reduce when synchronised)."""
     _chk(y, torch.bfloat16, "y")
     C = y.shape[-1]
     M = y.numel() // C
-    s1 = torch.empty(C, dtype=torch.float32, device=y.device)
-    s2 = torch.empty_like(s1)
+    s1, s2 = torch.empty((2, C), dtype=torch.float32, device=y.device)
     ws = _bn_workspace(y.device, M, C)
     _timed("bn_kernels", 0.0, lambda: check(_lib.lib().mi_bn_colsum2(_p(y), _p(pilot), M, C, _p(s1), _p(s2), _p(ws), ws.numel(), _stream()), "mi_bn_colsum2"),
            ("bn", 4, C, C, M, 0, 0))
     return s1, s2
+
+
+def bn_finalize(s1, s2, pilot, count, bn):
+    """[mean | invstd | gamma * invstd | beta - mean * gamma * invstd] ([4, C] fp32) from the pilot-form sums over `count` pixels, and torch's
+    running-statistics update of `bn` (an nn.BatchNorm2d), in one launch."""
+    C = s1.numel()
+    out = torch.empty((4, C), dtype=torch.float32, device=s1.device)
+    track = bn.track_running_stats and bn.running_mean is not None
+    if track and bn.momentum is None:
+        raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative average) is not used by the reference")
+    check(_lib.lib().mi_bn_finalize(_p(s1), _p(s2), _p(pilot), float(count), _p(bn.weight.detach()), _p(bn.bias.detach()),
+                                    _p(bn.running_mean) if track else None, _p(bn.running_var) if track else None,
+                                    _p(bn.num_batches_tracked) if track else None, float(bn.momentum or 0.0), float(bn.eps), _p(out), C, _stream()),
+          "mi_bn_finalize")
+    return out
 
 
 def bn_apply(y, mean, scale, beta, res=None, relu=False, want_mask=False):
@@ -521,14 +535,19 @@ def bn_apply(y, mean, scale, beta, res=None, relu=False, want_mask=False):
     return (out, bits) if want_mask else out
 
 
-def bn_bwd_colsums(g, y, mean, invstd, relu_bits=None):
-    """Raw (sum g, sum g * xhat) per channel; with relu_bits g counts only where the layer's output was positive."""
+def bn_bwd_colsums(g, y, mean, invstd, relu_bits=None, out=None):
+    """Raw (sum g, sum g * xhat) per channel; with relu_bits g counts only where the layer's output was positive.  out: (dbeta, dgamma) to
+    write into (the parameters' gradient slots)."""
     _chk(g, torch.bfloat16, "g")
     _chk(y, torch.bfloat16, "y")
     C = y.shape[-1]
     M = y.numel() // C
-    dbeta = torch.empty(C, dtype=torch.float32, device=y.device)
-    dgamma = torch.empty_like(dbeta)
+    if out is None:
+        dbeta, dgamma = torch.empty((2, C), dtype=torch.float32, device=y.device)
+    else:
+        dbeta, dgamma = out
+        _chk(dbeta, torch.float32, "dbeta")
+        _chk(dgamma, torch.float32, "dgamma")
     ws = _bn_workspace(y.device, M, C)
     _timed("bn_kernels", 0.0, lambda: check(_lib.lib().mi_bn_bwd_colsums(_p(g), _p(y), _p(mean), _p(invstd), _p(relu_bits), M, C, _p(dbeta), _p(dgamma),
                                                                          _p(ws), ws.numel(), _stream()), "mi_bn_bwd_colsums"), ("bn", 2, C, C, M, 0, 0))

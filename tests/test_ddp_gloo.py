@@ -341,6 +341,22 @@ class _TorchBnKernels:
         return d.sum(0), (d * d).sum(0)
 
     @staticmethod
+    def bn_finalize(s1, s2, pilot, count, bn):
+        """mi_bn_finalize's contract: pilot-form sums over `count` pixels -> [mean | invstd | gamma * invstd | beta - mean * gamma * invstd], running
+        statistics updated as torch.nn.BatchNorm2d does."""
+        d = s1.double() / count
+        mean = pilot.double() + d
+        var = (s2.double() / count - d * d).clamp_min(0.0)
+        invstd = torch.rsqrt(var + bn.eps)
+        scale = bn.weight.detach().double() * invstd
+        with torch.no_grad():
+            m = bn.momentum
+            bn.running_mean.copy_(((1 - m) * bn.running_mean.double() + m * mean).float())
+            bn.running_var.copy_(((1 - m) * bn.running_var.double() + m * var * count / max(count - 1, 1)).float())
+            bn.num_batches_tracked += 1
+        return torch.stack([mean, invstd, scale, bn.bias.detach().double() - mean * scale]).float()
+
+    @staticmethod
     def bn_apply(y, mean, scale, beta, res=None, relu=False, want_mask=False):
         out = (y.float() - mean) * scale + beta
         if res is not None:
@@ -355,11 +371,16 @@ class _TorchBnKernels:
         return (g.float() * bits).to(g.dtype)
 
     @staticmethod
-    def bn_bwd_colsums(g, y, mean, invstd, relu_bits=None):
+    def bn_bwd_colsums(g, y, mean, invstd, relu_bits=None, out=None):
         gf = g.float() * relu_bits if relu_bits is not None else g.float()
         xhat = (y.float() - mean) * invstd
         C = y.shape[-1]
-        return gf.reshape(-1, C).sum(0), (gf * xhat).reshape(-1, C).sum(0)
+        dbeta, dgamma = gf.reshape(-1, C).sum(0), (gf * xhat).reshape(-1, C).sum(0)
+        if out is not None:
+            out[0].copy_(dbeta)
+            out[1].copy_(dgamma)
+            return out
+        return dbeta, dgamma
 
     @staticmethod
     def bn_bwd_apply(g, y, mean, invstd, gamma, dbeta, dgamma, count, relu_bits=None):
@@ -373,7 +394,7 @@ def _syncbn_worker(rank, world, port, tmpdir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
     try:
-        for name in ("bn_colsum2", "bn_apply", "relu_mask", "bn_bwd_colsums", "bn_bwd_apply"):
+        for name in ("bn_colsum2", "bn_finalize", "bn_apply", "relu_mask", "bn_bwd_colsums", "bn_bwd_apply"):
             setattr(engine.K, name, getattr(_TorchBnKernels, name))
         g = torch.Generator().manual_seed(5)
         B, H, W, C = 4, 6, 5, 16
@@ -387,11 +408,14 @@ def _syncbn_worker(rank, world, port, tmpdir):
                 bn.weight.copy_(torch.linspace(0.5, 1.5, C))
                 bn.bias.copy_(torch.linspace(-0.2, 0.2, C))
             bn._mi_sync = sync
-            y = y_all[sl].clone().requires_grad_(True)
-            res = res_all[sl].clone().requires_grad_(True)
-            out = engine.BnActFn.apply(y, bn.weight, bn.bias, bn, res, True)
-            out.backward(gout_all[sl])
-            return out.detach(), y.grad, res.grad, bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_mean.clone(), bn.running_var.clone()
+            # the unit of StageEngine.forward_batchnorm / backward_batchnorm: statistics (+ exchange) -> normalise + residual + ReLU; backward:
+            # ReLU mask, affine gradients (this rank's sums), exchange of the sums, input gradient
+            y, res = y_all[sl].clone(), res_all[sl].clone()
+            fin, count = engine.bn_batch_statistics(y, bn)
+            out, bits = engine.K.bn_apply(y, fin[0], fin[2], bn.bias.detach(), res=res, relu=True, want_mask=True)
+            dres = engine.K.relu_mask(gout_all[sl], bits)
+            dy = engine.bn_backward(dres, y, fin, count, bn)
+            return out, dy, dres, bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_mean.clone(), bn.running_var.clone()
 
         half = slice(rank * 2, rank * 2 + 2)
         out_s, dy_s, dres_s, dg_s, db_s, rm_s, rv_s = run(half, True)
@@ -407,7 +431,7 @@ def _syncbn_worker(rank, world, port, tmpdir):
         ot = (bn(yt) + res_all.permute(0, 3, 1, 2)).relu()
         ot.backward(gout_all.permute(0, 3, 1, 2))
         close = lambda a, b, tol=2e-5: float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))
-        assert close(out_f, ot.detach().permute(0, 2, 3, 1)) and close(dy_f, yt.grad.permute(0, 2, 3, 1)), "single-process BnActFn vs torch"
+        assert close(out_f, ot.detach().permute(0, 2, 3, 1)) and close(dy_f, yt.grad.permute(0, 2, 3, 1)), "single-process BatchNorm unit vs torch"
         assert close(dg_f, bn.weight.grad) and close(db_f, bn.bias.grad) and close(rm_f, bn.running_mean) and close(rv_f, bn.running_var)
         # synchronised halves == the full batch: outputs, input / residual gradients of this rank's samples, summed affine gradients,
         # running statistics (global mean, unbiased global variance)
@@ -422,7 +446,7 @@ def _syncbn_worker(rank, world, port, tmpdir):
 
 
 def test_two_rank_gloo_synchronised_batchnorm_equals_full_batch(tmp_path):
-    """engine.BnActFn with `_mi_sync` (train_distill.py:53 SyncBatchNorm semantics) in a 2-rank gloo job, the BatchNorm kernels replaced
+    """engine.bn_batch_statistics / bn_backward with `_mi_sync` (train_distill.py:53 SyncBatchNorm semantics) in a 2-rank gloo job, the BatchNorm kernels replaced
     by torch stand-ins with the same contracts: the exchange of RAW sums, the global pixel count, the per-rank affine gradients and
     the running-statistics update reproduce one process on the full batch - and torch.nn.BatchNorm2d itself."""
     port = _free_port()
