@@ -44,6 +44,7 @@ extern "C" {
 #define MI_EPI_ZSPLIT 32     /* fp32 store to [n/zgw][M][zgw] (ASPP tap planes) */
 #define MI_EPI_WRITE_MASK 64 /* also store sign bits of the result: bit n%16 of uint16 mask_out[m][n/16] = (v > 0)   (N % 16 == 0) */
 #define MI_EPI_LEAKY 256     /* with MI_EPI_RELU: LeakyReLU(alpha); with MI_EPI_BITMASK: its backward (v *= alpha where the bit is 0) */
+#define MI_EPI_STATS 512     /* (mi_conv_gemm_stats only) plain bf16 store + per-tile sums of (out - pilot), (out - pilot)^2 per channel */
 #define MI_EPI_BITMASK 128   /* like MI_EPI_MASK but `msk` points at such packed bits: 1/16 of the bytes of the bf16 tensor */
 
 /* gather modes */
@@ -271,6 +272,16 @@ int mi_bn_colsum(const void* y_bf16, const float* mean, long M, int C, float* ou
 /* one pass: s1[c] = sum_m (y[m][c] - pilot[c]), s2[c] = sum_m (y[m][c] - pilot[c])^2; mean = pilot + s1/N, var = s2/N - (s1/N)^2.  The pilot
  * must be the same on every rank that shares the statistics (the running mean is). */
 int mi_bn_colsum2(const void* y_bf16, const float* pilot, long M, int C, float* s1, float* s2, void* workspace, size_t workspace_bytes, void* stream);
+/* Conv forward (mi_conv_gemm's contract, plain bf16 store) that also returns what mi_bn_colsum2 would compute on its output: sums[0][n] = sum_m (out[m][n] -
+ * pilot[n]), sums[1][n] = sum_m (out[m][n] - pilot[n])^2 over the bf16-rounded outputs, accumulated per row tile in the epilogue and added in a fixed
+ * order (bitwise reproducible) - the statistics pass over the conv output of `bn(conv(x))` (resnet.py:93-109 with feature_extractor.py:37) costs no
+ * extra read.  gamma != NULL: the last reduction launch also does mi_bn_finalize's work with count = B*Ho*Wo (gamma, beta, running_mean / running_var or
+ * both NULL, num_batches_tracked or NULL, momentum, eps, out4 [4][N]) - the unsynchronised BatchNorm2d; gamma == out4 == NULL: sums only (the caller
+ * all-reduces them and calls mi_bn_finalize).  workspace: mi_conv_gemm_stats_workspace(B*Ho*Wo, N) bytes. */
+size_t mi_conv_gemm_stats_workspace(long M, int N);
+int mi_conv_gemm_stats(const void* a, const void* wp, void* out, int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N, int ksize, int stride, int pad,
+                       int dil, const float* pilot, float* sums, void* workspace, size_t workspace_bytes, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps, float* out4, void* stream);
 /* (s1, s2) of mi_bn_colsum2 over `count` pixels (all ranks) -> out4 = [mean | invstd | gamma * invstd | beta - mean * gamma * invstd] ([4][C] fp32), in
  * double; running_mean / running_var (both or neither) updated as torch.nn.BatchNorm2d does (momentum, unbiased variance), num_batches_tracked
  * (optional, int64 scalar) += 1.  pilot may alias running_mean (it is read first).  Replaces the host arithmetic between statistics and normalise pass

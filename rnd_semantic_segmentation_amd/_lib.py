@@ -70,6 +70,8 @@ SIGNATURES = {
     "mi_bn_colsum": (I, [P, P, L, I, P, P, Z, P]),
     "mi_bn_apply": (I, [P, P, P, P, P, P, P, I, L, I, P]),
     "mi_bn_colsum2": (I, [P, P, L, I, P, P, P, Z, P]),
+    "mi_conv_gemm_stats_workspace": (Z, [L, I]),
+    "mi_conv_gemm_stats": (I, [P, P, P] + [I] * 11 + [P, P, P, Z, P, P, P, P, P, F, F, P, P]),
     "mi_bn_finalize": (I, [P, P, P, c_double, P, P, P, P, P, F, F, P, I, P]),
     "mi_bn_bwd_colsums": (I, [P, P, P, P, P, L, I, P, P, P, Z, P]),
     "mi_bn_bwd_apply": (I, [P, P, P, P, P, P, P, F, P, P, L, I, P]),

@@ -190,31 +190,88 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16x8* __restr
     dy[idx] = o;
 }
 
-// One thread per channel: the pilot-form sums of mi_bn_colsum2 (after the all-reduce over ranks, when the layer is synchronised) -> batch mean,
-// invstd, the folded affine (scale = gamma * invstd, shift = beta - mean * scale) and torch's running-statistics update (biased variance for the
-// normalisation, unbiased for running_var; num_batches_tracked += 1), in double: no host arithmetic between the conv and the normalise pass.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ s1, const float* __restrict__ s2, const float* __restrict__ pilot,
-                                                          double count, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt,
-                                                          float momentum, float eps, float* __restrict__ out, int C) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c == 0 && nbt) nbt[0] += 1;
-    if (c >= C) return;
-    const double d = (double)s1[c] / count;
-    const double mean = (double)pilot[c] + d;
-    double var = (double)s2[c] / count - d * d;
+// The pilot-form sums of one channel (after the all-reduce over ranks, when the layer is synchronised) -> batch mean, invstd, the folded affine
+// (scale = gamma * invstd, shift = beta - mean * scale) and torch's running-statistics update (biased variance for the normalisation, unbiased
+// for running_var), in double: no host arithmetic between the conv and the normalise pass.
+struct BnFinalArgs {
+    const float* pilot;
+    double count;
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    long long* nbt;
+    float momentum, eps;
+    float* out;          // [4][C]: mean | invstd | gamma * invstd | beta - mean * gamma * invstd
+};
+
+__device__ __forceinline__ void bn_finalize_channel(const BnFinalArgs& a, float s1, float s2, int c, int C) {
+    const double d = (double)s1 / a.count;
+    const double mean = (double)a.pilot[c] + d;
+    double var = (double)s2 / a.count - d * d;
     var = var > 0.0 ? var : 0.0;
-    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float sc = gamma[c] * invstd;
-    out[c] = (float)mean;
-    out[C + c] = invstd;
-    out[2 * C + c] = sc;
-    out[3 * C + c] = beta[c] - (float)mean * sc;
-    if (running_mean) {
-        const double unb = count > 1.0 ? count / (count - 1.0) : 1.0;
-        running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
-        running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * var * unb);
+    const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    const float sc = a.gamma[c] * invstd;
+    a.out[c] = (float)mean;
+    a.out[C + c] = invstd;
+    a.out[2 * C + c] = sc;
+    a.out[3 * C + c] = a.beta[c] - (float)mean * sc;
+    if (a.running_mean) {
+        const double unb = a.count > 1.0 ? a.count / (a.count - 1.0) : 1.0;
+        a.running_mean[c] = (float)((1.0 - (double)a.momentum) * (double)a.running_mean[c] + (double)a.momentum * mean);
+        a.running_var[c] = (float)((1.0 - (double)a.momentum) * (double)a.running_var[c] + (double)a.momentum * var * unb);
     }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ s1, const float* __restrict__ s2, BnFinalArgs a, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c == 0 && a.nbt) a.nbt[0] += 1;
+    if (c < C) bn_finalize_channel(a, s1[c], s2[c], c, C);
+}
+
+// Reduction of the conv epilogue's partial rows [nparts][2][C] (thousands of rows at M = 300 000: one per 64..160 output rows).  Stage 1: workgroup
+// (column group of 32 channels, row split) - thread (q, l) adds rows l, l+32, ... of its split for channels 4q..4q+3 of both planes (16-byte loads,
+// a 128-byte line per row and plane), then lane order 0..31 in LDS -> tmp[split][2][C].  Stage 2: one thread per channel adds the splits in
+// ascending order and, when asked, finalizes the BatchNorm statistics in the same launch.  Every order is fixed: bitwise reproducible.
+constexpr int BN_RED_ROWS = 256;       // partial rows per stage-1 workgroup
+
+__global__ __launch_bounds__(256) void bn_reduce_stage1_kernel(const float* __restrict__ partial, int nparts, int C, float* __restrict__ tmp) {
+    __shared__ f32x4 red[2][32][8];
+    const int q = threadIdx.x & 7, l = threadIdx.x >> 3;
+    const int c = blockIdx.x * 32 + 4 * q;
+    const int r0 = blockIdx.y * BN_RED_ROWS, r1 = min(nparts, r0 + BN_RED_ROWS);
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    if (c < C) {
+        for (int r = r0 + l; r < r1; r += 32) {
+            a0 += *reinterpret_cast<const f32x4*>(partial + ((long)r * 2) * C + c);
+            a1 += *reinterpret_cast<const f32x4*>(partial + ((long)r * 2 + 1) * C + c);
+        }
+    }
+    red[0][l][q] = a0;
+    red[1][l][q] = a1;
+    __syncthreads();
+    if (threadIdx.x < 16 && blockIdx.x * 32 + 4 * (threadIdx.x & 7) < C) {
+        const int pl = threadIdx.x >> 3, qq = threadIdx.x & 7;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < 32; ++k) t += red[pl][k][qq];
+        *reinterpret_cast<f32x4*>(tmp + ((long)blockIdx.y * 2 + pl) * C + blockIdx.x * 32 + 4 * qq) = t;
+    }
+}
+
+template <bool FINALIZE>
+__global__ __launch_bounds__(256) void bn_reduce_stage2_kernel(const float* __restrict__ tmp, int nsplit, int C, float* __restrict__ s1,
+                                                               float* __restrict__ s2, BnFinalArgs a) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (FINALIZE && c == 0 && a.nbt) a.nbt[0] += 1;
+    if (c >= C) return;
+    float t0 = 0.f, t1 = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        t0 += tmp[((long)s * 2) * C + c];
+        t1 += tmp[((long)s * 2 + 1) * C + c];
+    }
+    s1[c] = t0;
+    s2[c] = t1;
+    if (FINALIZE) bn_finalize_channel(a, t0, t1, c, C);
 }
 
 inline int pow2_at_least(int v) {
@@ -278,13 +335,40 @@ extern "C" int mi_bn_colsum2(const void* y_bf16, const float* pilot, long M, int
     return MI_OK;
 }
 
+static int bn_final_args_ok(const MiBnFinal* f) {
+    return f->pilot && f->gamma && f->beta && f->out4 && f->count >= 1.0 && ((f->running_mean == nullptr) == (f->running_var == nullptr));
+}
+
+static BnFinalArgs bn_final_args(const MiBnFinal* f) {
+    BnFinalArgs a;
+    a.pilot = f->pilot, a.count = f->count, a.gamma = f->gamma, a.beta = f->beta, a.running_mean = f->running_mean, a.running_var = f->running_var;
+    a.nbt = f->num_batches_tracked, a.momentum = f->momentum, a.eps = f->eps, a.out = f->out4;
+    return a;
+}
+
+size_t mi_bn_reduce_tmp_floats(int nparts, int C) { return (size_t)((nparts + BN_RED_ROWS - 1) / BN_RED_ROWS) * 2 * (size_t)C; }
+
+int mi_bn_reduce_partials(const float* partial, int nparts, int C, float* tmp, float* s1, float* s2, const MiBnFinal* fin, void* stream) {
+    MI_REQUIRE(partial && tmp && s1 && s2 && nparts > 0 && C > 0 && C % 4 == 0, "mi_bn_reduce_partials: null operand or C=%d not a multiple of 4", C);
+    MI_REQUIRE(!fin || bn_final_args_ok(fin), "mi_bn_reduce_partials: incomplete finalize arguments");
+    const int nsplit = (nparts + BN_RED_ROWS - 1) / BN_RED_ROWS;
+    hipLaunchKernelGGL(bn_reduce_stage1_kernel, dim3((C + 31) / 32, nsplit), dim3(256), 0, (hipStream_t)stream, partial, nparts, C, tmp);
+    if (fin)
+        hipLaunchKernelGGL(bn_reduce_stage2_kernel<true>, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)tmp, nsplit, C, s1, s2,
+                           bn_final_args(fin));
+    else
+        hipLaunchKernelGGL(bn_reduce_stage2_kernel<false>, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)tmp, nsplit, C, s1, s2,
+                           BnFinalArgs{});
+    MI_CHECK_LAUNCH("mi_bn_reduce_partials");
+    return MI_OK;
+}
+
 extern "C" int mi_bn_finalize(const float* s1, const float* s2, const float* pilot, double count, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps, float* out4,
                               int C, void* stream) {
-    MI_REQUIRE(s1 && s2 && pilot && gamma && beta && out4 && C > 0 && count >= 1.0, "mi_bn_finalize: null operand, C=%d, count=%g", C, count);
-    MI_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "mi_bn_finalize: running_mean and running_var go together");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, s1, s2, pilot, count, gamma, beta, running_mean,
-                       running_var, num_batches_tracked, momentum, eps, out4, C);
+    const MiBnFinal f{pilot, count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, out4};
+    MI_REQUIRE(s1 && s2 && C > 0 && bn_final_args_ok(&f), "mi_bn_finalize: null operand, C=%d, count=%g", C, count);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, s1, s2, bn_final_args(&f), C);
     MI_CHECK_LAUNCH("mi_bn_finalize");
     return MI_OK;
 }

@@ -23,7 +23,20 @@ struct IgemmParams {
     float alpha;                  // LeakyReLU negative slope (MI_EPI_LEAKY)
     int m_tiles, n_tiles;
     int korder;                   // igemm_pp_kernel: 0 = contraction runs tap-major (tap, then channels), 1 = channel-chunk-major (all taps of a chunk)
+    // MI_EPI_STATS (compile-time epilogue sets only): per wave row tile (MT*16 rows) and channel, sum (o - pilot) and sum (o - pilot)^2 of the
+    // bf16-rounded outputs o: stats[row tile][2][N] fp32, row tile = first row of the wave / (MT*16); reduced in a fixed order afterwards
+    float* stats;
+    const float* pilot;
 };
+
+// sum over the 16 lanes of a DPP row (lanes sharing lane >> 4); every lane receives the total
+__device__ __forceinline__ float igemm_row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));     // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));     // row_mirror
+    return v;
+}
 
 __device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -78,6 +91,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
                                                bf16x8 (&pres)[MT][2], unsigned (&pbits)[MT], char* stage = nullptr, bool mask_lds = false,
                                                const int* mrow = nullptr) {
     const int flags = EPI >= 0 ? EPI : p.flags;
+    constexpr bool STATS = EPI >= 0 && (EPI & MI_EPI_STATS) != 0;
+    float st0[STATS ? 16 : 1], st1[STATS ? 16 : 1];
     // ---- epilogue: lane owns pixel m (D col) and two groups of 8 contiguous channels: h = 0 -> nb .. nb+7 (MFMA tiles 0, 1),
     //      h = 1 -> nb+32 .. nb+39 (tiles 2, 3); tile i holds channels nb + 32*(i>>1) + 4*(i&1) + (0..3) ------------------------
     const int nb = n0 + wn * 64 + 8 * fq;
@@ -90,6 +105,18 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
             esc[i] = *reinterpret_cast<const f32x4*>(p.scale + n);
             ebi[i] = *reinterpret_cast<const f32x4*>(p.bias + n);
         }
+    }
+    f32x4 epil[4];                      // MI_EPI_STATS: the pilot (running mean) of this lane's 16 channels
+    if constexpr (STATS) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ni = nb + 32 * (i >> 1) + 4 * (i & 1);
+            epil[i] = *reinterpret_cast<const f32x4*>(p.pilot + ((ni < p.N) ? ni : 0));
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) st0[k] = st1[k] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(epil[i]));
     }
     // Everything the row loop below consumes must have LANDED before the loop: the loop body sits behind per-row exec-mask
     // branches (m < M, n < N), and hipcc places the s_waitcnt for a pending load inside the first conditional block that uses
@@ -217,11 +244,38 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
                     bf16x8 hv;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) hv[e] = (__bf16)v[2 * h + (e >> 2)][e & 3];
+                    if constexpr (STATS) {      // of the value as stored: what a statistics pass over the output tensor would read
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float d = (float)hv[e] - epil[2 * h + (e >> 2)][e & 3];
+                            st0[8 * h + e] += d;
+                            st1[8 * h + e] += d * d;
+                        }
+                    }
                     if (STAGED) {
                         const int row = wm * (MT * 16) + j * 16 + frow;
                         *reinterpret_cast<bf16x8*>(stage + row * 256 + (((wn * 8 + h * 4 + fq) ^ (row & 15)) << 4)) = hv;
                     } else {
                         *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.out) + o + 32 * h) = hv;
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (STATS) {
+        // rows: this lane's MT pixels are summed above; the 16 lanes of a DPP row hold the other pixels of the same 16 channels
+#pragma unroll
+        for (int k = 0; k < 16; ++k) st0[k] = igemm_row16_sum(st0[k]), st1[k] = igemm_row16_sum(st1[k]);
+        if (frow == 0) {
+            const long rt = (m0 + wm * (MT * 16)) / (MT * 16);
+            float* dst = p.stats + rt * 2 * (long)p.N;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (nb + 32 * h < p.N) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        *reinterpret_cast<f32x4*>(dst + nb + 32 * h + 4 * q) = f32x4{st0[8 * h + 4 * q], st0[8 * h + 4 * q + 1], st0[8 * h + 4 * q + 2], st0[8 * h + 4 * q + 3]};
+                        *reinterpret_cast<f32x4*>(dst + p.N + nb + 32 * h + 4 * q) = f32x4{st1[8 * h + 4 * q], st1[8 * h + 4 * q + 1], st1[8 * h + 4 * q + 2], st1[8 * h + 4 * q + 3]};
                     }
                 }
             }

@@ -326,6 +326,9 @@ void launch_variant(dim3 grid, hipStream_t stream, const IgemmParams& p) {
         if (fl == 71) return launch_one<MT, UNIT, PREF, BKT, 71, NWN>(grid, stream, p);
         if (fl == 130) return launch_one<MT, UNIT, PREF, BKT, 130, NWN>(grid, stream, p);
     }
+    if constexpr (!PREF && NWN == 2) {
+        if (fl == MI_EPI_STATS) return launch_one<MT, UNIT, PREF, BKT, MI_EPI_STATS, NWN>(grid, stream, p);      // plain store + BatchNorm tile statistics
+    }
     launch_one<MT, UNIT, PREF, BKT, -1, NWN>(grid, stream, p);
 }
 
@@ -350,7 +353,39 @@ extern "C" int mi_conv_gemm_route(int B, int Ha, int Wa, int Ca, int Ho, int Wo,
 extern "C" int mi_conv_gemm(const void* a, const void* wp, void* out, int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N,
                             int ksize, int stride, int pad, int dil, int gather_mode, const float* scale, const float* bias,
                             const void* res, const void* msk, void* mask_out, int flags, int zgw, float alpha, void* stream) {
+    return mi_conv_gemm_impl(a, wp, out, B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, pad, dil, gather_mode, scale, bias, res, msk, mask_out, flags, zgw, alpha,
+                             stream, nullptr);
+}
+
+extern "C" size_t mi_conv_gemm_stats_workspace(long M, int N) {
+    const long rows = (M + 63) / 64 + 2;               // the shortest wave row tile is 64 rows
+    return ((size_t)rows * 2 * (size_t)N + mi_bn_reduce_tmp_floats((int)rows, N)) * sizeof(float);
+}
+
+extern "C" int mi_conv_gemm_stats(const void* a, const void* wp, void* out, int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N, int ksize, int stride,
+                                  int pad, int dil, const float* pilot, float* sums, void* workspace, size_t workspace_bytes, const float* gamma,
+                                  const float* beta, float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps,
+                                  float* out4, void* stream) {
+    MI_REQUIRE(pilot && sums && workspace && mi_aligned16(pilot) && mi_aligned16(workspace), "mi_conv_gemm_stats: null or unaligned statistics operand");
+    MI_REQUIRE(B > 0 && Ho > 0 && Wo > 0 && N > 0 && N % 8 == 0, "mi_conv_gemm_stats: N=%d", N);
+    const long M = (long)B * Ho * Wo;
+    MI_REQUIRE(workspace_bytes >= mi_conv_gemm_stats_workspace(M, N), "mi_conv_gemm_stats: workspace of %zu bytes, need %zu", workspace_bytes,
+               mi_conv_gemm_stats_workspace(M, N));
+    MI_REQUIRE((gamma == nullptr) == (out4 == nullptr), "mi_conv_gemm_stats: gamma and out4 go together (finalize in the same call) or are both NULL");
+    MiConvStats st{(float*)workspace, pilot, 0};
+    const int rc = mi_conv_gemm_impl(a, wp, out, B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, pad, dil, MI_GATHER_FWD, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                     MI_EPI_STATS, 0, 0.f, stream, &st);
+    if (rc != MI_OK) return rc;
+    float* tmp = (float*)workspace + ((M + 63) / 64 + 2) * 2 * (long)N;
+    const MiBnFinal fin{pilot, (double)M, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, out4};
+    return mi_bn_reduce_partials((const float*)workspace, st.nparts, N, tmp, sums, sums + N, gamma ? &fin : nullptr, stream);
+}
+
+int mi_conv_gemm_impl(const void* a, const void* wp, void* out, int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N, int ksize, int stride, int pad,
+                      int dil, int gather_mode, const float* scale, const float* bias, const void* res, const void* msk, void* mask_out, int flags,
+                      int zgw, float alpha, void* stream, MiConvStats* st) {
     MI_REQUIRE(a && wp && out, "mi_conv_gemm: null operand");
+    MI_REQUIRE(((flags & MI_EPI_STATS) != 0) == (st != nullptr) && (!st || flags == MI_EPI_STATS), "mi_conv_gemm: MI_EPI_STATS comes alone, through mi_conv_gemm_stats");
     MI_REQUIRE(B > 0 && Ha > 0 && Wa > 0 && Ho > 0 && Wo > 0 && N > 0, "mi_conv_gemm: non-positive dimension");
     MI_REQUIRE(Ca > 0 && Ca % 64 == 0, "mi_conv_gemm: Ca=%d must be a multiple of 64", Ca);
     MI_REQUIRE(N % 8 == 0, "mi_conv_gemm: N=%d must be a multiple of 8", N);
@@ -378,10 +413,12 @@ extern "C" int mi_conv_gemm(const void* a, const void* wp, void* out, int B, int
     // are epilogue-bound and stay here.  MI_IGEMM_PP=0 switches the dispatch off.
     if (mi_conv_gemm_route(B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, flags) &&
         (long)B * Ha * Wa * Ca * 2 + 2L * ((long)(ksize - 1) * dil + pad) * (Wa + 1) * Ca * 2 < (1L << 31) - (1L << 20))     // its exact 32-bit offset bound
-        return mi_conv_gemm_pp(a, wp, out, B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, pad, dil, gather_mode, scale, bias, res, msk, mask_out, flags, zgw,
-                               alpha, 0, stream);
+        return mi_conv_gemm_pp_impl(a, wp, out, B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, pad, dil, gather_mode, scale, bias, res, msk, mask_out, flags, zgw,
+                                    alpha, 0, stream, st);
     IgemmParams p;
     p.korder = 0;
+    p.stats = st ? st->partial : nullptr;
+    p.pilot = st ? st->pilot : nullptr;
     p.A = (const __bf16*)a;
     p.Wp = (const __bf16*)wp;
     p.out = out;
@@ -448,27 +485,28 @@ extern "C" int mi_conv_gemm(const void* a, const void* wp, void* out, int B, int
     p.m_tiles = (int)((M + bm - 1) / bm);
     p.n_tiles = (N + bn - 1) / bn;
     const dim3 grid(p.m_tiles * p.n_tiles);
-    const hipStream_t st = (hipStream_t)stream;
+    if (st) st->nparts = 2 * p.m_tiles;                  // one partial row per wave row (MT*16 rows)
+    const hipStream_t sq = (hipStream_t)stream;
     if (!unit)
-        launch_variant<4, false, false, 64, 2>(grid, st, p);
+        launch_variant<4, false, false, 64, 2>(grid, sq, p);
 #ifdef MI_EXPERIMENTS
     else if (bn == 256 && mt_sel == 6)
-        launch_variant<6, true, false, 64, 4>(grid, st, p);
+        launch_variant<6, true, false, 64, 4>(grid, sq, p);
     else if (bn == 256 && mt_sel == 5)
-        launch_variant<5, true, false, 64, 4>(grid, st, p);
+        launch_variant<5, true, false, 64, 4>(grid, sq, p);
     else if (bn == 256)
-        launch_variant<4, true, false, 64, 4>(grid, st, p);
+        launch_variant<4, true, false, 64, 4>(grid, sq, p);
 #endif
     else if (pref && mt_sel == 5)
-        launch_variant<5, true, true, 64, 2>(grid, st, p);
+        launch_variant<5, true, true, 64, 2>(grid, sq, p);
     else if (pref)
-        launch_variant<4, true, true, 64, 2>(grid, st, p);
+        launch_variant<4, true, true, 64, 2>(grid, sq, p);
     else if (mt_sel == 6)
-        launch_variant<6, true, false, 64, 2>(grid, st, p);
+        launch_variant<6, true, false, 64, 2>(grid, sq, p);
     else if (mt_sel == 5)
-        launch_variant<5, true, false, 64, 2>(grid, st, p);
+        launch_variant<5, true, false, 64, 2>(grid, sq, p);
     else
-        launch_variant<4, true, false, 64, 2>(grid, st, p);
+        launch_variant<4, true, false, 64, 2>(grid, sq, p);
     MI_CHECK_LAUNCH("mi_conv_gemm");
     return MI_OK;
 }

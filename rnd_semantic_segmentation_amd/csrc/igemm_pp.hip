@@ -566,6 +566,7 @@ void launch_pp_flags(dim3 grid, hipStream_t stream, const IgemmParams& p) {
     if (p.flags == 0) return launch_pp<MTG, 0>(grid, stream, p);         // plain bf16 store (downsample data gradient, ASPP data gradient)
     if (p.flags == 1) return launch_pp<MTG, 1>(grid, stream, p);         // FrozenBN only (downsample forward)
     if (p.flags == 48) return launch_pp<MTG, 48>(grid, stream, p);       // fp32 tap planes (ASPP forward)
+    if (p.flags == MI_EPI_STATS) return launch_pp<MTG, MI_EPI_STATS>(grid, stream, p);      // plain store + BatchNorm tile statistics
     launch_pp<MTG, -1>(grid, stream, p);
 }
 
@@ -583,7 +584,15 @@ extern "C" int mi_pp_clock_read(unsigned* host) { return (int)hipMemcpyFromSymbo
 extern "C" int mi_conv_gemm_pp(const void* a, const void* wp, void* out, int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N, int ksize,
                                int stride, int pad, int dil, int gather_mode, const float* scale, const float* bias, const void* res,
                                const void* msk, void* mask_out, int flags, int zgw, float alpha, int mtg, void* stream) {
+    return mi_conv_gemm_pp_impl(a, wp, out, B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, pad, dil, gather_mode, scale, bias, res, msk, mask_out, flags, zgw, alpha,
+                                mtg, stream, nullptr);
+}
+
+int mi_conv_gemm_pp_impl(const void* a, const void* wp, void* out, int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N, int ksize, int stride, int pad,
+                         int dil, int gather_mode, const float* scale, const float* bias, const void* res, const void* msk, void* mask_out, int flags,
+                         int zgw, float alpha, int mtg, void* stream, MiConvStats* st) {
     MI_REQUIRE(a && wp && out, "mi_conv_gemm_pp: null operand");
+    MI_REQUIRE(((flags & MI_EPI_STATS) != 0) == (st != nullptr) && (!st || flags == MI_EPI_STATS), "mi_conv_gemm_pp: MI_EPI_STATS comes alone, through mi_conv_gemm_stats");
     MI_REQUIRE(B > 0 && Ha > 0 && Wa > 0 && N > 0, "mi_conv_gemm_pp: non-positive dimension");
     MI_REQUIRE(stride == 1 && Ha == Ho && Wa == Wo, "mi_conv_gemm_pp: stride-1, same-size convolutions only");
     MI_REQUIRE(Ca > 0 && Ca % 32 == 0, "mi_conv_gemm_pp: Ca=%d must be a multiple of 32", Ca);
@@ -625,6 +634,8 @@ extern "C" int mi_conv_gemm_pp(const void* a, const void* wp, void* out, int B, 
     p.flags = flags;
     p.zgw = zgw > 0 ? zgw : 4;
     p.alpha = alpha;
+    p.stats = st ? st->partial : nullptr;
+    p.pilot = st ? st->pilot : nullptr;
     p.korder = ksize > 1 ? mi_sw().pp_korder : 0;              // MI_IGEMM_PP_KORDER=0: tap-major contraction (the order of igemm_nt_kernel; bit-equal to it)
 #ifdef MI_PP_TRACE
     p.korder |= mi_sw().pp_trace_wg << 8;
@@ -663,6 +674,7 @@ extern "C" int mi_conv_gemm_pp(const void* a, const void* wp, void* out, int B, 
     p.m_tiles = (int)((M + bm - 1) / bm);
     p.n_tiles = (N + 255) / 256;
     const dim3 grid(p.m_tiles * p.n_tiles);
+    if (st) st->nparts = 2 * p.m_tiles;                    // one partial row per wave group (MTG*16 rows)
     if (mtg == 10) launch_pp_flags<10>(grid, (hipStream_t)stream, p);
     else launch_pp_flags<8>(grid, (hipStream_t)stream, p);
     MI_CHECK_LAUNCH("mi_conv_gemm_pp");

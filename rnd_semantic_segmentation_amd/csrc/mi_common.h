@@ -40,6 +40,36 @@ struct MiSwitches {
 };
 const MiSwitches& mi_sw();
 
+// Epilogue statistics of a conv launch (MI_EPI_STATS): where the per-row-tile partial sums go, the pilot they are taken against, and (out) how
+// many partial rows the launch wrote - the tile height is the launcher's choice.  Internal linkage between igemm_nt.hip, igemm_pp.hip, batchnorm.hip.
+struct MiConvStats {
+    float* partial;        // [rows][2][N] fp32, rows <= mi_conv_gemm_stats_workspace's bound
+    const float* pilot;    // [N]
+    int nparts;            // out
+};
+int mi_conv_gemm_impl(const void* a, const void* wp, void* out, int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N, int ksize, int stride, int pad,
+                      int dil, int gather_mode, const float* scale, const float* bias, const void* res, const void* msk, void* mask_out, int flags,
+                      int zgw, float alpha, void* stream, MiConvStats* st);
+int mi_conv_gemm_pp_impl(const void* a, const void* wp, void* out, int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N, int ksize, int stride, int pad,
+                         int dil, int gather_mode, const float* scale, const float* bias, const void* res, const void* msk, void* mask_out, int flags,
+                         int zgw, float alpha, int mtg, void* stream, MiConvStats* st);
+// BatchNorm finalize arguments (mi_bn_finalize's), for launches that finalize in the same kernel as their last reduction level
+struct MiBnFinal {
+    const float* pilot;
+    double count;
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    long long* num_batches_tracked;
+    float momentum, eps;
+    float* out4;
+};
+// fixed-order sum of `nparts` partial rows [part][2][C] into s1[C], s2[C] in two launches (batchnorm.hip); tmp: mi_bn_reduce_tmp_floats(nparts, C)
+// floats; fin != NULL: the second launch also finalizes the statistics
+size_t mi_bn_reduce_tmp_floats(int nparts, int C);
+int mi_bn_reduce_partials(const float* partial, int nparts, int C, float* tmp, float* s1, float* s2, const MiBnFinal* fin, void* stream);
+
 #define MI_REQUIRE(cond, ...)                         \
     do {                                              \
         if (!(cond)) return mi_set_error(MI_EINVAL, __VA_ARGS__); \

@@ -390,8 +390,13 @@ class StageEngine:
     def _bn_unit(x, rt, relu, res=None):
         """conv (plain store) -> batch statistics -> normalise (+ residual) (+ ReLU, + sign bits).  Returns (out, y, fin, count, bits)."""
         c = rt.spec
-        y = K.conv_gemm(x, rt.wp, arch.out_hw(x.shape[1], x.shape[2], c), c.k, c.stride, c.pad, c.dil, K.GATHER_FWD)
-        fin, count = bn_batch_statistics(y, rt.bn)
+        synced = _bn_synced(rt.bn)
+        y, s1, s2, fin = K.conv_gemm_stats(x, rt.wp, arch.out_hw(x.shape[1], x.shape[2], c), c.k, c.stride, c.pad, c.dil, bn_pilot(rt.bn, x.device),
+                                          bn=None if synced else rt.bn)
+        if synced:          # the raw sums are exchanged first, then finalized over the global pixel count
+            fin, count = bn_batch_statistics(y, rt.bn, (s1, s2))
+        else:
+            count = y.numel() // y.shape[-1]
         if relu:
             out, bits = K.bn_apply(y, fin[0], fin[2], rt.bn.bias.detach(), res=res, relu=True, want_mask=True)
         else:
@@ -480,16 +485,21 @@ def _bn_synced(bn):
     return getattr(bn, "_mi_sync", False) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
-def bn_batch_statistics(y, bn):
+def bn_batch_statistics(y, bn, sums=None):
     """BatchNorm2d in train() on the raw conv output y (NHWC bf16): ([mean | invstd | gamma * invstd | beta - mean * gamma * invstd], pixel count over
-    the ranks that share the statistics).  One pass over y (sums of y - pilot and (y - pilot)^2 with the running mean as the pilot: identical on
-    every rank, and close enough to the batch mean that var = E[d^2] - E[d]^2 loses 2-3 of fp32's 24 bits), the all-reduce of the raw sums when
-    the layer is synchronised, and one finalize launch that also updates the running statistics as torch does - no host arithmetic in between."""
+    the ranks that share the statistics).  The sums of y - pilot and (y - pilot)^2 (pilot = the running mean: identical on every rank, and close
+    enough to the batch mean that var = E[d^2] - E[d]^2 loses 2-3 of fp32's 24 bits) come out of the conv's epilogue (`sums`) or from one pass over
+    y; then the all-reduce of the raw sums when the layer is synchronised, and one finalize launch that also updates the running statistics as torch
+    does - no host arithmetic in between."""
     C = y.shape[-1]
-    pilot = bn.running_mean if bn.running_mean is not None else torch.zeros(C, dtype=torch.float32, device=y.device)
-    s1, s2 = K.bn_colsum2(y, pilot)
+    pilot = bn_pilot(bn, y.device)
+    s1, s2 = sums if sums is not None else K.bn_colsum2(y, pilot)
     count = (y.numel() // C) * _bn_allreduce(bn, s1, s2)
     return K.bn_finalize(s1, s2, pilot, count, bn), count
+
+
+def bn_pilot(bn, device):
+    return bn.running_mean if bn.running_mean is not None else torch.zeros(bn.num_features, dtype=torch.float32, device=device)
 
 
 def bn_backward(g, y, fin, count, bn, bits=None):

@@ -151,6 +151,37 @@ def conv_gemm(a, wp, out_hw, ksize=1, stride=1, pad=0, dil=1, mode=GATHER_FWD, s
 _ws_cache = {}
 
 
+def conv_gemm_stats(a, wp, out_hw, ksize, stride, pad, dil, pilot, bn=None):
+    """conv_gemm with a plain bf16 store that also returns the BatchNorm statistics of its output, taken in the epilogue: (out, s1, s2, fin) with
+    s1[n] = sum (out - pilot[n]), s2[n] = sum (out - pilot[n])^2 (rows of one [2, N] buffer) - bn_colsum2(out, pilot) without the extra read.
+    bn (an nn.BatchNorm2d whose statistics are NOT shared across ranks): the last reduction launch also finalizes them (bn_finalize's result `fin`
+    and running-statistics update, count = the pixels of this tensor); otherwise fin is None."""
+    _chk(a, torch.bfloat16, "a")
+    _chk(wp, torch.bfloat16, "wp")
+    _chk(pilot, torch.float32, "pilot")
+    B, Ha, Wa, Ca = a.shape
+    T, N, Cw = wp.shape
+    if T != ksize * ksize or Cw != Ca:
+        raise _lib.MiError("packed weight %s does not match ksize=%d, Ca=%d" % (tuple(wp.shape), ksize, Ca))
+    Ho, Wo = out_hw
+    out = torch.empty((B, Ho, Wo, N), dtype=torch.bfloat16, device=a.device)
+    sums = torch.empty((2, N), dtype=torch.float32, device=a.device)
+    ws = _workspace(int(_lib.lib().mi_conv_gemm_stats_workspace(B * Ho * Wo, N)), a.device, "conv_stats")
+    fin, fa = None, (None, None, None, None, None, 0.0, 0.0, None)
+    if bn is not None:
+        track = bn.track_running_stats and bn.running_mean is not None
+        if track and bn.momentum is None:
+            raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative average) is not used by the reference")
+        fin = torch.empty((4, N), dtype=torch.float32, device=a.device)
+        fa = (_p(bn.weight.detach()), _p(bn.bias.detach()), _p(bn.running_mean) if track else None, _p(bn.running_var) if track else None,
+              _p(bn.num_batches_tracked) if track else None, float(bn.momentum or 0.0), float(bn.eps), _p(fin))
+    flops = 2.0 * B * Ho * Wo * N * Ca * ksize * ksize
+    _timed("igemm_stats", flops, lambda: check(_lib.lib().mi_conv_gemm_stats(_p(a), _p(wp), _p(out), B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, pad, dil, _p(pilot),
+                                                                             _p(sums), _p(ws), ws.numel(), *fa, _stream()), "mi_conv_gemm_stats"),
+           ("fwd", ksize, Ca, N, B * Ho * Wo, 512, dil))
+    return out, sums[0], sums[1], fin
+
+
 def _workspace(nbytes, device, tag="ws"):
     # one buffer per (purpose, device, stream): launches on one stream are ordered, so they can share it; two streams cannot
     key = (tag, str(device), torch.cuda.current_stream().cuda_stream)

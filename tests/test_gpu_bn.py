@@ -266,8 +266,19 @@ if rank == 0:
     print("SYNCBN feat rel %.3e identical %.4f grad worst 1-cos %.3e norm ratio dev %.3e" % (r_feat, same, worst, ratio))
     # (a 1e-7 difference in a mean flips a bf16 rounding here and there, and twenty layers later most elements differ in the last bit:
     #  measured 1.4e-2 of the feature range, 42 % of the elements bit-identical, gradients 1 - cos 1.3e-2)
-    assert r_feat < 4e-2, (r_feat, same)
-    assert worst < 4e-2 and ratio < 6e-2, (worst, ratio)
+    # The yardstick for "equal": two FULL-batch runs whose inputs differ by one bf16 rounding in ONE element drift just as far apart (measured:
+    # features 1.8e-2, gradients 1 - cos 3.1e-2, norm ratio 4.3e-2; 16 elements: 8.2e-2 - tools/dbg/bn_chaos.py), so the fixed bars of the first
+    # version (4e-2 / 6e-2) sat inside that noise.  The synchronised run may deviate at most twice as far as that one-element perturbation does.
+    xp = xt.clone()
+    xp.view(-1)[12345] *= 1.0 + 2.0 ** -7
+    feat_p, g_p = run(build(False), xp)
+    f_feat = rel(feat_p[:2], feat_f[:2])
+    f_cos = max(1 - float(torch.dot(g_p[k].flatten().double(), g_f[k].flatten().double()) / (g_p[k].double().norm() * g_f[k].double().norm() + 1e-300))
+                for k in g_f if g_f[k].double().norm() > 1e-6)
+    f_ratio = max(abs(float(g_p[k].double().norm() / g_f[k].double().norm()) - 1) for k in g_f if g_f[k].double().norm() > 1e-6)
+    print("SYNCBN yardstick (one input element off by one bf16 ulp): feat rel %.3e grad worst 1-cos %.3e norm ratio dev %.3e" % (f_feat, f_cos, f_ratio))
+    assert r_feat < max(4e-2, 2 * f_feat), (r_feat, same, f_feat)
+    assert worst < max(4e-2, 2 * f_cos) and ratio < max(6e-2, 2 * f_ratio), (worst, ratio, f_cos, f_ratio)
     # without the exchange the halves normalise with their own statistics: visibly different features
     feat_l, _ = run(build(False), half)
     assert rel(feat_l, feat_f[:2]) > 5 * r_feat

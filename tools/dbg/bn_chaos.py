@@ -1,0 +1,31 @@
+"""How far do two runs of the trainable-BatchNorm tinynet drift apart when the input differs by one bf16 rounding in a few pixels?  The yardstick
+for tests/test_gpu_bn.py::test_synchronised_batchnorm_two_ranks_equal_the_full_batch (synchronised halves vs the full batch differ by the fp32
+summation order of the exchanged sums): feature deviation, worst gradient 1 - cos and norm-ratio deviation between two FULL-batch runs."""
+import os, sys, torch
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import _cases
+from rnd_semantic_segmentation_amd.host import modules, synth
+x, _ = _cases.net_inputs(4, 65, 17)
+xt = torch.from_numpy(x).cuda()
+def build():
+    fe = modules.resnet_feature_extractor("resnet101", freeze_bn=False, pretrained_backbone=False, layers=(1, 1, 2, 2))
+    synth.load_formula_weights(fe)
+    fe = fe.cuda().train(); fe.ensure_flat()
+    return fe
+def run(inp):
+    fe = build()
+    feat = fe(inp)
+    feat.float().square().mean().backward()
+    return feat.detach().float(), {k: p.grad.detach().clone() for k, p in fe.named_parameters()}
+fa, ga = run(xt)
+for trial, npix in enumerate((1, 16, 256)):
+    xp = xt.clone()
+    idx = torch.randperm(xp.numel(), device="cuda")[:npix]
+    xp.view(-1)[idx] *= 1.0 + 2.0 ** -7          # one bf16 ulp
+    fb, gb = run(xp)
+    rel = float((fa - fb).abs().max() / fa.abs().max())
+    same = float((fa == fb).float().mean())
+    worst = max(1 - float(torch.dot(ga[k].flatten().double(), gb[k].flatten().double()) / (ga[k].double().norm() * gb[k].double().norm() + 1e-300)) for k in ga if ga[k].double().norm() > 1e-6)
+    ratio = max((abs(float(gb[k].double().norm() / ga[k].double().norm()) - 1), k) for k in ga if ga[k].double().norm() > 1e-6)
+    print("perturb %4d inputs by one bf16 ulp: feat rel %.3e identical %.4f  grad worst 1-cos %.3e  norm ratio dev %.3e (%s)" % (npix, rel, same, worst, ratio[0], ratio[1]))
