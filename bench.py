@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md chip table
+INST = 3                       # instrumented steps (HIP events around every launch) run AFTER the timed region
 PEAK_HBM_TBS = 8.0             # HBM3E peak, same table (6.29 TB/s measured with a float4 copy)
 ALG_GFLOP_PER_IMAGE = 2518.5   # fwd + dgrad + wgrad of all 108 convs at 769x769
 
@@ -94,6 +95,154 @@ def cpu_baseline(size, budget_s=40.0):
             "sample": "%d full train steps (fwd+CE+bwd+2xSGD) of B=1 %dx%d fp32 after 1 warm-up, oracle/ref_model.py" % (n, size, size)}
 
 
+
+# ------------------------------------------------------------------------------------------------ the other two models of train_src.py
+def aux_workload(args, device):
+    """--workload pranet: BASELINE config[3] (configs/pranet_src_polyp.yaml: PraNet / Res2Net-50, batch 16, 352 x 352): one optimizer step = forward,
+    four structure losses, backward, clamped Adam - the pass of the trainer's three-scale loop at rate 1 (pranet_trainer.py:44-61).
+    --workload gald: configs/gald_src.yaml (HarDNet-68 encoder + GCPA decoder, batch 6, 1280 x 720): forward, four cross-entropies, backward, both Adams
+    (gald_trainer.py).  Same JSON contract as the default workload: whole-step images/s, `roofline` for the dominant kernel of INST instrumented steps
+    (HIP events around every launch), `cpu_baseline` = the oracle's torch-CPU restatement of the same step on the granted cores."""
+    from rnd_semantic_segmentation_amd import kernels
+    from rnd_semantic_segmentation_amd.host import gald, pranet, synth
+    torch.manual_seed(0)
+    if args.workload == "pranet":
+        B, H, W = args.batch or 16, args.size or 352, args.size or 352
+        net = pranet.PraNet().to(device).train()
+        net.ensure_flat()
+        opt = pranet.FlatAdam(net, 1e-4 / 8, grad_clamp=0.5)
+        img, mask = synth.synth_polyp(B, H, W, seed=3)
+        x, gt = torch.from_numpy(img).to(device), torch.from_numpy(mask).to(device)
+
+        def step():
+            opt.zero_grad()
+            ls = [pranet.structure_loss(o, gt) for o in net(x)]
+            (ls[3] + ls[2] + ls[1] + ls[0]).backward()
+            opt.step()
+            return ls[3]
+        graphed = None
+        if os.environ.get("MI_GRAPH", "1") == "1":        # the trainer's MI_GRAPH mode: the whole step as one HIP graph (bit-equal to eager: tests/test_gpu_pranet.py)
+            graphed = pranet.GraphedStep(net, opt, x, gt)
+        runner = (lambda: graphed()[3]) if graphed else step
+        metric = "train images/sec at %dx%d bf16 (PraNet Res2Net-50, BASELINE config[3])" % (H, W)
+        workload = "configs/pranet_src_polyp.yaml: PraNet, one optimizer step (the rate-1 pass of the three-scale loop), B=%d %dx%d" % (B, H, W)
+    else:
+        B, H, W = args.batch or 6, 720, 1280
+        enc, dec = gald.GCPAEncoder().to(device).train(), gald.GCPADecoder().to(device).train()
+        enc.ensure_flat()
+        dec.ensure_flat()
+        oe, od = pranet.FlatAdam(enc, 1e-4), pranet.FlatAdam(dec, 1e-3)
+        x = torch.from_numpy(synth.synth_image(B, H, W, seed=9)).to(device)
+        lab = torch.from_numpy(synth.synth_label(B, H, W, 19, seed=9)).to(device).long()
+
+        def step():
+            oe.zero_grad()
+            od.zero_grad()
+            l5, l4, l3, l2 = dec.losses(x, enc(x), lab)
+            loss = l2 * 1 + l3 * 0.8 + l4 * 0.6 + l5 * 0.4
+            loss.backward()
+            oe.step()
+            od.step()
+            return loss
+        graphed, runner = None, step
+        metric = "train images/sec at %dx%d bf16 (GALD: HarDNet-68 + GCPA decoder)" % (W, H)
+        workload = "configs/gald_src.yaml: GALD, one training step, B=%d %dx%d" % (B, W, H)
+    note("warm-up")
+    for _ in range(args.warmup):
+        loss = runner()
+    torch.cuda.synchronize()
+    note("timed region")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = runner()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    out = {"metric": metric, "value": round(B / dt, 2), "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+           "data": "synthetic, random-init weights", "config": {"workload": workload, "hip_graph": bool(graphed)}, "loss": round(float(loss), 4)}
+    if not args.no_kernel_events:
+        note("instrumented steps (eager, HIP events per launch)")
+        events = []
+        kernels.PROFILE = events
+        for _ in range(INST):
+            step()
+        kernels.PROFILE = None
+        torch.cuda.synchronize()
+        by = {}
+        for name, e0, e1, flops, tag in events:
+            v = by.setdefault(name, [0.0, 0.0, 0])
+            v[0] += e0.elapsed_time(e1) * 1e-3
+            v[1] += flops
+            v[2] += 1
+        tot = sum(v[0] for v in by.values())
+        conv_fl = sum(v[1] for v in by.values())
+        dom = max(by, key=lambda k: by[k][0])
+        tsec, fl, n = by[dom]
+        out["roofline"] = {"kernel": dom, "bound": "mfma" if fl else "hbm", "achieved": round(fl / tsec / 1e12, 2) if fl else None, "peak": PEAK_BF16_TFLOPS if fl else PEAK_HBM_TBS,
+                           "unit": "TFLOP/s" if fl else "TB/s", "frac": round(fl / tsec / 1e12 / PEAK_BF16_TFLOPS, 4) if fl else None, "traffic": None,
+                           "launches_per_step": n // INST, "avg_launch_us": round(1e6 * tsec / n, 2), "ms_per_step_in_kernel": round(1e3 * tsec / INST, 3),
+                           "note": "dominant = largest total launch time over %d eager instrumented steps after the timed region; algorithmic FLOPs = 2 * pixels * "
+                                   "C_out * C_in * taps per launch (SURVEY 8d); the convs of this net are short contractions (26 .. 512 channels) at 22 .. 176 "
+                                   "pixels a side: launch-latency and HBM-bound, far from the MFMA peak" % INST}
+        out["whole_step_mfma_frac"] = round(conv_fl / INST / dt / 1e12 / PEAK_BF16_TFLOPS, 4)
+        out["conv_gflop_per_step"] = round(conv_fl / INST / 1e9, 1)
+        out["kernels"] = {k: {"ms_per_step": round(1e3 * v[0] / INST, 3), "launches_per_step": v[2] // INST, "share": round(v[0] / tot, 3),
+                              "tflops": round(v[1] / v[0] / 1e12, 1) if v[1] else None} for k, v in sorted(by.items(), key=lambda kv: -kv[1][0])[:14]}
+        out["launches_per_step"] = sum(v[2] for v in by.values()) // INST
+    if not args.no_cpu_baseline:
+        note("CPU baseline (oracle port)")
+        out["cpu_baseline"] = aux_cpu_baseline(args.workload, H, W)
+    print(json.dumps(out), flush=True)
+
+
+def aux_cpu_baseline(workload, H, W, budget_s=30.0):
+    """The oracle's torch-CPU restatement of the same step (kind 'port'), bounded sample: B = 2 (BatchNorm needs a batch), fp32."""
+    import torch.nn.functional as F
+    from rnd_semantic_segmentation_amd.host import synth
+    cores = granted_cores()
+    torch.set_num_threads(cores)
+    Bc = 2
+    if workload == "pranet":
+        from oracle import ref_pranet
+        net = ref_pranet.PraNet().train()
+        opt = torch.optim.Adam(net.parameters(), 1e-4)
+        img, mask = synth.synth_polyp(Bc, H, W, seed=3)
+        x, gt = torch.from_numpy(img).float(), torch.from_numpy(mask).float()
+
+        def step():
+            opt.zero_grad()
+            outs = net(x)
+            sum(ref_pranet.structure_loss(o, gt) for o in outs).backward()
+            for group in opt.param_groups:
+                for p in group["params"]:
+                    if p.grad is not None:
+                        p.grad.data.clamp_(-0.5, 0.5)
+            opt.step()
+        what = "oracle/ref_pranet.py"
+    else:
+        from oracle import ref_gald
+        enc, dec = ref_gald.GCPAEncoder().train(), ref_gald.GCPADecoder().train()
+        oe, od = torch.optim.Adam(enc.parameters(), 1e-4), torch.optim.Adam(dec.parameters(), 1e-3)
+        x = torch.from_numpy(synth.synth_image(Bc, H, W, seed=9)).float()
+        lab = torch.from_numpy(synth.synth_label(Bc, H, W, 19, seed=9)).long()
+
+        def step():
+            oe.zero_grad()
+            od.zero_grad()
+            ref_gald.gald_losses(dec(x, enc(x)), lab)[1].backward()
+            oe.step()
+            od.step()
+        what = "oracle/ref_gald.py"
+    step()                                            # warm-up (oneDNN primitive creation)
+    n, t0 = 0, time.time()
+    while n < 3 and (n == 0 or time.time() - t0 < budget_s):
+        step()
+        n += 1
+    dt = time.time() - t0
+    return {"value": round(n * Bc / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d full train steps of B=%d %dx%d fp32 after 1 warm-up, %s" % (n, Bc, W, H, what)}
+
+
 _T0 = time.time()
 
 
@@ -106,8 +255,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=8, help="images per GPU (BASELINE: 8)")
-    ap.add_argument("--size", type=int, default=769)
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (BASELINE: 8; pranet 16, gald 6)")
+    ap.add_argument("--size", type=int, default=None, help="crop side (BASELINE: 769; pranet 352)")
+    ap.add_argument("--workload", choices=("deeplab", "pranet", "gald"), default="deeplab",
+                    help="deeplab = BASELINE config[1] (the headline, default); pranet = config[3]; gald = the third model of train_src.py")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
@@ -119,6 +270,11 @@ def main():
         raise SystemExit("bench.py measures the MI355X path; no GPU is visible")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    if args.workload != "deeplab":
+        if world != 1:
+            raise SystemExit("--workload %s is a one-GPU line" % args.workload)
+        return aux_workload(args, device)
+    args.batch, args.size = args.batch or 8, args.size or 769
     if world > 1 or os.environ.get("MI_DDP_FORCE") == "1":
         dist.init_process_group(backend="nccl", init_method="env://")       # RCCL
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
@@ -190,7 +346,6 @@ def main():
     if red is not None:
         red.measure = False
     events = [] if not args.no_kernel_events else None
-    INST = 3
     if events is not None:
         if graph:
             os.environ["MI_GRAPH"] = "0"          # events cannot be taken inside a graph replay

@@ -7,9 +7,33 @@ import ctypes
 
 import torch
 
-from . import _lib
+from . import _lib, kernels as _K
 from ._lib import check
 from .kernels import _p, _stream, _workspace, GATHER_FWD, GATHER_DGRAD  # noqa: F401
+
+
+class _TimedLib:
+    """kernels.PROFILE (bench.py's instrumented steps): every entry point called through this proxy is bracketed by HIP events on the launch stream
+    and recorded under its own name, with the algorithmic FLOPs the wrapper announced in `_work` (0 for the elementwise / reduction kernels)."""
+
+    def __getattr__(self, name):
+        fn = getattr(_lib.lib(), name)
+        if name.endswith(("_workspace", "_elems")):
+            return fn
+
+        def call(*args):
+            work, tag = _work[0], _work[1]
+            _work[0], _work[1] = 0.0, None
+            return _K._timed(name[3:], work, lambda: fn(*args), tag)
+        return call
+
+
+_work = [0.0, None]
+_timed_lib = _TimedLib()
+
+
+def _L():
+    return _timed_lib if _K.PROFILE is not None else _lib.lib()
 
 OP_ADD, OP_MUL, OP_COPY, OP_RELU_MASK, OP_MULRELU = 0, 1, 2, 3, 4
 
@@ -55,10 +79,12 @@ def gconv(a, wp, N, geom, out=None, mode=GATHER_FWD, out_hw=None, bias=None, sta
     po, ldo = view(out, torch.float32 if out_f32 else torch.bfloat16)
     if tuple(out.shape) != (B, Ho, Wo, N):
         raise _lib.MiError("gconv: out is %s, the conv writes %s" % (tuple(out.shape), (B, Ho, Wo, N)))
-    L = _lib.lib()
+    L = _L()
     st = None
     if stats:
         st = torch.empty(int(L.mi_gconv_stats_elems(B, Ho, Wo, N)), dtype=torch.float32, device=a.device)
+    if _K.PROFILE is not None:
+        _work[0], _work[1] = 2.0 * B * Ho * Wo * N * Ca * kh * kw, ("gconv", kh, kw, Ca, N, B * Ho * Wo, mode)          # 2 * pixels * C_out * C_in * taps
     check(L.mi_gconv(pa, lda, _p(wp), po, ldo, B, Ha, Wa, Ca, Ho, Wo, N, kh, kw, sh, sw, ph, pw, dh, dw, mode, _p(bias), _p(st), int(out_f32), _stream()),
           "mi_gconv")
     return out, st
@@ -73,19 +99,21 @@ def gconv_wgrad(dy, x, dw, geom, accumulate=False):
         raise _lib.MiError("gconv_wgrad: dw must be contiguous fp32 [O,I,kh,kw]")
     py, ldy = view(dy, torch.bfloat16)
     px, ldx = view(x, torch.bfloat16)
-    L = _lib.lib()
+    L = _L()
     ws = _workspace(L.mi_gconv_wgrad_workspace(B, Ho, Wo, O, I, kh, kw), dy.device, "gwgrad")
+    if _K.PROFILE is not None:
+        _work[0], _work[1] = 2.0 * B * Ho * Wo * O * I * kh * kw, ("gwgrad", kh, kw, I, O, B * Ho * Wo, 0)
     check(L.mi_gconv_wgrad(py, ldy, px, ldx, _p(dw), B, Ha, Wa, I, Ho, Wo, O, kh, kw, sh, sw, ph, pw, dh, dw_, int(accumulate), _p(ws), ws.numel(), _stream()),
           "mi_gconv_wgrad")
     return dw
 
 
 def gconv_pack_multi(wflat, wp, wpt, table_dev, n_desc, total_blocks):
-    check(_lib.lib().mi_gconv_pack_multi(_p(wflat), _p(wp), _p(wpt), _p(table_dev), n_desc, total_blocks, _stream()), "mi_gconv_pack_multi")
+    check(_L().mi_gconv_pack_multi(_p(wflat), _p(wp), _p(wpt), _p(table_dev), n_desc, total_blocks, _stream()), "mi_gconv_pack_multi")
 
 
 def pack_elems(O, I, kh, kw):
-    return int(_lib.lib().mi_gconv_pack_elems(O, I, kh, kw))
+    return int(_L().mi_gconv_pack_elems(O, I, kh, kw))
 
 
 def gconv_pack(w):
@@ -103,7 +131,7 @@ def gbn_finalize(stats, C, count, gamma, beta, running_mean, running_var, moment
     dev = stats.device
     out = torch.empty((4, C), dtype=torch.float32, device=dev)       # mean, invstd, scale, shift
     tiles = stats.numel() // (2 * C)
-    check(_lib.lib().mi_gbn_finalize(_p(stats), tiles, C, int(count), _p(gamma), _p(beta), _p(running_mean), _p(running_var), float(momentum), float(eps),
+    check(_L().mi_gbn_finalize(_p(stats), tiles, C, int(count), _p(gamma), _p(beta), _p(running_mean), _p(running_var), float(momentum), float(eps),
                                      _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), _stream()), "mi_gbn_finalize")
     return out
 
@@ -111,7 +139,7 @@ def gbn_finalize(stats, C, count, gamma, beta, running_mean, running_var, moment
 def gbn_fold(gamma, beta, rm, rv, eps):
     C = gamma.numel()
     out = torch.empty((2, C), dtype=torch.float32, device=gamma.device)
-    check(_lib.lib().mi_gbn_fold(_p(gamma), _p(beta), _p(rm), _p(rv), float(eps), _p(out[0]), _p(out[1]), C, _stream()), "mi_gbn_fold")
+    check(_L().mi_gbn_fold(_p(gamma), _p(beta), _p(rm), _p(rv), float(eps), _p(out[0]), _p(out[1]), C, _stream()), "mi_gbn_fold")
     return out[0], out[1]
 
 
@@ -122,7 +150,7 @@ def gbn_apply(y, scale, shift, relu, add=None, out=None, out_f32=False):
     py, ldy = view(y, torch.bfloat16)
     po, ldo = view(out, torch.float32 if out_f32 else torch.bfloat16)
     pa, lda = view(add, torch.bfloat16) if add is not None else (None, 0)
-    check(_lib.lib().mi_gbn_apply(py, ldy, _p(scale), _p(shift), pa, lda, po, ldo, int(out_f32), B * H * W, C, int(relu), _stream()), "mi_gbn_apply")
+    check(_L().mi_gbn_apply(py, ldy, _p(scale), _p(shift), pa, lda, po, ldo, int(out_f32), B * H * W, C, int(relu), _stream()), "mi_gbn_apply")
     return out
 
 
@@ -141,7 +169,7 @@ def gbn_bwd_sums(g, y, mask, mean, invstd, dbeta, dgamma, accumulate=False, relu
     M = B * H * W
     pg, ldg, gf, pm, ldm, mf = _gm(g, mask, relu6)
     py, ldy = view(y, torch.bfloat16) if y is not None else (None, 0)
-    L = _lib.lib()
+    L = _L()
     ws = _workspace(L.mi_gcolsum_workspace(M, C), g.device, "gcolsum")
     check(L.mi_gbn_bwd_sums(pg, ldg, gf, py, ldy, pm, ldm, mf, _p(mean), _p(invstd), M, C, _p(dbeta), _p(dgamma), int(accumulate), _p(ws), ws.numel(),
                             _stream()), "mi_gbn_bwd_sums")
@@ -154,7 +182,7 @@ def gbn_bwd_apply(g, y, mask, mean, invstd, gamma, dbeta, dgamma, count, out=Non
     pg, ldg, gf, pm, ldm, mf = _gm(g, mask, relu6)
     py, ldy = view(y, torch.bfloat16)
     po, ldo = view(out, torch.bfloat16)
-    check(_lib.lib().mi_gbn_bwd_apply(pg, ldg, gf, py, ldy, pm, ldm, mf, _p(mean), _p(invstd), _p(gamma), _p(dbeta), _p(dgamma), ctypes.c_float(1.0 / count),
+    check(_L().mi_gbn_bwd_apply(pg, ldg, gf, py, ldy, pm, ldm, mf, _p(mean), _p(invstd), _p(gamma), _p(dbeta), _p(dgamma), ctypes.c_float(1.0 / count),
                                       po, ldo, B * H * W, C, _stream()), "mi_gbn_bwd_apply")
     return out
 
@@ -172,7 +200,7 @@ def gbinary(op, a, b=None, out=None, out_dtype=None):
     pa, lda = view(a)
     pb, ldb = view(b, a.dtype) if b is not None else (None, 0)
     po, ldo = view(out)
-    check(_lib.lib().mi_gbinary(op, dt, pa, lda, pb, ldb, po, ldo, B * H * W, C, _stream()), "mi_gbinary")
+    check(_L().mi_gbinary(op, dt, pa, lda, pb, ldb, po, ldo, B * H * W, C, _stream()), "mi_gbinary")
     return out
 
 
@@ -183,7 +211,7 @@ def gavgpool(x, k, stride, pad, include_pad, out_hw, out=None):
         out = new(B, Ho, Wo, C, x.device)
     px, ldx = view(x, torch.bfloat16)
     po, ldo = view(out, torch.bfloat16)
-    check(_lib.lib().mi_gavgpool(px, ldx, po, ldo, B, H, W, C, Ho, Wo, k, stride, pad, int(include_pad), 0, _stream()), "mi_gavgpool")
+    check(_L().mi_gavgpool(px, ldx, po, ldo, B, H, W, C, Ho, Wo, k, stride, pad, int(include_pad), 0, _stream()), "mi_gavgpool")
     return out
 
 
@@ -194,7 +222,7 @@ def gavgpool_bwd(dout, in_hw, k, stride, pad, include_pad, dx=None):
         dx = new(B, H, W, C, dout.device)
     px, ldx = view(dx, torch.bfloat16)
     po, ldo = view(dout, torch.bfloat16)
-    check(_lib.lib().mi_gavgpool(px, ldx, po, ldo, B, H, W, C, Ho, Wo, k, stride, pad, int(include_pad), 1, _stream()), "mi_gavgpool(bwd)")
+    check(_L().mi_gavgpool(px, ldx, po, ldo, B, H, W, C, Ho, Wo, k, stride, pad, int(include_pad), 1, _stream()), "mi_gavgpool(bwd)")
     return dx
 
 
@@ -217,7 +245,7 @@ def gresize(x, out_hw, align_corners, scale_factor=None, out=None):
     sh, sw = resize_scales((H, W), out_hw, align_corners, scale_factor)
     px, ldx = view(x)
     po, ldo = view(out, x.dtype)
-    check(_lib.lib().mi_gresize(px, ldx, po, ldo, int(x.dtype == torch.float32), B, H, W, C, Ho, Wo, int(align_corners), sh, sw, 0, _stream()), "mi_gresize")
+    check(_L().mi_gresize(px, ldx, po, ldo, int(x.dtype == torch.float32), B, H, W, C, Ho, Wo, int(align_corners), sh, sw, 0, _stream()), "mi_gresize")
     return out
 
 
@@ -229,7 +257,7 @@ def gresize_bwd(dout, in_hw, align_corners, scale_factor=None, dx=None):
     sh, sw = resize_scales((H, W), (Ho, Wo), align_corners, scale_factor)
     px, ldx = view(dx, dout.dtype)
     po, ldo = view(dout)
-    check(_lib.lib().mi_gresize(px, ldx, po, ldo, int(dout.dtype == torch.float32), B, H, W, C, Ho, Wo, int(align_corners), sh, sw, 1, _stream()), "mi_gresize(bwd)")
+    check(_L().mi_gresize(px, ldx, po, ldo, int(dout.dtype == torch.float32), B, H, W, C, Ho, Wo, int(align_corners), sh, sw, 1, _stream()), "mi_gresize(bwd)")
     return dx
 
 
@@ -242,7 +270,7 @@ def gra_fwd(gate, feat, out=None):
     po, ldo = view(out, torch.bfloat16)
     if not (gate.dtype == torch.float32 and gate.is_contiguous() and gate.numel() == B * H * W):
         raise _lib.MiError("gra_fwd: gate must be contiguous fp32 with one value per pixel")
-    check(_lib.lib().mi_gra_fwd(_p(gate), pf, ldf, po, ldo, B * H * W, C, _stream()), "mi_gra_fwd")
+    check(_L().mi_gra_fwd(_p(gate), pf, ldf, po, ldo, B * H * W, C, _stream()), "mi_gra_fwd")
     return out
 
 
@@ -253,7 +281,7 @@ def gra_bwd(gate, feat, dy):
     pf, ldf = view(feat, torch.bfloat16)
     pd, ldd = view(dy, torch.bfloat16)
     po, ldo = view(dfeat, torch.bfloat16)
-    check(_lib.lib().mi_gra_bwd(_p(gate), pf, ldf, pd, ldd, po, ldo, _p(dgate), B * H * W, C, _stream()), "mi_gra_bwd")
+    check(_L().mi_gra_bwd(_p(gate), pf, ldf, pd, ldd, po, ldo, _p(dgate), B * H * W, C, _stream()), "mi_gra_bwd")
     return dfeat, dgate
 
 
@@ -266,7 +294,7 @@ def gdwconv(x, w, bias, stride, pad, out=None, stats=False):
         out = new(B, Ho, Wo, C, x.device)
     px, ldx = view(x, torch.bfloat16)
     po, ldo = view(out, torch.bfloat16)
-    L = _lib.lib()
+    L = _L()
     st = torch.empty(int(L.mi_gdwconv_stats_elems(B, Ho, Wo, C)), dtype=torch.float32, device=x.device) if stats else None
     check(L.mi_gdwconv(px, ldx, _p(w), _p(bias), po, ldo, B, H, W, C, Ho, Wo, stride, pad, _p(st), _stream()), "mi_gdwconv")
     return out, st
@@ -278,7 +306,7 @@ def gdwconv_backward(dy, x, w, dw, dbias, stride, pad, need_dx=True, accumulate=
     _, Ho, Wo, _ = dy.shape
     py, ldy = view(dy, torch.bfloat16)
     px, ldx = view(x, torch.bfloat16)
-    L = _lib.lib()
+    L = _L()
     ws = _workspace(L.mi_gdwconv_wgrad_workspace(B, Ho, Wo, C), x.device, "gdw")
     check(L.mi_gdwconv_wgrad(py, ldy, px, ldx, _p(dw), _p(dbias), B, H, W, C, Ho, Wo, stride, pad, int(accumulate), _p(ws), ws.numel(), _stream()), "mi_gdwconv_wgrad")
     if not need_dx:
@@ -296,7 +324,7 @@ def gcca_fwd(q, k, v):
     att = torch.empty((B, H, W, H + W), dtype=torch.float32, device=q.device)
     agg = new(B, H, W, C, q.device)
     (pq, ldq), (pk, ldk), (pv, ldv), (po, ldo) = view(q, torch.bfloat16), view(k, torch.bfloat16), view(v, torch.bfloat16), view(agg, torch.bfloat16)
-    check(_lib.lib().mi_gcca_fwd(pq, ldq, pk, ldk, pv, ldv, _p(att), po, ldo, B, H, W, Cq, C, _stream()), "mi_gcca_fwd")
+    check(_L().mi_gcca_fwd(pq, ldq, pk, ldk, pv, ldv, _p(att), po, ldo, B, H, W, Cq, C, _stream()), "mi_gcca_fwd")
     return agg, att
 
 
@@ -307,7 +335,7 @@ def gcca_bwd(q, k, v, att, dagg):
     de = torch.empty_like(att)
     (pq, ldq), (pk, ldk), (pv, ldv), (pg, ldg) = view(q, torch.bfloat16), view(k, torch.bfloat16), view(v, torch.bfloat16), view(dagg, torch.bfloat16)
     (p1, l1), (p2, l2), (p3, l3) = view(dq), view(dk), view(dv)
-    check(_lib.lib().mi_gcca_bwd(pq, ldq, pk, ldk, pv, ldv, _p(att), pg, ldg, _p(de), p1, l1, p2, l2, p3, l3, B, H, W, Cq, C, _stream()), "mi_gcca_bwd")
+    check(_L().mi_gcca_bwd(pq, ldq, pk, ldk, pv, ldv, _p(att), pg, ldg, _p(de), p1, l1, p2, l2, p3, l3, B, H, W, Cq, C, _stream()), "mi_gcca_bwd")
     return dq, dk, dv
 
 
@@ -316,7 +344,7 @@ def ggate(x, g):
     B, H, W, C = x.shape
     out = new(B, H, W, C, x.device)
     (px, ldx), (pg, ldg), (po, ldo) = view(x, torch.bfloat16), view(g, torch.bfloat16), view(out)
-    check(_lib.lib().mi_ggate(px, ldx, pg, ldg, None, 0, po, ldo, None, 0, B * H * W, C, _stream()), "mi_ggate")
+    check(_L().mi_ggate(px, ldx, pg, ldg, None, 0, po, ldo, None, 0, B * H * W, C, _stream()), "mi_ggate")
     return out
 
 
@@ -324,7 +352,7 @@ def ggate_bwd(x, g, dout):
     B, H, W, C = x.shape
     dx, dg = new(B, H, W, C, x.device), new(B, H, W, C, x.device)
     (px, ldx), (pg, ldg), (pd, ldd), (p1, l1), (p2, l2) = view(x, torch.bfloat16), view(g, torch.bfloat16), view(dout, torch.bfloat16), view(dx), view(dg)
-    check(_lib.lib().mi_ggate(px, ldx, pg, ldg, pd, ldd, p1, l1, p2, l2, B * H * W, C, _stream()), "mi_ggate(bwd)")
+    check(_L().mi_ggate(px, ldx, pg, ldg, pd, ldd, p1, l1, p2, l2, B * H * W, C, _stream()), "mi_ggate(bwd)")
     return dx, dg
 
 
@@ -335,7 +363,7 @@ def gmaxpool(x, k, stride, pad):
     out = new(B, Ho, Wo, C, x.device)
     idx = torch.empty((B, Ho, Wo, C), dtype=torch.uint8, device=x.device)
     (px, ldx), (po, ldo) = view(x, torch.bfloat16), view(out)
-    check(_lib.lib().mi_gmaxpool(px, ldx, po, ldo, _p(idx), B, H, W, C, Ho, Wo, k, stride, pad, 0, _stream()), "mi_gmaxpool")
+    check(_L().mi_gmaxpool(px, ldx, po, ldo, _p(idx), B, H, W, C, Ho, Wo, k, stride, pad, 0, _stream()), "mi_gmaxpool")
     return out, idx
 
 
@@ -345,7 +373,7 @@ def gmaxpool_bwd(dout, idx, in_hw, k, stride, pad, dx=None):
     if dx is None:
         dx = new(B, H, W, C, dout.device)
     (px, ldx), (po, ldo) = view(dx, torch.bfloat16), view(dout, torch.bfloat16)
-    check(_lib.lib().mi_gmaxpool(px, ldx, po, ldo, _p(idx), B, H, W, C, Ho, Wo, k, stride, pad, 1, _stream()), "mi_gmaxpool(bwd)")
+    check(_L().mi_gmaxpool(px, ldx, po, ldo, _p(idx), B, H, W, C, Ho, Wo, k, stride, pad, 1, _stream()), "mi_gmaxpool(bwd)")
     return dx
 
 
@@ -355,7 +383,7 @@ def gce(logits, labels, ignore_index=255, want_grad=True, grad_scale=1.0):
     pl, ld = view(logits, torch.float32)
     if not (labels.dtype == torch.int64 and labels.is_contiguous() and labels.numel() == B * H * W):
         raise _lib.MiError("gce: labels must be contiguous int64 [B,H,W]")
-    L = _lib.lib()
+    L = _L()
     ws = _workspace(L.mi_gce_workspace(B * H * W), logits.device, "gce")
     out = torch.empty(4, dtype=torch.float32, device=logits.device)
     d = torch.empty((B, H, W, Kc), dtype=torch.float32, device=logits.device) if want_grad else None

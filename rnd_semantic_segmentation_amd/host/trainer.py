@@ -100,8 +100,8 @@ class ASPPTrainer(BaseTrainer):
 
     def _graph_enabled(self):
         return (os.environ.get("MI_GRAPH") == "1" and self.device.type == "cuda" and self.reducer is None
-                and isinstance(self.optimizer_fea, FusedSGD) and hasattr(self.classifier, "loss")
-                and getattr(self.feature_extractor, "freeze_bn", True))          # the BatchNorm path is composed by autograd: eager only
+                and isinstance(self.optimizer_fea, FusedSGD) and hasattr(self.classifier, "loss"))
+        # (one GPU: BatchNorm2d statistics are not exchanged, and their finalize / running-statistics update run on the device - capturable)
 
     def _graph_step(self, src_input, src_label, current_lr):
         st = getattr(self, "_graph", None)
