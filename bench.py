@@ -176,6 +176,17 @@ def aux_workload(args, device):
             v[2] += 1
         tot = sum(v[0] for v in by.values())
         conv_fl = sum(v[1] for v in by.values())
+        if os.environ.get("MI_BENCH_SHAPES"):          # per-shape table of the convs (stderr): where the conv time goes
+            shapes = {}
+            for name, e0, e1, flops, tag in events:
+                if flops and tag is not None:
+                    v = shapes.setdefault((name,) + tuple(tag), [0.0, 0.0, 0])
+                    v[0] += e0.elapsed_time(e1) * 1e-3
+                    v[1] += flops
+                    v[2] += 1
+            for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][0])[:40]:
+                print("   %-70s %3d launches/step %8.1f us each %7.1f TFLOP/s %6.3f ms/step" % (k, v[2] // INST, 1e6 * v[0] / v[2], v[1] / v[0] / 1e12, 1e3 * v[0] / INST),
+                      file=sys.stderr)
         dom = max(by, key=lambda k: by[k][0])
         tsec, fl, n = by[dom]
         out["roofline"] = {"kernel": dom, "bound": "mfma" if fl else "hbm", "achieved": round(fl / tsec / 1e12, 2) if fl else None, "peak": PEAK_BF16_TFLOPS if fl else PEAK_HBM_TBS,

@@ -391,10 +391,10 @@ class StageEngine:
         """conv (plain store) -> batch statistics -> normalise (+ residual) (+ ReLU, + sign bits).  Returns (out, y, fin, count, bits)."""
         c = rt.spec
         synced = _bn_synced(rt.bn)
-        y, s1, s2, fin = K.conv_gemm_stats(x, rt.wp, arch.out_hw(x.shape[1], x.shape[2], c), c.k, c.stride, c.pad, c.dil, bn_pilot(rt.bn, x.device),
-                                          bn=None if synced else rt.bn)
+        y, sums, fin = K.conv_gemm_stats(x, rt.wp, arch.out_hw(x.shape[1], x.shape[2], c), c.k, c.stride, c.pad, c.dil, bn_pilot(rt.bn, x.device),
+                                         bn=None if synced else rt.bn)
         if synced:          # the raw sums are exchanged first, then finalized over the global pixel count
-            fin, count = bn_batch_statistics(y, rt.bn, (s1, s2))
+            fin, count = bn_batch_statistics(y, rt.bn, (sums[0], sums[1]))
         else:
             count = y.numel() // y.shape[-1]
         if relu:

@@ -26,7 +26,7 @@ from .. import _lib
 from .. import gk
 from .. import kernels as K
 from . import arch
-from .engine import FlatStore
+from .engine import FlatStore, _SideStream, _off_path
 from .plugin import BaseTrainer
 
 
@@ -148,12 +148,16 @@ def _mfma_tile_ok(u, x, out=None, out_f32=False):
 
 
 def _conv_forward(x, u, bias, stats, out=None, out_f32=False, net=None):
-    """(y, statistics partials or None): the general kernel, or the MFMA-tile kernels + one pass of column sums for the BatchNorm statistics."""
+    """(y, statistics partials or None): the general kernel, or the MFMA-tile kernels with the BatchNorm sums out of their epilogue (mi_conv_gemm_stats;
+    one extra pass of column sums where a bias or a slot output rules that entry out)."""
     if not _mfma_tile_ok(u, x, out, out_f32):
         return gk.gconv(x, u.wp, u.cout, u.geom, out=out, bias=bias, stats=stats, out_f32=out_f32)
     k, s, p, d = u.geom[0], u.geom[2], u.geom[4], u.geom[6]
     hw = gk.conv_out_hw(x.shape[1], x.shape[2], *u.geom)
     wp = u.wp.view(k * k, u.cout, u.cin)
+    if stats and bias is None and out is None:          # sum y and sum y^2 out of the conv's own epilogue (pilot 0: raw sums)
+        y, sums, _ = K.conv_gemm_stats(x, wp, hw, k, s, p, d, net._zeros(u.cout))
+        return y, sums.view(-1)
     y = K.conv_gemm(x, wp, hw, k, s, p, d, K.GATHER_FWD, scale=None if bias is None else net._ones(u.cout), bias=bias, out=out)
     st = None
     if stats:                       # sum y and sum y^2 in one pass: the backward-sums kernel with g = y, mean = 0, invstd = 1
@@ -172,7 +176,7 @@ class _Run:
     """One forward pass.  train: BatchNorm2d on batch statistics (module.training); rec: record the backward tape."""
 
     def __init__(self, net, train, rec):
-        self.net, self.train, self.rec, self.tape = net, train, rec, []
+        self.net, self.train, self.rec, self.tape, self.side = net, train, rec, [], None
 
     def record(self, fn):
         if self.rec:
@@ -234,17 +238,23 @@ class _Run:
         return ov
 
     def _conv_backward(self, x, u, dy):
+        """Weight gradient (off the critical path: nothing reads it before the optimizer, so it runs on the side stream beside the data-gradient
+        chain - the convs of these nets are far too small to fill 256 CUs alone) and data gradient."""
         slot, acc = self.net._grad_slot(u.weight)
+        # measured: every weight gradient on the side stream costs PraNet 6 % as a graph and 18 % eager (hundreds of 20-60 us launches, each fork / join
+        # a dependency the GPU has to resolve), and gains GALD 2.6 % (its 0.3-1 ms launches overlap): only launches of >= 8 GFLOP leave the main stream
+        work = 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * u.cout * (1 if u.depthwise else u.cin) * u.geom[0] * u.geom[1]
+        side = self.side if work >= 8e9 else None
         if _mfma_tile_ok(u, x.t) and dy.is_contiguous():
             k, s, p, d = u.geom[0], u.geom[2], u.geom[4], u.geom[6]
-            K.conv_wgrad(dy, x.t, slot, k, s, p, d, accumulate=acc)
+            _off_path(side, lambda: K.conv_wgrad(dy, x.t, slot, k, s, p, d, accumulate=acc), dy, x.t)
             if x.needs:
                 tgt = _grad_target(x)
                 dx = K.conv_gemm(dy, u.wpt.view(k * k, u.cin, u.cout), (x.t.shape[1], x.t.shape[2]), k, s, p, d, K.GATHER_DGRAD,
                                  out=tgt if (tgt is not None and tgt.is_contiguous()) else None)
                 _acc(x, dx, True)
             return
-        gk.gconv_wgrad(dy, x.t, slot, u.geom, accumulate=acc)
+        _off_path(side, lambda: gk.gconv_wgrad(dy, x.t, slot, u.geom, accumulate=acc), dy, x.t)
         if x.needs:
             dx, _ = gk.gconv(dy, u.wpt, u.cin, u.geom, out=_grad_target(x), mode=gk.GATHER_DGRAD, out_hw=(x.t.shape[1], x.t.shape[2]))
             _acc(x, dx, True)
@@ -400,9 +410,12 @@ class _Run:
         return parts, slots
 
     def backward(self):
+        self.side = _SideStream.get(self.net._store.data.device) if os.environ.get("MI_TAPE_WGRAD_STREAM", "1") != "0" else None
         for fn in reversed(self.tape):
             fn()
         self.tape = []
+        if self.side is not None:
+            self.side.join()          # the caller (optimizer, gradient exchange) sees complete weight gradients on its own stream
 
 
 # ------------------------------------------------------------------------------------------------ graph pieces

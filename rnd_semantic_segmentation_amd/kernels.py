@@ -152,8 +152,8 @@ _ws_cache = {}
 
 
 def conv_gemm_stats(a, wp, out_hw, ksize, stride, pad, dil, pilot, bn=None):
-    """conv_gemm with a plain bf16 store that also returns the BatchNorm statistics of its output, taken in the epilogue: (out, s1, s2, fin) with
-    s1[n] = sum (out - pilot[n]), s2[n] = sum (out - pilot[n])^2 (rows of one [2, N] buffer) - bn_colsum2(out, pilot) without the extra read.
+    """conv_gemm with a plain bf16 store that also returns the BatchNorm statistics of its output, taken in the epilogue: (out, sums, fin) with
+    sums[0][n] = sum (out - pilot[n]), sums[1][n] = sum (out - pilot[n])^2 ([2, N] fp32) - bn_colsum2(out, pilot) without the extra read.
     bn (an nn.BatchNorm2d whose statistics are NOT shared across ranks): the last reduction launch also finalizes them (bn_finalize's result `fin`
     and running-statistics update, count = the pixels of this tensor); otherwise fin is None."""
     _chk(a, torch.bfloat16, "a")
@@ -179,7 +179,7 @@ def conv_gemm_stats(a, wp, out_hw, ksize, stride, pad, dil, pilot, bn=None):
     _timed("igemm_stats", flops, lambda: check(_lib.lib().mi_conv_gemm_stats(_p(a), _p(wp), _p(out), B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, pad, dil, _p(pilot),
                                                                              _p(sums), _p(ws), ws.numel(), *fa, _stream()), "mi_conv_gemm_stats"),
            ("fwd", ksize, Ca, N, B * Ho * Wo, 512, dil))
-    return out, sums[0], sums[1], fin
+    return out, sums, fin
 
 
 def _workspace(nbytes, device, tag="ws"):
