@@ -44,6 +44,24 @@ __device__ __attribute__((aligned(256))) uint32_t g_gzero[64];        // source 
 // Loads are UNCONDITIONAL (an out-of-range access reads the zero page instead of being branched around): with control flow around a load
 // the compiler cannot count the loads in flight and waits for all of them (s_waitcnt vmcnt(0)) at the first use - which also drains the
 // prefetch of the chunk after next, i.e. every K step would pay a full memory round trip.
+// 16 bytes from a 4-byte aligned address (a channel slice whose offset / row stride is even but not a multiple of 8 elements: HarDNet's 466-, 142-,
+// 68-channel tensors, Res2Net's 26-channel groups): ONE global_load_dwordx4 - the hardware takes dword-aligned addresses for it - instead of four
+// dword loads.  8 channels c0 .. c0+7 of a row of C (even, >= 8) channels: a chunk that would run past the row end is fetched as the row's LAST 16
+// bytes and shifted down (zero fill), so that nothing outside [src, src + C) is ever read; channels >= C and !ok rows read the zero page.
+typedef u32x4 __attribute__((aligned(4))) u32x4_a4;
+
+__device__ __forceinline__ bf16x8 gload8_a4(const __bf16* src, int c0, int C, bool ok) {
+    const int rem = C - c0;
+    const bool live = ok && rem > 0, part = live && rem < 8;
+    const __bf16* ptr = live ? (part ? src + C - 8 : src + c0) : reinterpret_cast<const __bf16*>(g_gzero);
+    u32x4 v = *reinterpret_cast<const u32x4_a4*>(ptr);
+    if (part) {
+        const int drop = (8 - rem) >> 1;          // dwords of the window that belong to channels below c0
+        v = drop == 1 ? u32x4{v[1], v[2], v[3], 0u} : (drop == 2 ? u32x4{v[2], v[3], 0u, 0u} : u32x4{v[3], 0u, 0u, 0u});
+    }
+    return __builtin_bit_cast(bf16x8, v);
+}
+
 template <int VEC>
 __device__ __forceinline__ void gload16(const __bf16* src, int c0, int C, bool ok, bf16x8 (&r)[2]) {
     // 16 channels c0 .. c0+15 of one pixel row; channels >= C (and everything when !ok) read as zero
@@ -54,15 +72,9 @@ __device__ __forceinline__ void gload16(const __bf16* src, int c0, int C, bool o
             const int c = c0 + 8 * h;
             r[h] = *reinterpret_cast<const bf16x8*>((ok && c < C) ? src + c : zero);
         }
-    } else if constexpr (VEC == 2) {
-        union { bf16x8 v[2]; uint32_t u[8]; } x;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = c0 + 2 * j;
-            x.u[j] = *reinterpret_cast<const uint32_t*>((ok && c < C) ? src + c : zero);
-        }
-        r[0] = x.v[0];
-        r[1] = x.v[1];
+    } else if constexpr (VEC == 4) {
+        r[0] = gload8_a4(src, c0, C, ok);
+        r[1] = gload8_a4(src, c0 + 8, C, ok);
     } else {
         union { bf16x8 v[2]; uint16_t u[16]; } x;
 #pragma unroll
@@ -234,16 +246,22 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
         }
         __syncthreads();
         __bf16* out = reinterpret_cast<__bf16*>(p.out);
-        constexpr int G = BN / OVEC;                 // stores per row
+        constexpr int OW = OVEC == 4 ? 8 : OVEC;     // channels per store slot
+        constexpr int G = BN / OW;                   // store slots per row
         for (int idx = tid; idx < GBM * G; idx += 256) {
             const int row = idx / G, cg = idx - row * G;
-            const int m = m0 + row, n = n0 + cg * OVEC;
+            const int m = m0 + row, n = n0 + cg * OW;
             if (m < p.M && n < p.N) {
                 __bf16* dst = out + (long)m * p.ldo + n;
-                const __bf16* src = Cs + row * CSW + cg * OVEC;
+                const __bf16* src = Cs + row * CSW + cg * OW;
                 if constexpr (OVEC == 8) *reinterpret_cast<bf16x8*>(dst) = *reinterpret_cast<const bf16x8*>(src);
-                else if constexpr (OVEC == 2) *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(src);
-                else *dst = *src;
+                else if constexpr (OVEC == 4) {       // 4-byte aligned rows, even N: one 16-byte store per full chunk, dword stores for the row's tail
+                    if (n + 8 <= p.N) {
+                        *reinterpret_cast<u32x4_a4*>(dst) = *reinterpret_cast<const u32x4*>(src);
+                    } else {
+                        for (int e = 0; n + e < p.N; e += 2) *reinterpret_cast<uint32_t*>(dst + e) = *reinterpret_cast<const uint32_t*>(src + e);
+                    }
+                } else *dst = *src;
             }
         }
         if (p.stats) {
@@ -294,14 +312,14 @@ void glaunch_o(const GConvP& p, int ovec, bool f32, hipStream_t s) {
         return;
     }
     if (ovec == 8) glaunch<BN, KC, AVEC, 8, false>(p, s);
-    else if (ovec == 2) glaunch<BN, KC, AVEC, 2, false>(p, s);
+    else if (ovec == 4) glaunch<BN, KC, AVEC, 4, false>(p, s);
     else glaunch<BN, KC, AVEC, 1, false>(p, s);
 }
 
 template <int BN, int KC>
 void glaunch_a(const GConvP& p, int avec, int ovec, bool f32, hipStream_t s) {
     if (avec == 8) glaunch_o<BN, KC, 8>(p, ovec, f32, s);
-    else if (avec == 2) glaunch_o<BN, KC, 2>(p, ovec, f32, s);
+    else if (avec == 4) glaunch_o<BN, KC, 4>(p, ovec, f32, s);
     else glaunch_o<BN, KC, 1>(p, ovec, f32, s);
 }
 
@@ -319,10 +337,10 @@ void glaunch_k(GConvP& p, int avec, int ovec, bool f32, hipStream_t s) {
     glaunch_a<BN, 32>(p, avec, ovec, f32, s);
 }
 
-int view_vec(const void* ptr, long ld, int C) {
+int view_vec(const void* ptr, long ld, int C, bool load = true) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
     if ((a & 15) == 0 && ld % 8 == 0 && C % 8 == 0) return 8;
-    if ((a & 3) == 0 && ld % 2 == 0 && C % 2 == 0) return 2;
+    if ((a & 3) == 0 && ld % 2 == 0 && C % 2 == 0 && (C >= 8 || !load)) return 4;        // 16-byte accesses at 4-byte alignment (loads need a full window)
     return 1;
 }
 
@@ -349,9 +367,8 @@ __device__ __forceinline__ bf16x8 gload8(const __bf16* src, int c0, int C, bool 
     const __bf16* zero = reinterpret_cast<const __bf16*>(g_gzero);
     if constexpr (VEC == 8) {
         x.v = *reinterpret_cast<const bf16x8*>((ok && c0 < C) ? src + c0 : zero);
-    } else if constexpr (VEC == 2) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) x.u[j] = *reinterpret_cast<const uint32_t*>((ok && c0 + 2 * j < C) ? src + c0 + 2 * j : zero);
+    } else if constexpr (VEC == 4) {
+        x.v = gload8_a4(src, c0, C, ok);
     } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) x.h[j] = *reinterpret_cast<const uint16_t*>((ok && c0 + j < C) ? src + c0 + j : zero);
@@ -607,7 +624,7 @@ int mi_gconv(const void* a, long lda, const void* wp, void* out, long ldo, int B
     p.nchunks = p.Cpad / 32;
     const int avec = view_vec(a, lda, Ca);
     int ovec = 1;
-    if (!out_f32) ovec = view_vec(out, ldo, N);
+    if (!out_f32) ovec = view_vec(out, ldo, N, false);
     else MI_REQUIRE((reinterpret_cast<uintptr_t>(out) & 3) == 0, "mi_gconv: fp32 output must be 4-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const long mt = (p.M + GBM - 1) / GBM;
@@ -657,13 +674,13 @@ int mi_gconv_wgrad(const void* dy, long ldy, const void* x, long ldx, float* dw,
     const dim3 grid(p.o_tiles * p.i_tiles * p.T * p.S);
 #define GW(YV, XV) hipLaunchKernelGGL((gwgrad_kernel<YV, XV>), grid, dim3(256), 0, s, p)
     if (yv == 8 && xv == 8) GW(8, 8);
-    else if (yv == 8 && xv == 2) GW(8, 2);
+    else if (yv == 8 && xv == 4) GW(8, 4);
     else if (yv == 8) GW(8, 1);
-    else if (yv == 2 && xv == 8) GW(2, 8);
-    else if (yv == 2 && xv == 2) GW(2, 2);
-    else if (yv == 2) GW(2, 1);
+    else if (yv == 4 && xv == 8) GW(4, 8);
+    else if (yv == 4 && xv == 4) GW(4, 4);
+    else if (yv == 4) GW(4, 1);
     else if (xv == 8) GW(1, 8);
-    else if (xv == 2) GW(1, 2);
+    else if (xv == 4) GW(1, 4);
     else GW(1, 1);
 #undef GW
     MI_CHECK_LAUNCH("gwgrad_kernel");

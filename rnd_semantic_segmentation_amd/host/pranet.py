@@ -241,8 +241,9 @@ class _Run:
         """Weight gradient (off the critical path: nothing reads it before the optimizer, so it runs on the side stream beside the data-gradient
         chain - the convs of these nets are far too small to fill 256 CUs alone) and data gradient."""
         slot, acc = self.net._grad_slot(u.weight)
-        # measured: every weight gradient on the side stream costs PraNet 6 % as a graph and 18 % eager (hundreds of 20-60 us launches, each fork / join
-        # a dependency the GPU has to resolve), and gains GALD 2.6 % (its 0.3-1 ms launches overlap): only launches of >= 8 GFLOP leave the main stream
+        # MI_TAPE_WGRAD_STREAM=1 (off by default).  Measured: every weight gradient on the side stream costs PraNet 6 % as a graph and 18 % eager
+        # (hundreds of 20-60 us launches, each fork / join a dependency the GPU has to resolve); only the launches of >= 8 GFLOP there: PraNet still
+        # -10 % as a graph (659 vs 734 images/s: a second stream in the capture changes how the whole graph is scheduled), GALD +1 % (110.9 vs 109.7)
         work = 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * u.cout * (1 if u.depthwise else u.cin) * u.geom[0] * u.geom[1]
         side = self.side if work >= 8e9 else None
         if _mfma_tile_ok(u, x.t) and dy.is_contiguous():
@@ -410,7 +411,7 @@ class _Run:
         return parts, slots
 
     def backward(self):
-        self.side = _SideStream.get(self.net._store.data.device) if os.environ.get("MI_TAPE_WGRAD_STREAM", "1") != "0" else None
+        self.side = _SideStream.get(self.net._store.data.device) if os.environ.get("MI_TAPE_WGRAD_STREAM", "0") == "1" else None
         for fn in reversed(self.tape):
             fn()
         self.tape = []
