@@ -838,6 +838,12 @@ class AsppLossFn(torch.autograd.Function):
             loss_out, dlow = K.upsample_ce(low, labels, want_grad=train, ignore_index=ignore_index)
         ctx.eng, ctx.x, ctx.dlow = eng, (x if train else None), dlow
         ctx.loss_out = eng.last_loss_out = loss_out          # [loss, n_valid, out-of-range labels, -]: see K.check_labels
+        # every step's count goes into a persistent device counter (the kernel zeroes its own per call): the trainer reads it once per logging
+        # window, so a bad label in ANY step of the window raises, as torch's device assert would - also under HIP-graph replay (the add is captured)
+        bad = getattr(eng, "bad_labels", None)
+        if bad is None or bad.device != loss_out.device:
+            bad = eng.bad_labels = torch.zeros(1, dtype=torch.float32, device=loss_out.device)
+        bad.add_(loss_out[2:3])
         return loss_out[0].clone()
 
     @staticmethod

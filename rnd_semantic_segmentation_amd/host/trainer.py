@@ -103,6 +103,18 @@ class ASPPTrainer(BaseTrainer):
                 and isinstance(self.optimizer_fea, FusedSGD) and hasattr(self.classifier, "loss"))
         # (one GPU: BatchNorm2d statistics are not exchanged, and their finalize / running-statistics update run on the device - capturable)
 
+    def _graph_signature(self):
+        """What a captured step depends on besides the bytes it reads: the flat stores (pointers), the normalisation buffers' versions (a FrozenBN
+        refold happens in prepare(), outside the replay) and the train / eval state of the packs."""
+        from . import engine
+        fe, cls = self.feature_extractor, self.classifier
+        sig = [getattr(m, "_store", None) is not None and m._store.data.data_ptr() for m in (fe, cls)]
+        eng = getattr(fe, "_engine", None)
+        if eng is not None:
+            sig.append(sum(engine.bn_versions(rt.bn) for rt in eng.convs) if getattr(fe, "freeze_bn", True) else -1)
+            sig.append(bool(eng._have_dgrad))
+        return tuple(sig)
+
     def _graph_step(self, src_input, src_label, current_lr):
         st = getattr(self, "_graph", None)
         if st is None:
@@ -123,9 +135,14 @@ class ASPPTrainer(BaseTrainer):
             with torch.cuda.graph(g):
                 st["loss"] = self._step_core(st["x"], st["y"])
             st["graph"] = g
+            st["sig"] = self._graph_signature()
             # the capture did not execute anything: fall through to the first replay
-        if src_input.shape != st["x"].shape:
-            raise RuntimeError("MI_GRAPH=1 captured a step for inputs of shape %s, got %s" % (tuple(st["x"].shape), tuple(src_input.shape)))
+        if src_input.shape != st["x"].shape or self._graph_signature() != st["sig"]:
+            # another batch shape (a last partial batch), or something the capture froze has changed out of band (load_state_dict into the
+            # BatchNorm buffers, a repack by an eval in between, parameters moved): this step runs eager, and the graph is rebuilt after
+            # the usual warm-up
+            self._graph = {"eager": 0, "graph": None}
+            return None
         st["x"].copy_(src_input, non_blocking=True)
         st["y"].copy_(src_label, non_blocking=True)
         self.optimizer_fea.push_hyper()
@@ -205,10 +222,14 @@ class ASPPTrainer(BaseTrainer):
         images = 0
 
         def flush():
-            lo = getattr(getattr(self.classifier, "_engine", None), "last_loss_out", None)
-            if lo is not None and pending:                  # the loss is fetched here anyway: one more float
-                from .. import kernels
-                kernels.check_labels(lo, self.cfg.MODEL.NUM_CLASSES, "train labels")
+            bad = getattr(getattr(self.classifier, "_engine", None), "bad_labels", None)
+            if bad is not None and pending:                 # the losses are fetched here anyway: one more float, summed over every step since the last flush
+                n = int(bad.item())
+                bad.zero_()
+                if n:
+                    raise ValueError("train labels: %d label values in the last %d steps lie outside [0, %d) and are not ignore_index - "
+                                     "torch.nn.CrossEntropyLoss would raise a device assert; map the label ids to train ids first"
+                                     % (n, len(pending), self.cfg.MODEL.NUM_CLASSES))
             for l, lr in pending:
                 v = float(l)
                 meters.update(loss_seg=v)

@@ -328,6 +328,75 @@ def test_hip_graph_replay_of_the_training_step_is_bit_equal_to_eager(tmp_path, m
     assert eager[-1] < eager[0]
 
 
+def test_hip_graph_falls_back_to_eager_when_the_capture_no_longer_fits(tmp_path, monkeypatch):
+    """MI_GRAPH=1: a batch of another shape, or FrozenBN buffers changed out of band (load_state_dict), must not replay the stale
+    capture: the step runs eager (and the graph is rebuilt after the usual warm-up); losses stay bit-equal to a trainer that never used a graph."""
+    import logging
+    from rnd_semantic_segmentation_amd.host import config as hc
+    from rnd_semantic_segmentation_amd.host.trainer import ASPPTrainer
+    cfg = hc.CfgNode(hc.default_tree())
+    cfg.merge_from_list(["MODEL.FREEZE_BN", True, "MODEL.NUM_CLASSES", 19, "SOLVER.BASE_LR", 5e-4, "OUTPUT_DIR", str(tmp_path)])
+    cfg.freeze()
+    x, lab = _cases.net_inputs(2, 129, 71)
+    xt, lt = torch.from_numpy(x), torch.from_numpy(lab)
+    x1, l1 = xt[:1].contiguous(), lt[:1].contiguous()
+
+    def run(graph):
+        monkeypatch.setenv("MI_GRAPH", "1" if graph else "0")
+        tr = ASPPTrainer("aspp", cfg, [None] * 50, 0, logger=logging.getLogger("graph-fallback"))
+        with torch.no_grad():
+            for m in (tr.feature_extractor, tr.classifier):
+                synth.load_formula_weights(m)
+                m._store.generation += 1
+        losses, states = [], []
+        for it in range(12):
+            if it == 8:                 # out of band: the FrozenBN statistics of one layer change (a checkpoint loaded mid-run)
+                bn = getattr(tr.feature_extractor.backbone.layer3, "0").bn2
+                sd = {k: v.clone() for k, v in bn.state_dict().items()}
+                sd["running_mean"] = sd["running_mean"] + 0.05
+                bn.load_state_dict(sd)
+            a, b = (x1, l1) if it == 6 else (xt, lt)          # step 6: a last partial batch
+            loss, _ = tr.train_step(a, b, 40)
+            tr.iteration += 1
+            losses.append(loss)
+            states.append(getattr(tr, "_graph", None) is not None and tr._graph.get("graph") is not None)
+        torch.cuda.synchronize()
+        return [float(l) for l in losses], states
+
+    eager, _ = run(False)
+    graph, states = run(True)
+    print("eager", eager, "\ngraph", graph, "\ncaptured", states)
+    assert eager == graph
+    assert states[5] and not states[6] and not states[8] and states[-1]          # captured, dropped at the odd batch, dropped again at the reload, rebuilt
+
+
+def test_out_of_range_label_in_any_step_of_the_logging_window_raises(tmp_path):
+    """A label outside [0, NUM_CLASSES) that is not ignore_index makes torch.nn.CrossEntropyLoss raise (device assert).  The fused loss drops it and
+    counts it; the counts of ALL steps since the last flush are summed on the device, so the bad batch need not be the window's last one."""
+    import logging
+    import pytest
+    from rnd_semantic_segmentation_amd.host import config as hc
+    from rnd_semantic_segmentation_amd.host.trainer import ASPPTrainer
+    cfg = hc.CfgNode(hc.default_tree())
+    cfg.merge_from_list(["MODEL.FREEZE_BN", True, "MODEL.NUM_CLASSES", 19, "SOLVER.BASE_LR", 5e-4, "SOLVER.EPOCHS", 1, "OUTPUT_DIR", str(tmp_path)])
+    cfg.freeze()
+    x, lab = _cases.net_inputs(2, 65, 13)
+    xt, good = torch.from_numpy(x), torch.from_numpy(lab)
+    bad = good.clone()
+    bad[0, 10, 10] = 50
+    for loader, raises in (([(xt, bad, None), (xt, good, None), (xt, good, None)], True), ([(xt, good, None)] * 3, False)):
+        tr = ASPPTrainer("aspp", cfg, loader, 0, logger=logging.getLogger("labels"))
+        with torch.no_grad():
+            for m in (tr.feature_extractor, tr.classifier):
+                synth.load_formula_weights(m)
+                m._store.generation += 1
+        if raises:
+            with pytest.raises(ValueError, match="outside"):
+                tr.train()
+        else:
+            tr.train()
+
+
 def test_training_is_bit_reproducible_run_to_run():
     """Every launch of the step has a fixed summation order (split-K slabs and BatchNorm / bias sums are reduced in a fixed order, no
     float atomics), including the stem conv's weight gradient, which runs as patch matrix + 1x1 weight gradient instead of the
