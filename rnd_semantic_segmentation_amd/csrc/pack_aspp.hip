@@ -174,6 +174,106 @@ __global__ void aspp_im2col_kernel(const float* __restrict__ dlow, __bf16* __res
     *reinterpret_cast<bf16x8*>(gmat + m * MI_ASPP_KPAD + k0) = out;
 }
 
+// Row-blocked forms of the two kernels above (one workgroup per output image row): every access to the big tensor is a 16-byte access to a
+// contiguous row segment, and the small one (dlow) is staged in LDS once per source row instead of being re-fetched 4 bytes at a time.
+//
+// col2im: thread item = (pixel w, 4-class group j); a tap plane contributes the contiguous segment z[g][(b, h + (ky-1)d, *)][20 floats] shifted by
+// (kx-1)d pixels: consecutive items read consecutive float4s.  Same association as the reference: (((conv0 + conv1) + conv2) + conv3), conv = bias + taps.
+__global__ __launch_bounds__(256) void aspp_col2im_rows_kernel(const float* __restrict__ z, const float* __restrict__ bias4, float* __restrict__ low,
+                                                               int B, int H, int W, int K, Rates rates) {
+    constexpr int Q = MI_ASPP_ZGW / 4;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const long M = (long)B * H * W, mrow = ((long)b * H + h) * W;
+    for (int item = threadIdx.x; item < W * Q; item += 256) {
+        const int w = item / Q, j = item - w * Q;
+        f32x4 total = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int d = rates.d[r];
+            f32x4 s;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] = (4 * j + e < K) ? bias4[r * K + 4 * j + e] : 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int hh = h + (ky - 1) * d;
+                if ((unsigned)hh >= (unsigned)H) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ww = w + (kx - 1) * d;
+                    if ((unsigned)ww >= (unsigned)W) continue;
+                    const int g = r * 9 + ky * 3 + kx;
+                    const long ms = mrow + (long)(ky - 1) * d * W + ww;
+                    s += *reinterpret_cast<const f32x4*>(z + ((long)g * M + ms) * MI_ASPP_ZGW + 4 * j);
+                }
+            }
+            total = (r == 0) ? s : total + s;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * j + e < K) low[(mrow + w) * K + 4 * j + e] = total[e];
+    }
+}
+
+// im2col: the 12 source rows (rate r, kernel row ky) of dlow that an output row draws from are copied to LDS as bf16 in their own layout ([W][K]
+// contiguous: a straight float4 copy, zero rows where the source row lies outside the image); an LDS table maps every column k = g*K + n of the
+// patch matrix to (LDS offset of its source at pixel 0, pixel shift).  No division on the per-element path.
+constexpr int IM2COL_ROW = 2496;                        // bf16 elements per source-row slot: W * K <= 2496 (W <= 131 at 19 classes); 12 slots + tables = 62.6 KiB
+__global__ __launch_bounds__(256) void aspp_im2col_rows_kernel(const float* __restrict__ dlow, __bf16* __restrict__ gmat, int B, int H, int W, int K,
+                                                               Rates rates) {
+    __shared__ __attribute__((aligned(16))) __bf16 rows[12 * IM2COL_ROW];
+    __shared__ __attribute__((aligned(16))) int kbase[MI_ASPP_KPAD];       // slot * IM2COL_ROW + shift * K + n; padding column: any valid offset
+    __shared__ __attribute__((aligned(16))) short kshift[MI_ASPP_KPAD];    // pixel shift; padding column: -30000 (always out of range)
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const long mrow = ((long)b * H + h) * W;
+    for (int k = threadIdx.x; k < MI_ASPP_KPAD; k += 256) {
+        int base = 0, sh = -30000;
+        if (k < 36 * K) {
+            const int g = k / K, n = k - g * K;
+            const int r = g / 9, tap = g - r * 9;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            sh = -(kx - 1) * rates.d[r];                // out[p] += W_tap x[p + s]  =>  dx[q] += W_tap^T dout[q - s]
+            base = (r * 3 + ky) * IM2COL_ROW + sh * K + n;
+        }
+        kbase[k] = base;
+        kshift[k] = (short)sh;
+    }
+    typedef f32x4 __attribute__((aligned(4))) f32x4_a4;      // a source row starts at a multiple of W * K floats: 4-byte aligned, 16-byte loads all the same
+    const int rowlen = W * K, row4 = rowlen >> 2;
+    for (int slot = 0; slot < 12; ++slot) {
+        const int r = slot / 3, ky = slot - r * 3;
+        const int hh = h - (ky - 1) * rates.d[r];
+        __bf16* dst = rows + slot * IM2COL_ROW;
+        const bool inside = (unsigned)hh < (unsigned)H;
+        const float* src = dlow + (((long)b * H + (inside ? hh : h)) * W) * K;
+        for (int i = threadIdx.x; i < row4; i += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4_a4*>(src + 4 * i);
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (__bf16)(inside ? v[e] : 0.f);
+            *reinterpret_cast<bf16x4*>(dst + 4 * i) = o;
+        }
+        for (int i = 4 * row4 + threadIdx.x; i < rowlen; i += 256) dst[i] = (__bf16)(inside ? src[i] : 0.f);
+    }
+    __syncthreads();
+    constexpr int CH = MI_ASPP_KPAD / 8;
+    typedef int __attribute__((ext_vector_type(4))) i32x4;
+    typedef short __attribute__((ext_vector_type(8))) s16x8;
+    for (int item = threadIdx.x; item < W * CH; item += 256) {
+        const int w = item / CH, k0 = (item - w * CH) * 8;
+        const int wk = w * K;
+        const i32x4 b0 = *reinterpret_cast<const i32x4*>(kbase + k0), b1 = *reinterpret_cast<const i32x4*>(kbase + k0 + 4);
+        const s16x8 sh = *reinterpret_cast<const s16x8*>(kshift + k0);
+        bf16x8 out;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool in = (unsigned)(w + sh[e]) < (unsigned)W;
+            const __bf16 x = rows[in ? (e < 4 ? b0[e] : b1[e - 4]) + wk : 0];
+            out[e] = in ? x : (__bf16)0.f;
+        }
+        *reinterpret_cast<bf16x8*>(gmat + (mrow + w) * MI_ASPP_KPAD + k0) = out;
+    }
+}
+
 inline unsigned nblk(long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
 }  // namespace
@@ -223,8 +323,12 @@ extern "C" int mi_aspp_col2im(const float* z, const float* bias4, float* low, in
         MI_REQUIRE(rates4[i] >= 1, "mi_aspp_col2im: rate");
         r.d[i] = rates4[i];
     }
-    const long n = (long)B * H * W * MI_ASPP_ZGW;
-    hipLaunchKernelGGL(aspp_col2im_kernel, dim3(nblk(n, 320)), dim3(320), 0, (hipStream_t)stream, z, bias4, low, B, H, W, K, r);
+    if (mi_aligned16(z) && (long)B * H < (1L << 31)) {
+        hipLaunchKernelGGL(aspp_col2im_rows_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, z, bias4, low, B, H, W, K, r);
+    } else {
+        const long n = (long)B * H * W * MI_ASPP_ZGW;
+        hipLaunchKernelGGL(aspp_col2im_kernel, dim3(nblk(n, 320)), dim3(320), 0, (hipStream_t)stream, z, bias4, low, B, H, W, K, r);
+    }
     MI_CHECK_LAUNCH("mi_aspp_col2im");
     return MI_OK;
 }
@@ -234,8 +338,14 @@ extern "C" int mi_aspp_im2col(const float* dlow, void* g, int B, int H, int W, i
     MI_REQUIRE(mi_aligned16(g), "mi_aspp_im2col: alignment");
     Rates r;
     for (int i = 0; i < 4; ++i) r.d[i] = rates4[i];
-    const long n = (long)B * H * W * (MI_ASPP_KPAD / 8);
-    hipLaunchKernelGGL(aspp_im2col_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, dlow, (__bf16*)g, B, H, W, K, r);
+    bool small_shift = (long)W * K <= IM2COL_ROW;
+    for (int i = 0; i < 4; ++i) small_shift = small_shift && r.d[i] >= 1 && r.d[i] < 30000;
+    if (small_shift) {         // the row-blocked kernel: a source row fits its LDS slot, a shift fits the table's byte
+        hipLaunchKernelGGL(aspp_im2col_rows_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, dlow, (__bf16*)g, B, H, W, K, r);
+    } else {
+        const long n = (long)B * H * W * (MI_ASPP_KPAD / 8);
+        hipLaunchKernelGGL(aspp_im2col_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, dlow, (__bf16*)g, B, H, W, K, r);
+    }
     MI_CHECK_LAUNCH("mi_aspp_im2col");
     return MI_OK;
 }

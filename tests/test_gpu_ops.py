@@ -705,3 +705,40 @@ def test_stem_weight_gradient_patch_matrix_plus_1x1_wgrad_vs_torch(B, H, W):
     want = torch.nn.functional.conv2d(x.float(), w.to(torch.bfloat16).float(), None, 2, 3).permute(0, 2, 3, 1)
     assert relmax(y.float().cpu().numpy(), want.numpy()) < 2.0 ** -8
     assert torch.equal(K.stem_wgrad(dyd, col=col), dw)
+
+
+@pytest.mark.parametrize("B,H,W,ncls", [(2, 21, 19, 19), (1, 30, 131, 19), (2, 97, 97, 19), (1, 9, 40, 7)])
+def test_aspp_col2im_and_im2col_rows_vs_torch(B, H, W, ncls):
+    """mi_aspp_col2im (36 shifted tap planes + bias -> logits, the reference's association order classifier.py:26-29) and mi_aspp_im2col (the patch
+    matrix of d loss / d logits) in their row-blocked forms (W <= 128) and the per-element forms (wider maps), against torch index arithmetic.
+    col2im sums fp32 values in the reference's order: bit-exact; im2col moves bf16-rounded values: bit-exact."""
+    rates = [6, 12, 18, 24]
+    g = torch.Generator().manual_seed(B * H + W)
+    M = B * H * W
+    z = torch.randn(36, M, 20, generator=g)
+    bias = torch.randn(4, ncls, generator=g)
+    low = K.aspp_col2im(z.to(DEV).contiguous(), bias.to(DEV), B, H, W, ncls, rates)
+    zz = z.view(36, B, H, W, 20)
+    want = None
+    for r, d in enumerate(rates):
+        s = bias[r].view(1, 1, 1, ncls).expand(B, H, W, ncls).clone()
+        for ky in range(3):
+            for kx in range(3):
+                dy, dx = (ky - 1) * d, (kx - 1) * d
+                h0, h1, w0, w1 = max(0, -dy), min(H, H - dy), max(0, -dx), min(W, W - dx)
+                if h0 < h1 and w0 < w1:
+                    s[:, h0:h1, w0:w1] += zz[r * 9 + ky * 3 + kx][:, h0 + dy:h1 + dy, w0 + dx:w1 + dx, :ncls]
+        want = s if want is None else want + s
+    assert torch.equal(low.cpu().view(B, H, W, ncls), want)
+    dlow = torch.randn(B, H, W, ncls, generator=g)
+    gm = K.aspp_im2col(dlow.to(DEV), rates)
+    ref = torch.zeros(B, H, W, K.ASPP_KPAD)
+    for r, d in enumerate(rates):
+        for ky in range(3):
+            for kx in range(3):
+                dy, dx = (ky - 1) * d, (kx - 1) * d           # dx[q] += W_tap^T dout[q - s]
+                h0, h1, w0, w1 = max(0, dy), min(H, H + dy), max(0, dx), min(W, W + dx)
+                col = (r * 9 + ky * 3 + kx) * ncls
+                if h0 < h1 and w0 < w1:
+                    ref[:, h0:h1, w0:w1, col:col + ncls] = dlow[:, h0 - dy:h1 - dy, w0 - dx:w1 - dx]
+    assert torch.equal(gm.float().cpu().view(B, H, W, -1), ref.to(torch.bfloat16).float())
