@@ -745,6 +745,96 @@ __global__ __launch_bounds__(256) void gresize_bwd_pix_kernel(const T* dout, T* 
     }
 }
 
+// 8-channel forms for bf16 feature maps whose views allow 16-byte accesses (C % 8 == 0, 16-byte aligned rows): thread item = (pixel, 8-channel
+// chunk), four 16-byte loads and one store forward; backward the same candidate walk as gresize_bwd_pix_kernel (same order of additions per
+// channel: identical results) with one 16-byte load per contributing destination pixel instead of 2-byte loads per lane.
+__global__ __launch_bounds__(256) void gresize_fwd8_kernel(const __bf16* x, __bf16* out, ResizeP q) {
+    const int c8n = q.C >> 3;
+    const long n = (long)q.B * q.Ho * q.Wo * c8n;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % c8n) * 8;
+        long m = e / c8n;
+        const int ow = (int)(m % q.Wo);
+        const long t = m / q.Wo;
+        const int oh = (int)(t % q.Ho), b = (int)(t / q.Ho);
+        int h0, hp, w0, wp;
+        float hl, wl;
+        rs_src(oh, q.sh, q.align, q.H, h0, hp, hl);
+        rs_src(ow, q.sw, q.align, q.W, w0, wp, wl);
+        const __bf16* r0 = x + (((long)b * q.H + h0) * q.W) * q.ldx + c;
+        const __bf16* r1 = r0 + (long)hp * q.W * q.ldx;
+        const bf16x8 v00 = *reinterpret_cast<const bf16x8*>(r0 + (long)w0 * q.ldx), v01 = *reinterpret_cast<const bf16x8*>(r0 + (long)(w0 + wp) * q.ldx);
+        const bf16x8 v10 = *reinterpret_cast<const bf16x8*>(r1 + (long)w0 * q.ldx), v11 = *reinterpret_cast<const bf16x8*>(r1 + (long)(w0 + wp) * q.ldx);
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            o[k] = (__bf16)((1.f - hl) * ((1.f - wl) * (float)v00[k] + wl * (float)v01[k]) + hl * ((1.f - wl) * (float)v10[k] + wl * (float)v11[k]));
+        *reinterpret_cast<bf16x8*>(out + m * q.ldo + c) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void gresize_bwd8_kernel(const __bf16* dout, __bf16* dx, ResizeP q) {
+    const int c8n = q.C >> 3;
+    const long n = (long)q.B * q.H * q.W * c8n;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int c = (int)(e % c8n) * 8;
+    const long m = e / c8n;
+    const int iw = (int)(m % q.W);
+    const long t = m / q.W;
+    const int ih = (int)(t % q.H), b = (int)(t / q.H);
+    auto range = [&](int i, float scale, int out, int& lo, int& hi) {
+        if (scale <= 0.f) {
+            lo = 0;
+            hi = out - 1;
+            return;
+        }
+        const float off = q.align ? 0.f : 0.5f;
+        lo = (int)floorf(((float)(i - 1) + off) / scale - off) - 2;
+        hi = (int)ceilf(((float)(i + 1) + off) / scale - off) + 2;
+        if (lo < 0) lo = 0;
+        if (hi > out - 1) hi = out - 1;
+    };
+    int hlo, hhi, wlo, whi;
+    range(ih, q.sh, q.Ho, hlo, hhi);
+    range(iw, q.sw, q.Wo, wlo, whi);
+    float s[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = 0.f;
+    for (int oh = hlo; oh <= hhi; ++oh) {
+        int h0, hp;
+        float hl;
+        rs_src(oh, q.sh, q.align, q.H, h0, hp, hl);
+        float wh = 0.f;
+        if (h0 == ih) wh += 1.f - hl;
+        if (h0 + hp == ih) wh += hl;
+        if (wh == 0.f) continue;
+        float rsum[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) rsum[k] = 0.f;
+        const __bf16* drow = dout + (((long)b * q.Ho + oh) * q.Wo) * q.ldo + c;
+        for (int ow = wlo; ow <= whi; ++ow) {
+            int w0, wp;
+            float wl;
+            rs_src(ow, q.sw, q.align, q.W, w0, wp, wl);
+            float ww = 0.f;
+            if (w0 == iw) ww += 1.f - wl;
+            if (w0 + wp == iw) ww += wl;
+            if (ww != 0.f) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(drow + (long)ow * q.ldo);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) rsum[k] += ww * (float)v[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] += wh * rsum[k];
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (__bf16)s[k];
+    *reinterpret_cast<bf16x8*>(dx + m * q.ldx + c) = o;
+}
+
 // ------------------------------------------------------------------------------------------------ reverse attention (PraNet_Res2Net.py:131-133)
 // out[m][c] = (1 - sigmoid(gate[m])) * feat[m][c]   ( `-1*(torch.sigmoid(crop)) + 1` expanded over the channels, times the feature )
 __global__ __launch_bounds__(256) void gra_fwd_kernel(const float* gate, const __bf16* feat, long ldf_, __bf16* out, long ldo, long M, int C) {
@@ -963,14 +1053,23 @@ int mi_gresize(const void* x, long ldx, void* out, long ldo, int f32, int B, int
     MI_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && ldx >= C && ldo >= C, "mi_gresize: bad shape");
     ResizeP q{B, H, W, C, Ho, Wo, align_corners, scale_h, scale_w, ldx, ldo};
     hipStream_t s = (hipStream_t)stream;
+    const bool vec8 = !f32 && C % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
     if (!backward) {
+        if (vec8) {
+            hipLaunchKernelGGL(gresize_fwd8_kernel, dim3(grid_for((long)B * Ho * Wo * (C / 8))), dim3(256), 0, s, (const __bf16*)x, (__bf16*)out, q);
+            MI_CHECK_LAUNCH("gresize_fwd8_kernel");
+            return MI_OK;
+        }
         const dim3 grid(grid_for((long)B * Ho * Wo * C));
         if (f32) hipLaunchKernelGGL((gresize_fwd_kernel<float>), grid, dim3(256), 0, s, (const float*)x, (float*)out, q);
         else hipLaunchKernelGGL((gresize_fwd_kernel<__bf16>), grid, dim3(256), 0, s, (const __bf16*)x, (__bf16*)out, q);
     } else {       // x = dx (written), out = dout (read)
         const long nsrc = (long)B * H * W * C;
         const float mag = (scale_h > 0.f ? 1.f / scale_h : (float)Ho) * (scale_w > 0.f ? 1.f / scale_w : (float)Wo);
-        if (C >= 8 && mag >= 4.f) {                      // feature maps / class logits: one wave per source pixel, lanes over the channels
+        if (vec8 && mag < 64.f) {                        // bf16 feature maps with 16-byte views: thread per (source pixel, 8 channels)
+            const long items = (long)B * H * W * (C / 8);
+            hipLaunchKernelGGL(gresize_bwd8_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, (const __bf16*)out, (__bf16*)const_cast<void*>(x), q);
+        } else if (C >= 8 && mag >= 4.f) {               // feature maps / class logits: one wave per source pixel, lanes over the channels
             const dim3 grid((unsigned)(((long)B * H * W + 3) / 4));
             if (f32) hipLaunchKernelGGL((gresize_bwd_pix_kernel<float>), grid, dim3(256), 0, s, (const float*)out, (float*)const_cast<void*>(x), q);
             else hipLaunchKernelGGL((gresize_bwd_pix_kernel<__bf16>), grid, dim3(256), 0, s, (const __bf16*)out, (__bf16*)const_cast<void*>(x), q);

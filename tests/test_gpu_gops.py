@@ -219,7 +219,8 @@ def test_average_pools(gk, k, s, p, inc, H, W):
 
 
 @pytest.mark.parametrize("H,W,sf,align,f32", [(11, 11, 32, False, True), (44, 44, 0.25, False, True), (11, 11, 2, False, True), (12, 9, 8, False, True),
-                                               (6, 5, 2, True, False), (3, 3, 2, True, False)])
+                                               (6, 5, 2, True, False), (3, 3, 2, True, False), (9, 7, 2, False, False), (16, 12, 0.5, False, False),
+                                               (5, 6, 4, False, False)])
 def test_bilinear_resize_both_conventions(gk, H, W, sf, align, f32):
     """F.interpolate(scale_factor=..., mode='bilinear') with align_corners False (PraNet_Res2Net.py:127-177) on fp32 one-channel maps and
     nn.Upsample(scale_factor=2, align_corners=True) (:67) on bf16 feature maps; forward and backward."""
