@@ -268,8 +268,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (BASELINE: 8; pranet 16, gald 6)")
     ap.add_argument("--size", type=int, default=None, help="crop side (BASELINE: 769; pranet 352)")
-    ap.add_argument("--workload", choices=("deeplab", "pranet", "gald"), default="deeplab",
-                    help="deeplab = BASELINE config[1] (the headline, default); pranet = config[3]; gald = the third model of train_src.py")
+    ap.add_argument("--workload", choices=("deeplab", "deeplab_bn", "pranet", "gald"), default="deeplab",
+                    help="deeplab = BASELINE config[1] (the headline, default); deeplab_bn = the same step with MODEL.FREEZE_BN False (trainable "
+                         "BatchNorm2d on batch statistics); pranet = config[3]; gald = the third model of train_src.py")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
@@ -281,7 +282,7 @@ def main():
         raise SystemExit("bench.py measures the MI355X path; no GPU is visible")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if args.workload != "deeplab":
+    if args.workload not in ("deeplab", "deeplab_bn"):
         if world != 1:
             raise SystemExit("--workload %s is a one-GPU line" % args.workload)
         return aux_workload(args, device)
@@ -298,6 +299,8 @@ def main():
     cfg = hc.CfgNode(hc.default_tree())
     cfg.merge_from_file(os.path.join(ROOT, "configs", "deeplabv2_r101_src.yaml"))
     cfg.merge_from_list(["OUTPUT_DIR", os.path.join(ROOT, "gpurun_out", "bench_out")])
+    if args.workload == "deeplab_bn":
+        cfg.merge_from_list(["MODEL.FREEZE_BN", "False"])
     cfg.freeze()
     import logging
     log = logging.getLogger("bench")
@@ -376,11 +379,12 @@ def main():
         images = args.batch * world * args.steps
         value = images / elapsed
         out = {
-            "metric": "train images/sec at 769x769 bf16 (DeepLabV2-ResNet101 + ASPP)", "value": round(value, 3), "unit": "images/s",
+            "metric": "train images/sec at 769x769 bf16 (DeepLabV2-ResNet101 + ASPP)" + (", MODEL.FREEZE_BN False" if args.workload == "deeplab_bn" else ""),
+            "value": round(value, 3), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "train_src.py DeepLabV2-R101 bf16, %dx%d synthetic Cityscapes crops, batch %d per GPU, %dxMI355X"
-                                   % (args.size, args.size, args.batch, world),
+            "config": {"workload": "train_src.py DeepLabV2-R101 bf16, %dx%d synthetic Cityscapes crops, batch %d per GPU, %dxMI355X%s"
+                                   % (args.size, args.size, args.batch, world, ", trainable BatchNorm2d on batch statistics" if args.workload == "deeplab_bn" else ""),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "weights": "formula (synthetic)",
                        "hip_graph_replay": bool(graph),
                        "final_loss": round(final_loss, 5)},
