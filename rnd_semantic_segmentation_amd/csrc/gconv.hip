@@ -327,7 +327,7 @@ void glaunch_a(const GConvP& p, int avec, int ovec, bool f32, hipStream_t s) {
 template <int BN>
 void glaunch_k(GConvP& p, int avec, int ovec, bool f32, hipStream_t s) {
     if constexpr (BN <= 64) {
-        if (p.Cpad >= 64 && p.T * ((p.Cpad + 63) / 64) >= 2) {
+        if (p.Cpad >= 64 && p.T * ((p.Cpad + 63) / 64) >= 2 && mi_sw().gconv_kc != 32) {
             p.nchunks = (p.Cpad + 63) / 64;
             glaunch_a<BN, 64>(p, avec, ovec, f32, s);
             return;
