@@ -123,11 +123,30 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
     // two register sets: the chunk after next is in flight while the next one waits in registers and the current one is in LDS
     bf16x8 ra0[2 * AQ], rb0[BROWS], ra1[2 * AQ], rb1[BROWS];
     const int total = p.T * p.nchunks;
+    // load() is called for it = 0, 1, 2, ... in order: (tap, chunk, ky, kx) advance with it instead of being divided out of it on every call
+    // (counters of one launch: 113 VALU + 143 SALU instructions per wave and K step beside 16 MFMAs - the waves were issuing index arithmetic half
+    // of their time)
+    int l_tap = 0, l_kc = 0, l_ky = 0, l_kx = 0;
+    const bool unit_stride = p.sh == 1 && p.sw == 1;
+    long boff[BROWS];                                      // this thread's weight rows: offset inside a tap's [Npad][Cpad] plane, channel offset, row in range
+    int bch8[BROWS];
+    bool brow_ok[BROWS];
+#pragma unroll
+    for (int j = 0; j < BROWS; ++j) {
+        const int idx = tid + j * 256;
+        const int nr = idx / BCH, ch = idx - nr * BCH;
+        bch8[j] = ch * 8;
+        brow_ok[j] = idx < BLOADS && n0 + nr < p.Npad;
+        boff[j] = (long)(n0 + nr) * p.Cpad + ch * 8;
+    }
     auto load = [&](int it, bf16x8 (&ra)[2 * AQ], bf16x8 (&rb)[BROWS]) {
         const bool live = it < total;                  // past the end: every lane reads the zero page (cheap, and keeps the issue unconditional)
-        it = live ? it : 0;
-        const int tap = it / p.nchunks, kc = it - tap * p.nchunks;
-        const int ky = tap / p.kw, kx = tap - ky * p.kw;
+        const int tap = l_tap, kc = l_kc, ky = l_ky, kx = l_kx;
+        if (++l_kc == p.nchunks) {
+            l_kc = 0;
+            ++l_tap;
+            if (++l_kx == p.kw) l_kx = 0, ++l_ky;
+        }
         bool ok = am_ok && live;
         int ih, iw;
         if (p.mode == MI_GATHER_FWD) {
@@ -135,9 +154,14 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
             iw = aow * p.sw + kx * p.dw - p.pw;
         } else {
             const int nh = aoh + p.ph - ky * p.dh, nw = aow + p.pw - kx * p.dw;
-            ih = nh / p.sh;
-            iw = nw / p.sw;
-            ok = ok && nh >= 0 && nw >= 0 && ih * p.sh == nh && iw * p.sw == nw;
+            if (unit_stride) {                             // (negative nh / nw fail the unsigned range test below)
+                ih = nh;
+                iw = nw;
+            } else {
+                ih = nh / p.sh;
+                iw = nw / p.sw;
+                ok = ok && nh >= 0 && nw >= 0 && ih * p.sh == nh && iw * p.sw == nw;
+            }
         }
         ok = ok && (unsigned)ih < (unsigned)p.Ha && (unsigned)iw < (unsigned)p.Wa;
         const long pix = ok ? ((long)ab * p.Ha + ih) * p.Wa + iw : 0;
@@ -151,11 +175,8 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
         const __bf16* wt = p.Wp + ((long)tap * p.Npad) * p.Cpad + kc * KC;
 #pragma unroll
         for (int j = 0; j < BROWS; ++j) {
-            const int idx = tid + j * 256;
-            const int nr = idx / BCH, ch = idx - nr * BCH;
-            const int n = n0 + nr;
-            const bool bok = live && idx < BLOADS && n < p.Npad && kc * KC + ch * 8 < p.Cpad;
-            rb[j] = *reinterpret_cast<const bf16x8*>(bok ? wt + (long)n * p.Cpad + ch * 8 : reinterpret_cast<const __bf16*>(g_gzero));
+            const bool bok = live && brow_ok[j] && kc * KC + bch8[j] < p.Cpad;
+            rb[j] = *reinterpret_cast<const bf16x8*>(bok ? wt + boff[j] : reinterpret_cast<const __bf16*>(g_gzero));
         }
     };
     auto stash = [&](int buf, const bf16x8 (&ra)[2 * AQ], const bf16x8 (&rb)[BROWS]) {
@@ -383,7 +404,7 @@ __device__ __forceinline__ s16x4 tr_read(const char* lds_generic) {
 // One workgroup = one (K split, tap, o tile, i tile).  Both operands have the contraction index (pixel) as their memory row, so the
 // tiles are staged pixel-major and the MFMA fragments come from ds_read_b64_tr_b16 (hardware transpose), as in igemm_tn.hip.
 template <int YVEC, int XVEC>
-__global__ __launch_bounds__(256) void gwgrad_kernel(GWgP p) {
+__global__ __launch_bounds__(256, 4) void gwgrad_kernel(GWgP p) {       // four workgroups per CU (<= 128 VGPRs): the large launches are bandwidth-bound, 136 VGPRs cost them 25 %
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * WKP * WRS];      // [buf][dy | x][64 pixels][144 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles = p.o_tiles * p.i_tiles;
@@ -401,15 +422,29 @@ __global__ __launch_bounds__(256) void gwgrad_kernel(GWgP p) {
     const int hw = p.Ho * p.Wo;
 
     bf16x8 ry0[2], rx0[2], ry1[2], rx1[2];
+    // load() is called for kt = 0, 1, 2, ... in order: the (image, row, column) of this thread's two pixel rows advance by 64 pixels per call instead of
+    // being divided out of the pixel index every time (four integer divisions per step and thread in the first version)
+    int cb[2], coh[2], cow[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int m = m_begin + lpx + 32 * h;
+        cb[h] = m / hw;
+        const int rem = m - cb[h] * hw;
+        coh[h] = rem / p.Wo;
+        cow[h] = rem - coh[h] * p.Wo;
+    }
+    const int step_rows = WKP / p.Wo, step_cols = WKP - step_rows * p.Wo;
     auto load = [&](int kt, bf16x8 (&ry)[2], bf16x8 (&rx)[2]) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int m = m_begin + kt * WKP + lpx + 32 * h;
             const bool ok = m < m_end;                 // (a step past the last one has every row >= m_end: zero-page reads)
-            const int mm = ok ? m : 0;
-            ry[h] = gload8<YVEC>(p.dY + (long)mm * p.ldy, o0 + lch * 8, p.O, ok);
-            const int b = mm / hw, rem = mm - b * hw;
-            const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+            ry[h] = gload8<YVEC>(p.dY + (long)(ok ? m : 0) * p.ldy, o0 + lch * 8, p.O, ok);
+            const int b = cb[h], oh = coh[h], ow = cow[h];
+            cow[h] += step_cols;
+            coh[h] += step_rows;
+            if (cow[h] >= p.Wo) cow[h] -= p.Wo, ++coh[h];
+            while (coh[h] >= p.Ho) coh[h] -= p.Ho, ++cb[h];
             const int ih = oh * p.sh + ky * p.dh - p.ph, iw = ow * p.sw + kx * p.dw - p.pw;
             const bool xok = ok && (unsigned)ih < (unsigned)p.Ha && (unsigned)iw < (unsigned)p.Wa;
             const long pix = xok ? ((long)b * p.Ha + ih) * p.Wa + iw : 0;
