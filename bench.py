@@ -429,7 +429,17 @@ def main():
                 traffic_src = {"file": "profiles/pmc.json", "profiled_commit": pmc.get("_meta", {}).get("commit"), "round": pmc.get("_meta", {}).get("round")}
             except (OSError, KeyError, ValueError):
                 pass
-            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(fl / tsec / 1e12, 2), "peak": PEAK_BF16_TFLOPS,
+            if dom == "bn_kernels":      # MODEL.FREEZE_BN False: the elementwise BatchNorm passes together outweigh any one conv kernel - HBM-bound
+                passes = {0: 1, 1: 2, 2: 2, 3: 3, 4: 1}       # tensor passes of [M, C] bf16 per op (sums 1-2 reads, normalise read + write, input gradient 2 reads + write)
+                nbytes = sum(passes[t[1]] * t[4] * t[2] * 2.0 for nm, _, _, _, t in events if nm == "bn_kernels")
+                out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(nbytes / tsec / 1e12, 3), "peak": PEAK_HBM_TBS, "unit": "TB/s",
+                                   "frac": round(nbytes / tsec / 1e12 / PEAK_HBM_TBS, 4), "traffic": None, "launches_per_step": n // inst_steps,
+                                   "avg_launch_us": round(1e6 * tsec / n, 2), "ms_per_step_in_kernel": round(1e3 * tsec / inst_steps, 3),
+                                   "alg_gbytes_per_step": round(nbytes / inst_steps / 1e9, 2),
+                                   "note": "the normalise / backward-sums / input-gradient passes of trainable BatchNorm2d (csrc/batchnorm.hip): algorithmic bytes = "
+                                           "tensor passes x M x C x 2 (residual reads and sign bits not counted)"}
+            else:
+              out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(fl / tsec / 1e12, 2), "peak": PEAK_BF16_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(fl / tsec / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src, "l2": l2,
                                "launches_per_step": n // inst_steps, "avg_launch_us": round(1e6 * tsec / n, 2),
                                "alg_gflop_per_launch": round(fl / n / 1e9, 3), "ms_per_step_in_kernel": round(1e3 * tsec / inst_steps, 3),
