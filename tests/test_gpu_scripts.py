@@ -91,6 +91,22 @@ def test_bench_under_torchrun_nccl_single_rank_exercises_the_reducer():
     assert abs(out2["config"]["final_loss"] - out["config"]["final_loss"]) < 1e-4
 
 
+@pytest.mark.parametrize("workload,extra", [("pranet", ["--batch", "2", "--size", "96"]), ("gald", ["--batch", "1"]), ("deeplab_bn", ["--batch", "2", "--size", "161"])])
+def test_bench_other_workloads_print_the_contract_line(workload, extra):
+    """bench.py --workload pranet | gald | deeplab_bn (BASELINE config[3], the GALD step, the trainable-BatchNorm DeepLab step): one JSON line with the
+    contract's keys, a roofline object for the dominant kernel of the instrumented steps, finite loss."""
+    import math
+    r = run(["bench.py", "--workload", workload, "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + extra, {})
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in out, k
+    assert out["value"] > 0 and out["steps"] == 2 and out["unit"] == "images/s" and "workload" in out["config"]
+    assert out["roofline"]["bound"] in ("mfma", "hbm") and out["roofline"]["kernel"]
+    loss = out.get("loss", out["config"].get("final_loss"))
+    assert loss is not None and math.isfinite(loss)
+
+
 def test_opt_in_kernel_variants_and_single_stream_schedule_stay_correct():
     """Selections of the product library that are not the default still have to be right: the 128-wide kernel on the shapes the ping-pong
     main loop normally takes (MI_IGEMM_PP=0), the tap-major contraction order, the 4-wave fused-row 3x3 weight gradient forced onto tiny
