@@ -707,10 +707,10 @@ def test_stem_weight_gradient_patch_matrix_plus_1x1_wgrad_vs_torch(B, H, W):
     assert torch.equal(K.stem_wgrad(dyd, col=col), dw)
 
 
-@pytest.mark.parametrize("B,H,W,ncls", [(2, 21, 19, 19), (1, 30, 131, 19), (2, 97, 97, 19), (1, 9, 40, 7)])
+@pytest.mark.parametrize("B,H,W,ncls", [(2, 21, 19, 19), (1, 30, 131, 19), (1, 12, 140, 19), (2, 97, 97, 19), (1, 9, 40, 7)])
 def test_aspp_col2im_and_im2col_rows_vs_torch(B, H, W, ncls):
     """mi_aspp_col2im (36 shifted tap planes + bias -> logits, the reference's association order classifier.py:26-29) and mi_aspp_im2col (the patch
-    matrix of d loss / d logits) in their row-blocked forms (W <= 128) and the per-element forms (wider maps), against torch index arithmetic.
+    matrix of d loss / d logits) in their row-blocked forms and im2col's per-element form (W * classes > 2496: the 140-wide case), against torch index arithmetic.
     col2im sums fp32 values in the reference's order: bit-exact; im2col moves bf16-rounded values: bit-exact."""
     rates = [6, 12, 18, 24]
     g = torch.Generator().manual_seed(B * H + W)
