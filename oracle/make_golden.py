@@ -492,6 +492,26 @@ def g_pranet(ref, out):
     save(out, "g12_pranet_96", **full)
 
 
+def g_pranet_lr(ref, out):
+    """G12 (learning-rate schedule of pranet_trainer.py:97-104): the reference's own GradualWarmupScheduler(multiplier 8, 5 epochs)
+    (core/utils/adapt_lr.py:19-45, imported as is) chained to torch's CosineAnnealingLR(T_max 100), stepped once per epoch as the trainer
+    does: the learning rate every one of the first 40 epochs trains with, for Adam(BASE_LR / 8) of configs/pranet_src_polyp.yaml."""
+    import warnings
+    from core.utils.adapt_lr import GradualWarmupScheduler
+    base = 1e-4 / 8
+    opt = torch.optim.Adam([nn.Parameter(torch.zeros(1))], base)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cosine = torch.optim.lr_scheduler.CosineAnnealingLR(opt, 100, eta_min=0, last_epoch=-1)
+        sched = GradualWarmupScheduler(opt, multiplier=8, total_epoch=5, after_scheduler=cosine)
+        lrs = []
+        for _ in range(40):
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sched.step()
+    save(out, "g12_pranet_lr", base_lr=np.float64(base), lrs=np.array(lrs, np.float64))
+
+
 def import_gald():
     """The reference's GALD / GCPA modules: core/models/classifiers/gcpacc/gcpa_cc2.py (GCPAEncoder / GCPADecoder),
     encoders/hardnet_68.py, contextagg/ccnet.py (CrissCrossAttention), contextagg/GALDNet.py (LocalAttenModule), gcpa_gald.py (FAM).
@@ -829,7 +849,7 @@ def main():
     torch.set_num_threads(8)
     ref = import_reference()
     jobs = dict(conv=lambda: g_conv(ref, args.out), aspp=lambda: g_aspp(ref, args.out),
-                frozenbn=lambda: g_frozenbn(ref, args.out), tinynet=lambda: g_tinynet(ref, args.out), tinynet_bn=lambda: g_tinynet_bn(ref, args.out), structure_loss=lambda: g_structure_loss(ref, args.out), pranet=lambda: g_pranet(ref, args.out), gald=lambda: g_gald(ref, args.out),
+                frozenbn=lambda: g_frozenbn(ref, args.out), tinynet=lambda: g_tinynet(ref, args.out), tinynet_bn=lambda: g_tinynet_bn(ref, args.out), structure_loss=lambda: g_structure_loss(ref, args.out), pranet=lambda: g_pranet(ref, args.out), pranet_lr=lambda: g_pranet_lr(ref, args.out), gald=lambda: g_gald(ref, args.out),
                 r101=lambda: g_r101(ref, args.out, not args.skip_big), metrics=lambda: g_metrics(ref, args.out),
                 fada=lambda: g_fada(ref, args.out))
     for name, fn in jobs.items():

@@ -678,7 +678,9 @@ size_t mi_gconv_stats_elems(int B, int Ho, int Wo, int N) { return (size_t)(((lo
 
 size_t mi_gconv_wgrad_workspace(int B, int Ho, int Wo, int O, int I, int kh, int kw) {
     int S, rows, ot, it;
-    gwgrad_plan(B * Ho * Wo, O, I, kh * kw, &S, &rows, &ot, &it);
+    const long M = (long)B * Ho * Wo;
+    if (M <= 0 || M >= (1L << 31)) return 0;          // mi_gconv_wgrad refuses such a shape
+    gwgrad_plan((int)M, O, I, kh * kw, &S, &rows, &ot, &it);
     return (size_t)S * kh * kw * O * ((I + 3) & ~3) * sizeof(float);
 }
 
@@ -688,6 +690,8 @@ int mi_gconv_wgrad(const void* dy, long ldy, const void* x, long ldx, float* dw,
     MI_REQUIRE(dy && x && dw && workspace, "mi_gconv_wgrad: null operand");
     MI_REQUIRE(B > 0 && Ha > 0 && Wa > 0 && Ho > 0 && Wo > 0 && I > 0 && O > 0, "mi_gconv_wgrad: empty shape");
     MI_REQUIRE(ldy >= O && ldx >= I, "mi_gconv_wgrad: a view's row stride is smaller than its channel count");
+    MI_REQUIRE(kh > 0 && kw > 0 && sh > 0 && sw > 0 && dh > 0 && dw_ > 0 && ph >= 0 && pw >= 0, "mi_gconv_wgrad: bad conv geometry");
+    MI_REQUIRE((long)B * Ho * Wo < (1L << 31) && (long)B * Ha * Wa < (1L << 31), "mi_gconv_wgrad: more than 2^31 pixels");
     MI_REQUIRE((Ha + 2 * ph - dh * (kh - 1) - 1) / sh + 1 == Ho && (Wa + 2 * pw - dw_ * (kw - 1) - 1) / sw + 1 == Wo,
                "mi_gconv_wgrad: output %dx%d does not follow from input %dx%d", Ho, Wo, Ha, Wa);
     MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "mi_gconv_wgrad: workspace must be 16-byte aligned");

@@ -41,6 +41,7 @@ class FlatStore:
         self.data = torch.zeros(off, dtype=torch.float32, device=device)
         self.grad = torch.zeros(off, dtype=torch.float32, device=device)
         self.written = set()      # ids of params whose .grad the engine has overwritten since zero_grad
+        self.dirty = set()        # ids of params whose slot holds a gradient of SOME backward pass (tape engines: see zero_stale)
         self.generation = 0       # bumped by FusedSGD.step (raw-pointer updates do not bump torch versions)
         self.grad_hooks = []      # callables(store, lo, hi) fired when grads [lo, hi) are final (DDP)
         with torch.no_grad():
@@ -51,6 +52,18 @@ class FlatStore:
                 p.grad = self.grad[o:o + p.numel()].view_as(p)
                 p._mi_store = self
                 p._mi_off = o
+
+    def zero_stale(self):
+        """zero_grad() of the tape engines only forgets which slots were written (the next backward overwrites them).  A backward pass that
+        does NOT reach a parameter (a loss on some outputs only, an input branch without gradient) would leave the previous pass's values in its
+        slot for the optimizer to apply: after a pass, slots written by an earlier pass and not by this one are cleared - what torch's
+        zero_grad(set_to_none=False) leaves there."""
+        stale = self.dirty - self.written
+        if stale:
+            for p in self.params:
+                if id(p) in stale:
+                    self.grad[p._mi_off:p._mi_off + p.numel()].zero_()
+        self.dirty = set(self.written)
 
     def owns(self, p):
         return getattr(p, "_mi_store", None) is self and p.data_ptr() == self.data.data_ptr() + 4 * p._mi_off

@@ -104,6 +104,7 @@ class _GaldRun(_Run):
         """criterion(F.interpolate(low, size=labels.shape[-2:], mode="bilinear"), labels) (gcpa_cc2.py:78-81 + gald_trainer.py:76-79) fused: the
         full-resolution logits are never written; d loss / d low comes out of the same pass."""
         loss_out, dlow = K.upsample_ce(low.t, labels, want_grad=self.rec, ignore_index=ignore_index, align_corners=False)
+        _count_bad_labels(self.net, loss_out)
         ov = self.var(loss_out[0].clone())
 
         def back():
@@ -141,6 +142,32 @@ class _GaldRun(_Run):
             _acc(v, dv, True)
         self.record(back)
         return ov
+
+
+def _count_bad_labels(holder, loss_out):
+    """Labels outside [0, K) that are not ignore_index are skipped AND counted by the cross-entropy kernels (loss_out[2]); torch's
+    CrossEntropyLoss (gald_trainer.py:107) would device-assert on them.  Every call's count goes into a persistent device counter on `holder`
+    (the decoder / the criterion module), read by GALDTrainer where it fetches the loss anyway."""
+    bad = holder.__dict__.get("bad_labels")
+    if bad is None or bad.device != loss_out.device:
+        bad = holder.__dict__["bad_labels"] = torch.zeros(1, dtype=torch.float32, device=loss_out.device)
+    bad.add_(loss_out[2:3])
+
+
+def take_bad_labels(*holders):
+    """Sum and reset the counters of `_count_bad_labels` (one host sync); under torch.distributed the sum is all-reduced first so that every rank
+    sees the same count and raises (or not) together."""
+    bads = [h.__dict__.get("bad_labels") for h in holders]
+    bads = [b for b in bads if b is not None]
+    if not bads:
+        return 0
+    total = torch.stack([b.reshape(()) for b in bads]).sum().reshape(1)
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        torch.distributed.all_reduce(total)
+    n = int(total.item())
+    for b in bads:
+        b.zero_()
+    return n
 
 
 # ------------------------------------------------------------------------------------------------ HarDNet-68
@@ -328,11 +355,13 @@ class GCPADecoder(_Engine):
 
 class _NhwcCEFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits_nchw, labels, ignore_index):
+    def forward(ctx, logits_nchw, labels, ignore_index, holder):
         nhwc = logits_nchw.permute(0, 2, 3, 1)                                     # the decoder's outputs ARE NHWC memory: a free view
         if not nhwc.is_contiguous():
             nhwc = nhwc.contiguous()
         out, d = gk.gce(nhwc, labels.contiguous(), ignore_index, want_grad=logits_nchw.requires_grad)
+        if holder is not None:
+            _count_bad_labels(holder, out)
         ctx.d = d
         return out[0].clone()
 
@@ -340,7 +369,7 @@ class _NhwcCEFn(torch.autograd.Function):
     def backward(ctx, gout):
         d = ctx.d
         ctx.d = None
-        return (d * gout).permute(0, 3, 1, 2), None, None
+        return (d * gout).permute(0, 3, 1, 2), None, None, None
 
 
 class CrossEntropyNHWC(nn.Module):
@@ -353,7 +382,7 @@ class CrossEntropyNHWC(nn.Module):
     def forward(self, logits, target):
         if not logits.is_cuda:
             raise _lib.MiError("CrossEntropyNHWC runs on the MI355X only")
-        return _NhwcCEFn.apply(logits.float(), target.long(), self.ignore_index)
+        return _NhwcCEFn.apply(logits.float(), target.long(), self.ignore_index, self)
 
 
 class GALDTrainer(BaseTrainer):
@@ -419,6 +448,10 @@ class GALDTrainer(BaseTrainer):
             loss, _ = self.train_step(src_input, src_label, max_iter)
             self.lr_data.append(self.optimizer_enc.param_groups[0]["lr"])
             self.loss_data.append(loss.item())
+            bad = take_bad_labels(self.decoder, self.criterion)      # (the loss was fetched above: the step is complete on the device)
+            if bad:
+                raise ValueError("train labels: %d label values lie outside [0, %d) and are not ignore_index - torch.nn.CrossEntropyLoss "
+                                 "(gald_trainer.py:107) would raise a device assert; map the label ids to train ids first" % (bad, self.cfg.MODEL.NUM_CLASSES))
             if i % 20 == 0 or i == n:
                 self.logger.info("{} Epoch [{:03d}/{:03d}], Step [{:04d}/{:04d}], loss: [{:0.4f}], encode_learning_rate: [{:0.8f}], decode_learning_rate: [{:0.8f}]".format(
                     datetime.now(), epoch, self.cfg.SOLVER.EPOCHS, i, n, self.loss_data[-1], self.optimizer_enc.param_groups[0]["lr"], self.optimizer_dec.param_groups[0]["lr"]))

@@ -695,6 +695,7 @@ class _EngineFn(torch.autograd.Function):
             if g is not None:
                 o.g, o.own = (g.permute(0, 2, 3, 1).to(o.t.dtype).contiguous() if g.dim() == 4 else g), True
         run.backward()
+        run.net._store.zero_stale()          # parameters this pass did not reach must not keep the previous pass's gradient
         gin = [None if (v.g is None) else v.g.permute(0, 3, 1, 2).to(dt) for v, dt in zip(ctx.ins, ctx.in_dtypes)]
         ctx.run = ctx.ins = ctx.outs = None
         return (None, None) + tuple(gin) + (None,) * (len(ctx.needs_input_grad) - 2 - ctx.n_in)
@@ -926,12 +927,14 @@ class GraphedStep:
 
 def warmup_cosine_lr(base_lr, steps, multiplier=8.0, warm=5, t_max=100):
     """Learning rate after `steps` calls of scheduler.step() in pranet_trainer.py:97-104: GradualWarmupScheduler(multiplier=8, total_epoch=5)
-    (core/utils/adapt_lr.py:19-45) climbs linearly from base_lr to 8 * base_lr over 5 epochs, holds it for the hand-over epoch, then
-    CosineAnnealingLR(T_max=100, eta_min=0) takes over from 8 * base_lr."""
+    (core/utils/adapt_lr.py:19-45) climbs linearly from base_lr to 8 * base_lr over 5 epochs, then hands over to CosineAnnealingLR(T_max=100,
+    eta_min=0).  The hand-over as the reference's chain performs it (pinned by tests/golden/g12_pranet_lr.npz, written by running that chain):
+    the cosine scheduler continues RECURSIVELY from the group's current rate 8 * base_lr with its own epoch counter already at 1, so epoch
+    warm + 1 overshoots to 8 * base_lr * 2 / (1 + cos(pi / t_max)) and every later rate keeps that factor over the textbook closed form."""
     if steps <= warm:
         return base_lr * ((multiplier - 1.0) * steps / warm + 1.0)
     t = steps - warm - 1
-    return base_lr * multiplier * (1.0 + math.cos(math.pi * t / t_max)) / 2.0
+    return base_lr * multiplier * (1.0 + math.cos(math.pi * t / t_max)) / (1.0 + math.cos(math.pi / t_max))
 
 
 def clip_gradient(optimizer, grad_clip):

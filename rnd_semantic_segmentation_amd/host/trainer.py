@@ -224,6 +224,8 @@ class ASPPTrainer(BaseTrainer):
         def flush():
             bad = getattr(getattr(self.classifier, "_engine", None), "bad_labels", None)
             if bad is not None and pending:                 # the losses are fetched here anyway: one more float, summed over every step since the last flush
+                if self.world_size > 1 and torch.distributed.is_initialized():      # every rank must raise (or not) together: a lone ValueError would leave
+                    torch.distributed.all_reduce(bad)                               # the other ranks blocked in the next collective
                 n = int(bad.item())
                 bad.zero_()
                 if n:

@@ -286,3 +286,15 @@ def test_optimizer_state_dict_interchanges_with_reference_order():
         back.load_state_dict(opt.state_dict())          # this build's checkpoint -> the reference
         for p_ref, p in zip(ref_mod.parameters(), params):
             assert back.state[p_ref]["momentum_buffer"].shape == p_ref.shape
+
+
+def test_pranet_warmup_cosine_schedule_equals_the_references_scheduler_chain():
+    """warmup_cosine_lr against the learning rates the reference's own GradualWarmupScheduler(8, 5) + CosineAnnealingLR(100) chain produced for the
+    first 40 epochs (g12_pranet_lr, pranet_trainer.py:97-104 / core/utils/adapt_lr.py:19-45): the linear warm-up AND the hand-over quirk (the
+    cosine scheduler continues recursively from 8 * base_lr with its epoch counter already at 1: epoch 6 overshoots to 1.000247e-4)."""
+    from rnd_semantic_segmentation_amd.host.pranet import warmup_cosine_lr
+    g = _cases.load("g12_pranet_lr")
+    base, lrs = float(g["base_lr"]), g["lrs"]
+    assert len(lrs) == 40 and lrs[6] > lrs[5] == 8 * base                        # the overshoot is in the fixture
+    for k, want in enumerate(lrs):
+        assert abs(warmup_cosine_lr(base, k) / want - 1) < 1e-12, (k, warmup_cosine_lr(base, k), want)
