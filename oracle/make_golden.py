@@ -414,7 +414,7 @@ def _grad_norms(module):
 def g_pranet(ref, out):
     """G12: module-level and whole-net fixtures of the PraNet path with formula weights - a Res2Net bottleneck of
     each kind ('normal', 'stage' with the avg-pool downsample), RFB_modified, the partial decoder (aggregation), and PraNet at
-    2 x 3 x 96 x 96: eval-mode lateral maps, train-mode (batch statistics) structure-loss sum of pranet_trainer.py:50-56 and the
+    8 x 3 x 160 x 160: eval-mode lateral maps, train-mode (batch statistics) structure-loss sum of pranet_trainer.py:50-56 and the
     gradient norm of every parameter; state_dict keys and parameter count of the full model."""
     from core.trainers.pranet_trainer import PraNetTrainer
     import warnings
@@ -449,15 +449,17 @@ def g_pranet(ref, out):
     # ---- the whole net
     torch.manual_seed(0)
     net = P.PraNet(channel=32)
-    synth.load_formula_weights(net, prefix="pranet.")
+    synth.load_formula_weights(net, prefix="pranet.", bn_bias=synth.COND_BN_BIAS)          # the conditioned regime (host/synth.py)
     keys = list(net.state_dict().keys())
     with open(os.path.join(out, "g8_pranet_keys.json"), "w") as f:
         json.dump({"keys": keys, "n_params": sum(p.numel() for p in net.parameters()), "n_tensors": len(list(net.parameters()))}, f)
-    B, S = 2, 96
+    # 8 x 3 x 160 x 160: the deepest maps are 5 x 5, i.e. 200 samples per BatchNorm channel (the first fixture, 2 x 3 x 96 x 96, had 18, and the
+    # reference's own bf16-autocast run deviated from this fp32 run by more than 100 % there)
+    B, S = 8, 160
     x = synth.synth_image(B, S, S, seed=31)
     blob = synth.uniform("pn.gt", (B, 1, S // 8, S // 8))
     gt = F.avg_pool2d(t(np.kron((blob > 0.1).astype(np.float32), np.ones((8, 8), np.float32))), 5, 1, 2).numpy()
-    full = dict(x_seed=31, gt=gt)
+    full = dict(x_seed=31, gt_sha=sha(gt))
     net.train()
     outs = net(t(x))
     with warnings.catch_warnings():
@@ -468,15 +470,15 @@ def g_pranet(ref, out):
     full["train_losses"] = np.array([l.item() for l in losses])
     full["train_loss"] = np.float64(loss.item())
     for i, m in enumerate(outs):
-        full["train_map%d_crop" % i] = m.detach().numpy()[:, :, ::4, ::4].copy()
+        full["train_map%d_crop" % i] = m.detach().numpy()[:, :, ::8, ::8].copy()
     gn = _grad_norms(net)
     names = sorted(gn)
     full["pnames"] = np.array(names)
     full["pgrad"] = np.array([gn[k] for k in names])
-    # eval(): with the formula running statistics a 50-layer eval forward overflows, so the running statistics are first driven to the
-    # batch statistics the way training does it - 120 more train-mode forwards (momentum 0.1: 0.9^121 = 3e-6 of the initial values left)
+    # eval(): with the formula running statistics a 50-layer eval forward overflows, so the running statistics are first driven towards the
+    # batch statistics the way training does it - 40 more train-mode forwards (momentum 0.1: 0.9^41 = 1.3 % of the initial values left)
     with torch.no_grad():
-        for _ in range(120):
+        for _ in range(40):
             net(t(x))
     sd = net.state_dict()
     full["num_batches_tracked"] = int(sd["resnet.bn1.num_batches_tracked"])
@@ -487,9 +489,22 @@ def g_pranet(ref, out):
     with torch.no_grad():
         maps = [m.numpy() for m in net(t(x))]
     for i, m in enumerate(maps):
-        full["eval_map%d_crop" % i] = m[:, :, ::4, ::4].copy()
+        full["eval_map%d_crop" % i] = m[:, :, ::8, ::8].copy()
         full["eval_map%d_norm" % i] = np.float64(np.sqrt((m.astype(np.float64) ** 2).sum()))
-    save(out, "g12_pranet_96", **full)
+    # what PranetTester.test makes of the reference model's lateral_map_2 (res2) - pranet_tester.py:37-46 restated on it: resize to the label size
+    # (here the input size), sigmoid, min-max normalisation over the batch, argmax of (1 - p, p); the full map of two images, the mask of all
+    res = t(maps[3])
+    res = F.upsample(res, size=(S, S), mode="bilinear", align_corners=False)
+    res = res.sigmoid().data.cpu().numpy().squeeze()
+    res = (res - res.min()) / (res.max() - res.min() + 1e-8)
+    pred = torch.from_numpy(np.stack([1 - res, res], 1)).max(1)[1].numpy()
+    full["eval_map3_full01"] = maps[3][:2].copy()
+    full["eval_mask_bits"] = np.packbits(pred.astype(np.uint8).reshape(-1))
+    full["eval_mask_shape"] = np.array(pred.shape)
+    margin = np.abs(2.0 * res.astype(np.float64) - 1.0).reshape(-1)
+    order = np.argsort(margin)[:64]
+    full["eval_margin_idx"], full["eval_margin"] = order, margin[order]
+    save(out, "g12_pranet_160", **full)
 
 
 def g_pranet_lr(ref, out):
@@ -545,7 +560,7 @@ def g_gald(ref, out):
     (ccnet.py:37-127: affinities along the column and the row through bmm, -inf on the column's own position, ONE softmax over both,
     gamma * aggregation + x), LocalAttenModule (GALDNet.py:124-157: two depthwise 3x3 stride-2 convs without padding + BatchNorm + ReLU,
     bilinear align_corners=True back to the input size, sigmoid gate, x * gate + x), FAM (gcpa_gald.py:47-107), a HarDBlock
-    (hardnet_68.py:83-160) - and the whole GCPAEncoder + GCPADecoder at 2 x 3 x 224 x 224 with the four deep-supervision cross-entropy
+    (hardnet_68.py:83-160) - and the whole GCPAEncoder + GCPADecoder at 4 x 3 x 352 x 352 with the four deep-supervision cross-entropy
     losses weighted 1 / 0.8 / 0.6 / 0.4 (gald_trainer.py:66-84): outputs, losses, every parameter-gradient norm, state_dict keys."""
     R = import_gald()
     arrays = {}
@@ -576,12 +591,14 @@ def g_gald(ref, out):
     # ---- the whole net
     torch.manual_seed(0)
     enc, dec = R.G.GCPAEncoder(), R.G.GCPADecoder()
-    synth.load_formula_weights(enc, prefix="gald.enc.")
-    synth.load_formula_weights(dec, prefix="gald.dec.")
+    synth.load_formula_weights(enc, prefix="gald.enc.", bn_bias=synth.COND_BN_BIAS)        # the conditioned regime (host/synth.py)
+    synth.load_formula_weights(dec, prefix="gald.dec.", bn_bias=synth.COND_BN_BIAS)
     with open(os.path.join(out, "g8_gald_keys.json"), "w") as f:
         json.dump({"encoder": list(enc.state_dict().keys()), "decoder": list(dec.state_dict().keys()),
                    "n_enc": sum(p.numel() for p in enc.parameters()), "n_dec": sum(p.numel() for p in dec.parameters())}, f)
-    B, S = 2, 224
+    # 4 x 3 x 352 x 352: the 1/32 map is 11 x 11, the local attention modules' second depthwise conv leaves 2 x 2 (the first fixture, 2 x 3 x 224 x 224,
+    # left 1 x 1: two samples per BatchNorm channel)
+    B, S = 4, 352
     x = synth.synth_image(B, S, S, seed=51)
     lab = synth.synth_label(B, S, S, 19, seed=51)
     enc.train()
@@ -600,7 +617,33 @@ def g_gald(ref, out):
     ge, gd = _grad_norms(enc), _grad_norms(dec)
     full["enc_pnames"], full["enc_pgrad"] = np.array(sorted(ge)), np.array([ge[k] for k in sorted(ge)])
     full["dec_pnames"], full["dec_pgrad"] = np.array(sorted(gd)), np.array([gd[k] for k in sorted(gd)])
-    save(out, "g13_gald_224", **full)
+    # eval(): 12 more train-mode forwards move the running statistics towards the batch statistics (13 updates at momentum 0.1), then what
+    # GALDTester.test makes of the reference modules' res2 - gald_tester.py:56-70 restated on it: resize to the label size (here the input size),
+    # softmax, argmax
+    with torch.no_grad():
+        for _ in range(12):
+            dec(t(x), enc(t(x)))
+    sde, sdd = enc.state_dict(), dec.state_dict()
+    full["num_batches_tracked"] = int(sdd["conva.1.num_batches_tracked"])
+    for tag, sd_, k in (("enc", sde, "hardnet.base.8.layers.3.norm"), ("enc", sde, "hardnet.base.15.norm"), ("dec", sdd, "fam34.bn3"), ("dec", sdd, "local_attention_3.dconv2.1")):
+        full["stat_%s_%s_mean" % (tag, k.replace(".", "_"))] = sd_[k + ".running_mean"].numpy().copy()
+        full["stat_%s_%s_var" % (tag, k.replace(".", "_"))] = sd_[k + ".running_var"].numpy().copy()
+    enc.eval()
+    dec.eval()
+    with torch.no_grad():
+        res2 = dec(t(x), enc(t(x)))[3]
+        res2 = F.upsample(res2, size=(S, S), mode="bilinear", align_corners=False)
+        prob = F.softmax(res2, dim=1)
+        pred = prob.max(1)[1].numpy()
+    full["eval_res2_crop"] = res2.numpy()[:, :, ::16, ::16].copy()
+    full["eval_res2_norm"] = np.float64(res2.double().norm())
+    full["eval_pred0"] = pred[0].astype(np.uint8)
+    full["eval_pred_sha"] = sha(pred.astype(np.uint8))
+    top2 = torch.topk(res2, 2, dim=1).values
+    margin = (top2[:, 0] - top2[:, 1]).double().reshape(-1).numpy()
+    order = np.argsort(margin)[:256]
+    full["eval_margin_idx"], full["eval_margin"] = order, margin[order]
+    save(out, "g13_gald_352", **full)
 
 
 def eval_record(ref, probs, pred, lab):

@@ -15,6 +15,17 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+def _tap(module, name, t):
+    """Test infrastructure: with a `_taps` dict on the module, named intermediates are kept (and their gradients retained) - the teacher-forced tests
+    feed them to the engine block by block."""
+    taps = module.__dict__.get("_taps")
+    if taps is not None:
+        if t.requires_grad:
+            t.retain_grad()
+        taps[name] = t
+    return t
+
+
 class ConvBN6(nn.Module):
     """conv (no bias, pad k // 2) -> BatchNorm2d -> ReLU6"""
 
@@ -88,7 +99,7 @@ class HarDNet68(nn.Module):
     def forward(self, x):
         outs = []
         for i, m in enumerate(self.base[:-1]):
-            x = m(x)
+            x = _tap(self, "base.%d" % i, m(x))
             if i in self.taps:
                 outs.append(x)
         return outs
@@ -162,6 +173,7 @@ class GCPAEncoder(nn.Module):
         self.hardnet = HarDNet68()
 
     def forward(self, x):
+        self.hardnet.__dict__["_taps"] = self.__dict__.get("_taps")
         return self.hardnet(x)
 
 
@@ -177,13 +189,15 @@ class GCPADecoder(nn.Module):
 
     def forward(self, x, feats):
         f2, f3, f4, f5 = feats
-        top = self.conva(f5)
-        ctx = self.long_relation(self.long_relation(top))                    # the SAME criss-cross module twice (recurrence 2)
-        o4 = self.fam45(f4, top, self.local_attention_4(ctx))
-        o3 = self.fam34(f3, o4, self.local_attention_3(ctx))
-        o2 = self.fam23(f2, o3, self.local_attention_2(ctx))
+        tap = lambda name, t: _tap(self, name, t)
+        top = tap("conva", self.conva(f5))
+        ctx = tap("cca2", self.long_relation(tap("cca1", self.long_relation(top))))      # the SAME criss-cross module twice (recurrence 2)
+        o4 = tap("fam45", self.fam45(f4, top, tap("lam4", self.local_attention_4(ctx))))
+        o3 = tap("fam34", self.fam34(f3, o4, tap("lam3", self.local_attention_3(ctx))))
+        o2 = tap("fam23", self.fam23(f2, o3, tap("lam2", self.local_attention_2(ctx))))
         up = lambda t: F.interpolate(t, size=x.shape[2:], mode="bilinear")
-        return up(self.linear5(top)), up(self.linear4(o4)), up(self.linear3(o3)), up(self.linear2(o2))
+        lows = [tap("linear%d" % i, getattr(self, "linear%d" % i)(v)) for i, v in ((5, top), (4, o4), (3, o3), (2, o2))]
+        return tuple(tap("out%d" % i, up(v)) for i, v in enumerate(lows))
 
 
 def gald_losses(outs, label, ignore_index=255):

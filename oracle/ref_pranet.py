@@ -185,24 +185,40 @@ class PraNet(nn.Module):
     def _resize(x, factor):
         return F.interpolate(x, scale_factor=factor, mode="bilinear")          # align_corners left at its default (False), as in the reference
 
+    def _tap(self, name, t):
+        """Test infrastructure: with a `_taps` dict on the module, named intermediates are kept (and their gradients retained) - the teacher-forced
+        tests feed them to the engine block by block."""
+        taps = self.__dict__.get("_taps")
+        if taps is not None:
+            if t.requires_grad:
+                t.retain_grad()
+            taps[name] = t
+        return t
+
     def forward(self, x):
-        r = self.resnet
-        x1 = r.layer1(r.stem(x))
-        x2 = r.layer2(x1)
-        x3 = r.layer3(x2)
-        x4 = r.layer4(x3)
-        coarse = self.agg1(self.rfb4_1(x4), self.rfb3_1(x3), self.rfb2_1(x2))          # 1/8 resolution, one channel
+        r, tap = self.resnet, self._tap
+        y = tap("stem0", r.conv1[2](r.conv1[1](r.conv1[0](x))))
+        y = tap("stem1", r.conv1[5](r.conv1[4](r.conv1[3](y))))
+        y = tap("stem", F.max_pool2d(F.relu(r.bn1(r.conv1[6](y))), 3, 2, 1))          # = r.stem(x)
+        ends = {}
+        for li in (1, 2, 3, 4):
+            for bi, blk in enumerate(getattr(r, "layer%d" % li)):
+                y = tap("resnet.layer%d.%d" % (li, bi), blk(y))
+            ends[li] = y
+        x2, x3, x4 = ends[2], ends[3], ends[4]
+        f2, f3, f4 = tap("rfb2", self.rfb2_1(x2)), tap("rfb3", self.rfb3_1(x3)), tap("rfb4", self.rfb4_1(x4))
+        coarse = tap("coarse", self.agg1(f4, f3, f2))                                  # 1/8 resolution, one channel
         maps = [self._resize(coarse, 8)]
         # reverse attention, level 4 (1/32): erase what the coarser map already marks as foreground, predict a residual
         g = self._resize(coarse, 0.25)
         y = self.ra4_conv1((1 - torch.sigmoid(g)) * x4)
         y = F.relu(self.ra4_conv4(F.relu(self.ra4_conv3(F.relu(self.ra4_conv2(y))))))
-        g = self.ra4_conv5(y) + g
+        g = tap("ra4", self.ra4_conv5(y) + g)
         maps.append(self._resize(g, 32))
         for lvl, feat, up in ((3, x3, 16), (2, x2, 8)):
             g = self._resize(g, 2)
             y = getattr(self, "ra%d_conv1" % lvl)((1 - torch.sigmoid(g)) * feat)
             y = F.relu(getattr(self, "ra%d_conv3" % lvl)(F.relu(getattr(self, "ra%d_conv2" % lvl)(y))))
-            g = getattr(self, "ra%d_conv4" % lvl)(y) + g
+            g = tap("ra%d" % lvl, getattr(self, "ra%d_conv4" % lvl)(y) + g)
             maps.append(self._resize(g, up))
-        return tuple(maps)
+        return tuple(tap("map%d" % i, m) for i, m in enumerate(maps))

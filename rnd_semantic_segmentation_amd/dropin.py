@@ -35,11 +35,16 @@ ALIASES = {
     "core.utils.utils": _PKG + "pranet",                              # clip_gradient, AvgMeter (core/utils/utils.py:6-38)
     "core.trainers.gald_trainer": _PKG + "gald",                      # core/trainers/gald_trainer.py
     "core.models.classifiers.gcpacc.gcpa_cc2": _PKG + "gald",         # GCPAEncoder, GCPADecoder
+    "core.testers.gald_tester": _PKG + "gald",                        # core/testers/gald_tester.py (made runnable: see GALDTester)
+    "core.models.classifiers.gcpacc.gcpa_gald": _PKG + "gald",        # FAM (gcpa_gald.py:47-107)
+    "core.models.classifiers.gcpacc.encoders.hardnet_68": _PKG + "gald",      # HarDBlock (hardnet_68.py:86-160)
+    "core.models.classifiers.gcpacc.contextagg.ccnet": _PKG + "gald",         # CrissCrossAttention (ccnet.py:37-127)
+    "core.models.classifiers.gcpacc.contextagg.GALDNet": _PKG + "gald",       # LocalAttenModule (GALDNet.py:124-157)
     "core.datasets.build": _PKG + "data",                             # core/datasets/build.py:5-30
     "base.base_trainer": _PKG + "plugin",                             # base/base_trainer.py
     "base.base_model": _PKG + "plugin",                               # base/base_model.py
 }
-PACKAGES = {"core.models", "core.models.classifiers", "core.models.classifiers.aspp", "core.models.classifiers.pranet", "core.models.classifiers.gcpacc", "core.components", "core.trainers", "core.adapters", "core.combos",
+PACKAGES = {"core.models", "core.models.classifiers", "core.models.classifiers.aspp", "core.models.classifiers.pranet", "core.models.classifiers.gcpacc", "core.models.classifiers.gcpacc.encoders", "core.models.classifiers.gcpacc.contextagg", "core.components", "core.trainers", "core.adapters", "core.combos",
             "core.testers", "core.utils", "core.datasets"}
 
 

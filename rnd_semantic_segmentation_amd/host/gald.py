@@ -24,7 +24,7 @@ from .. import _lib
 from .. import gk
 from .. import kernels as K
 from . import arch
-from .metrics import adjust_learning_rate, dump_json
+from .metrics import AverageMeter, adjust_learning_rate, confusion_matrix, dump_json, intersectionAndUnionGPU
 from .plugin import BaseTrainer
 from .pranet import FlatAdam, _acc, _Engine, _grad_target, _Run, _Unit
 
@@ -189,6 +189,47 @@ def _conv_layer(name, cin, cout, k=3, stride=1):
     return _Unit(name + ".conv", name + ".norm", cin, cout, k, stride, k // 2)
 
 
+def _hard_block(run, x, layers, links, out_ch):
+    """HarDBlock.forward (hardnet_68.py:137-160): the layers that make up the block's output (the odd ones and the last) write straight
+    into their channel range of the output buffer; a layer with several links reads a gathered copy."""
+    B, H, W, _ = x.t.shape
+    n = len(layers)
+    keep = [i for i in range(1, n + 1) if i == n or i % 2 == 1]                 # indices into outs (0 = the block input)
+    offs, off = {}, 0
+    for i in keep:
+        offs[i] = off
+        off += layers[i - 1].cout
+    outbuf = gk.new(B, H, W, out_ch, x.t.device, x.t.dtype)
+    outs = [x]
+    for li, (u, lk) in enumerate(zip(layers, links), 1):
+        if len(lk) > 1:
+            cin = sum(outs[j].t.shape[-1] for j in lk)
+            buf = gk.new(B, H, W, cin, x.t.device, x.t.dtype)
+            pieces, o = [], 0
+            for j in lk:
+                c = outs[j].t.shape[-1]
+                pieces.append(run.copy_into(outs[j], buf[..., o:o + c]))
+                o += c
+            inp = run.cat(buf, pieces)
+        else:
+            inp = outs[lk[0]]
+        dst = outbuf[..., offs[li]:offs[li] + u.cout] if li in offs else None
+        outs.append(run.conv_bn(inp, u, 6, out=dst))
+    return run.cat(outbuf, [outs[i] for i in keep])
+
+
+def _hard_block_units(prefix, cin, growth, mul, n):
+    """(units, links, out channels) of HarDBlock(cin, growth, mul, n) with state_dict keys <prefix>layers.<i>.{conv,norm}.*"""
+    layers, links, out_ch = [], [], 0
+    for i in range(n):
+        oc, ic, lk = _hard_link(i + 1, cin, growth, mul)
+        layers.append(_conv_layer("%slayers.%d" % (prefix, i), ic, oc))
+        links.append(lk)
+        if i % 2 == 0 or i == n - 1:
+            out_ch += oc
+    return layers, links, out_ch
+
+
 class GCPAEncoder(_Engine):
     """HarDNet-68 trunk (gcpa_cc2.py:16-23); forward(x [B,3,H,W]) -> the four features at 1/4 (128), 1/8 (320), 1/16 (640), 1/32 (1024),
     bf16, NCHW-shaped views of NHWC memory.  The reference loads 'pretrained/hardnet68.pth', which the image lacks: weights keep the module
@@ -202,13 +243,7 @@ class GCPAEncoder(_Engine):
         self._seq = [("conv", order[0]), ("conv", order[1]), ("pool3", None)]
         ch, idx = 64, 3
         for width, growth, n, down in zip((128, 256, 320, 640, 1024), (14, 16, 20, 40, 160), (8, 16, 16, 16, 4), (1, 0, 1, 1, 0)):
-            layers, links, out_ch = [], [], 0
-            for i in range(n):
-                oc, ic, lk = _hard_link(i + 1, ch, growth, 1.7)
-                layers.append(_conv_layer("%s%d.layers.%d" % (p, idx, i), ic, oc))
-                links.append(lk)
-                if i % 2 == 0 or i == n - 1:
-                    out_ch += oc
+            layers, links, out_ch = _hard_block_units("%s%d." % (p, idx), ch, growth, 1.7, n)
             order += layers
             self._seq.append(("block", (layers, links, out_ch)))
             trans = _conv_layer(p + str(idx + 1), out_ch, width, 1)
@@ -224,58 +259,66 @@ class GCPAEncoder(_Engine):
                   (self._head_key + ".bias", torch.empty(1000).uniform_(-1, 1) / 32.0)]                    # state_dict, never run
         self._register(order)
 
-    def _block(self, run, x, layers, links, out_ch):
-        """HarDBlock.forward (hardnet_68.py:137-160): the layers that make up the block's output (the odd ones and the last) write straight
-        into their channel range of the output buffer; a layer with several links reads a gathered copy."""
-        B, H, W, _ = x.t.shape
-        n = len(layers)
-        keep = [i for i in range(1, n + 1) if i == n or i % 2 == 1]                 # indices into outs (0 = the block input)
-        offs, off = {}, 0
-        for i in keep:
-            offs[i] = off
-            off += layers[i - 1].cout
-        outbuf = gk.new(B, H, W, out_ch, x.t.device)
-        outs = [x]
-        for li, (u, lk) in enumerate(zip(layers, links), 1):
-            if len(lk) > 1:
-                cin = sum(outs[j].t.shape[-1] for j in lk)
-                buf = gk.new(B, H, W, cin, x.t.device)
-                pieces, o = [], 0
-                for j in lk:
-                    c = outs[j].t.shape[-1]
-                    pieces.append(run.copy_into(outs[j], buf[..., o:o + c]))
-                    o += c
-                inp = run.cat(buf, pieces)
-            else:
-                inp = outs[lk[0]]
-            dst = outbuf[..., offs[li]:offs[li] + u.cout] if li in offs else None
-            outs.append(run.conv_bn(inp, u, 6, out=dst))
-        return run.cat(outbuf, [outs[i] for i in keep])
-
     def _graph(self, run, x):
         feats, y = [], x
-        for kind, arg in self._seq:
+        for i, (kind, arg) in enumerate(self._seq):          # i = the module's index in the reference's `hardnet.base` list
             if kind in ("conv", "conv_tap"):
                 y = run.conv_bn(y, arg, 6)
-                if kind == "conv_tap":
-                    feats.append(y)
             elif kind == "pool3":
                 y = run.maxpool(y, 3, 2, 1)
             elif kind == "pool2":
                 y = run.maxpool(y, 2, 2, 0)
             else:
-                y = self._block(run, y, *arg)
+                y = _hard_block(run, y, *arg)
+            y = run.tap("base.%d" % i, y)
+            if kind == "conv_tap":
+                feats.append(y)
         return feats
 
 
-def _fam_units(name, c_left, c_down, c_right, c):
-    u = dict(conv0=_Unit(name + ".conv0", name + ".bn0", c_left, c, 3, 1, 1), conv1=_Unit(name + ".conv1", name + ".bn1", c_down, c, 3, 1, 1),
-             conv2=_Unit(name + ".conv2", name + ".bn2", c_right, c, 3, 1, 1), conv_d1=_Unit(name + ".conv_d1", None, c, c, 3, 1, 1),
-             conv_d2=_Unit(name + ".conv_d2", None, c, c, 3, 1, 1), conv_l=_Unit(name + ".conv_l", None, c, c, 3, 1, 1),
-             conv3=_Unit(name + ".conv3", name + ".bn3", 3 * c, c, 3, 1, 1))
+def _fam_units(prefix, c_left, c_down, c_right, c):
+    n = prefix
+    u = dict(conv0=_Unit(n + "conv0", n + "bn0", c_left, c, 3, 1, 1), conv1=_Unit(n + "conv1", n + "bn1", c_down, c, 3, 1, 1),
+             conv2=_Unit(n + "conv2", n + "bn2", c_right, c, 3, 1, 1), conv_d1=_Unit(n + "conv_d1", None, c, c, 3, 1, 1),
+             conv_d2=_Unit(n + "conv_d2", None, c, c, 3, 1, 1), conv_l=_Unit(n + "conv_l", None, c, c, 3, 1, 1),
+             conv3=_Unit(n + "conv3", n + "bn3", 3 * c, c, 3, 1, 1))
     for k in ("conv0", "conv1", "conv2", "conv3"):
         u[k].bias = True                                     # nn.Conv2d default: these convs carry a bias in front of their BatchNorm
     return u, [u[k] for k in ("conv0", "conv1", "conv2", "conv_d1", "conv_d2", "conv_l", "conv3")]
+
+
+def _fam_block(run, U, c, left, down, right):
+    """FAM.forward (gcpa_gald.py:83-107)."""
+    left = run.conv_bn(left, U["conv0"], True)
+    down = run.conv_bn(down, U["conv1"], True)
+    right = run.conv_bn(right, U["conv2"], True)
+    size = (left.t.shape[1], left.t.shape[2])
+    fit = lambda v: v if (v.t.shape[1], v.t.shape[2]) == size else run.resize(v, None, False, size=size)
+    B = left.t.shape[0]
+    cat = gk.new(B, size[0], size[1], 3 * c, left.t.device, left.t.dtype)
+    z1 = run.mulrelu(run.conv_bias(left, U["conv_l"], out_f32=False), fit(down), out=cat[..., :c])
+    z2 = run.mulrelu(fit(run.conv_bias(down, U["conv_d1"], out_f32=False)), left, out=cat[..., c:2 * c])
+    z3 = run.mulrelu(fit(run.conv_bias(right, U["conv_d2"], out_f32=False)), left, out=cat[..., 2 * c:])
+    return run.conv_bn(run.cat(cat, [z1, z2, z3]), U["conv3"], True)
+
+
+def _local_attention(run, x, units):
+    """LocalAttenModule.forward (GALDNet.py:143-157); dconv3 is never run."""
+    g = run.dw_bn_relu(run.dw_bn_relu(x, units[0]), units[1])
+    return run.gate(x, run.resize(g, None, True, size=(x.t.shape[1], x.t.shape[2])))
+
+
+def _lam_units(prefix, c):
+    units = [_Unit("%sdconv%d.0" % (prefix, j), "%sdconv%d.1" % (prefix, j), c, c, 3, 2, 0) for j in (1, 2, 3)]
+    for u in units:
+        u.bias, u.depthwise = True, True
+    return units
+
+
+def _cca_units(prefix, c):
+    """[gamma entry, query, key, value] in the reference's state_dict order (a module's own parameters precede its children's)."""
+    return [(prefix + "gamma", torch.zeros(1)), _Unit(prefix + "query_conv", None, c, c // 8, 1), _Unit(prefix + "key_conv", None, c, c // 8, 1),
+            _Unit(prefix + "value_conv", None, c, c, 1)]
 
 
 class GCPADecoder(_Engine):
@@ -287,58 +330,36 @@ class GCPADecoder(_Engine):
         self.num_classes, self._c = num_classes, c
         order, self._fam = [], {}
         for name, cl in (("fam45", 640), ("fam34", 320), ("fam23", 128)):
-            self._fam[name], flat = _fam_units(name, cl, c, c, c)
+            self._fam[name], flat = _fam_units(name + ".", cl, c, c, c)
             order += flat
         self._lin = {i: _Unit("linear%d" % i, None, c, num_classes, 3, 1, 1) for i in (5, 4, 3, 2)}
         order += [self._lin[i] for i in (5, 4, 3, 2)]
         self._conva = _Unit("conva.0", "conva.1", 1024, c, 3, 1, 1)
         order.append(self._conva)
-        self._cca = [_Unit("long_relation.query_conv", None, c, c // 8, 1), _Unit("long_relation.key_conv", None, c, c // 8, 1),
-                     _Unit("long_relation.value_conv", None, c, c, 1)]
-        order.append(("long_relation.gamma", torch.zeros(1)))          # (a module's own parameters precede its children's in the state_dict)
-        order += self._cca
+        cca = _cca_units("long_relation.", c)
+        self._cca = cca[1:]
+        order += cca
         self._lam = {}
         for i in (4, 3, 2):
-            name = "local_attention_%d" % i
-            self._lam[i] = [_Unit("%s.dconv%d.0" % (name, j), "%s.dconv%d.1" % (name, j), c, c, 3, 2, 0) for j in (1, 2, 3)]
-            for u in self._lam[i]:
-                u.bias, u.depthwise = True, True
+            self._lam[i] = _lam_units("local_attention_%d." % i, c)
             order += self._lam[i]
         self._register(order)
 
-    def _fam_block(self, run, U, left, down, right):
-        """FAM.forward (gcpa_gald.py:83-107)."""
-        c = self._c
-        left = run.conv_bn(left, U["conv0"], True)
-        down = run.conv_bn(down, U["conv1"], True)
-        right = run.conv_bn(right, U["conv2"], True)
-        size = (left.t.shape[1], left.t.shape[2])
-        fit = lambda v: v if (v.t.shape[1], v.t.shape[2]) == size else run.resize(v, None, False, size=size)
-        B = left.t.shape[0]
-        cat = gk.new(B, size[0], size[1], 3 * c, left.t.device)
-        z1 = run.mulrelu(run.conv_bias(left, U["conv_l"], out_f32=False), fit(down), out=cat[..., :c])
-        z2 = run.mulrelu(fit(run.conv_bias(down, U["conv_d1"], out_f32=False)), left, out=cat[..., c:2 * c])
-        z3 = run.mulrelu(fit(run.conv_bias(right, U["conv_d2"], out_f32=False)), left, out=cat[..., 2 * c:])
-        return run.conv_bn(run.cat(cat, [z1, z2, z3]), U["conv3"], True)
-
-    def _local_attention(self, run, x, units):
-        """LocalAttenModule.forward (GALDNet.py:143-157); dconv3 is never run."""
-        g = run.dw_bn_relu(run.dw_bn_relu(x, units[0]), units[1])
-        return run.gate(x, run.resize(g, None, True, size=(x.t.shape[1], x.t.shape[2])))
-
     def _graph(self, run, x, f2, f3, f4, f5):
-        top = run.conv_bn(f5, self._conva, True)
+        top = run.tap("conva", run.conv_bn(f5, self._conva, True))
         gamma = arch.node_at(self, "long_relation").gamma
-        ctx = run.criss_cross(run.criss_cross(top, *self._cca, gamma), *self._cca, gamma)        # the same module twice (gcpa_cc2.py:56-57)
-        o4 = self._fam_block(run, self._fam["fam45"], f4, top, self._local_attention(run, ctx, self._lam[4]))
-        o3 = self._fam_block(run, self._fam["fam34"], f3, o4, self._local_attention(run, ctx, self._lam[3]))
-        o2 = self._fam_block(run, self._fam["fam23"], f2, o3, self._local_attention(run, ctx, self._lam[2]))
-        lows = [run.conv_bias(top, self._lin[5]), run.conv_bias(o4, self._lin[4]), run.conv_bias(o3, self._lin[3]), run.conv_bias(o2, self._lin[2])]
+        ctx = run.tap("cca1", run.criss_cross(top, *self._cca, gamma))
+        ctx = run.tap("cca2", run.criss_cross(ctx, *self._cca, gamma))                          # the same module twice (gcpa_cc2.py:56-57)
+        c = self._c
+        o4 = run.tap("fam45", _fam_block(run, self._fam["fam45"], c, f4, top, run.tap("lam4", _local_attention(run, ctx, self._lam[4]))))
+        o3 = run.tap("fam34", _fam_block(run, self._fam["fam34"], c, f3, o4, run.tap("lam3", _local_attention(run, ctx, self._lam[3]))))
+        o2 = run.tap("fam23", _fam_block(run, self._fam["fam23"], c, f2, o3, run.tap("lam2", _local_attention(run, ctx, self._lam[2]))))
+        lows = [run.tap("linear%d" % i, run.conv_bias(v, self._lin[i])) for i, v in ((5, top), (4, o4), (3, o3), (2, o2))]
         labels = self.__dict__.get("_ce_labels")
         if labels is not None:                                                                 # the trainer's fused path: four scalar losses
             return [run.ce_head(v, labels, self._ce_ignore) for v in lows]
         size = (x.t.shape[1], x.t.shape[2])
-        return [run.resize(v, None, False, size=size) for v in lows]                           # F.interpolate(..., size=x.size()[2:], mode="bilinear")
+        return [run.tap("out%d" % i, run.resize(v, None, False, size=size)) for i, v in enumerate(lows)]      # F.interpolate(..., size=x.size()[2:], mode="bilinear")
 
     def forward(self, x, feats):
         return super().forward(x, *feats)
@@ -351,6 +372,74 @@ class GCPADecoder(_Engine):
             return super().forward(x, *feats)
         finally:
             self._ce_labels = None
+
+
+# ------------------------------------------------------------------------------------------------ the building blocks as stand-alone modules
+# Same constructor arguments and state_dict keys as the reference's classes, the SAME graph functions the two networks above are made of
+# (tests/test_gpu_gald.py runs them against the reference's own module fixtures, g13_gald_modules).
+class HarDBlock(_Engine):
+    """hardnet_68.py:86-160 (the plain variant HarDNet-68 uses: keepBase False, no depthwise layers)."""
+    RUN = _GaldRun
+
+    def __init__(self, in_channels, growth_rate, grmul, n_layers, keepBase=False, residual_out=False, dwconv=False):
+        super().__init__()
+        if keepBase or dwconv:
+            raise NotImplementedError("HarDNet-68 builds HarDBlock(keepBase=False, dwconv=False)")
+        self._arg = _hard_block_units("", in_channels, growth_rate, grmul, n_layers)
+        self.out_channels = self._arg[2]
+        self._register(self._arg[0])
+
+    def get_out_ch(self):
+        return self.out_channels
+
+    def _graph(self, run, x):
+        return [_hard_block(run, x, *self._arg)]
+
+
+class FAM(_Engine):
+    """gcpa_gald.py:47-107: forward(left, down, right)."""
+    RUN = _GaldRun
+
+    def __init__(self, in_channel_left, in_channel_down, in_channel_right, interplanes=256):
+        super().__init__()
+        self._U, flat = _fam_units("", in_channel_left, in_channel_down, in_channel_right, interplanes)
+        self._c = interplanes
+        self._register(flat)
+
+    def _graph(self, run, left, down, right):
+        return [_fam_block(run, self._U, self._c, left, down, right)]
+
+
+class CrissCrossAttention(_Engine):
+    """contextagg/ccnet.py:37-127.  `recurrence` (default 1, not a constructor argument of the reference) applies the module that many times inside
+    ONE graph with shared parameters - what GCPADecoder does with its `long_relation` (gcpa_cc2.py:56-57)."""
+    RUN = _GaldRun
+    recurrence = 1
+
+    def __init__(self, in_dim):
+        super().__init__()
+        order = _cca_units("", in_dim)
+        self._cca = order[1:]
+        self._register(order)
+
+    def _graph(self, run, x):
+        for _ in range(self.recurrence):
+            x = run.criss_cross(x, *self._cca, self.gamma)
+        return [x]
+
+
+class LocalAttenModule(_Engine):
+    """contextagg/GALDNet.py:124-157."""
+    RUN = _GaldRun
+
+    def __init__(self, inplane):
+        super().__init__()
+        self._units = _lam_units("", inplane)
+        self._lam = list(self._units)
+        self._register(self._lam)
+
+    def _graph(self, run, x):
+        return [_local_attention(run, x, self._lam)]
 
 
 class _NhwcCEFn(torch.autograd.Function):
@@ -473,3 +562,64 @@ class GALDTrainer(BaseTrainer):
             self._train_epoch(epoch)
         if self.local_rank == 0:
             dump_json(os.path.join(self.cfg.OUTPUT_DIR, "gald_chart_params.json"), {"learning rate": self.lr_data, "loss": self.loss_data})
+
+
+class GALDTester:
+    """core/testers/gald_tester.py:10-90, device-agnostic and runnable: encoder + decoder in eval(), res2 resized to the label size
+    (align_corners False), softmax, argmax, confusion matrix + intersection / union meters, summary, gald_confusion_matrix.json.  Upstream the loop
+    cannot run as written - `cmt` is used before assignment (:77) and `self.trainid2name` is never set (:87): here the matrix starts as zeros
+    [K, K] like aspp_tester.py:53 and `trainid2name` is an optional constructor argument (class indices as names when absent)."""
+
+    def __init__(self, cfg, device, test_loader, logger, palette, saveres=False, trainid2name=None):
+        self.cfg, self.logger, self.test_loader, self.device = cfg, logger, test_loader, device
+        self.palette, self.saveres, self.trainid2name = palette, saveres, trainid2name
+        self.encoder = GCPAEncoder()
+        self.decoder = GCPADecoder(cfg.MODEL.NUM_CLASSES) if cfg.MODEL.NUM_CLASSES != 19 else GCPADecoder()
+        self.encoder.to(device)
+        self.decoder.to(device)
+
+    def _load_checkpoint(self):
+        self.logger.info("Loading checkpoint from {}".format(self.cfg.resume))
+        checkpoint = torch.load(self.cfg.resume, map_location=self.device)
+        self.encoder.load_state_dict(checkpoint["encoder"])
+        self.decoder.load_state_dict(checkpoint["decoder"])
+
+    def save_distill(self, output, name):
+        """gald_tester.py:30-43: palette PNG of the argmax mask under PSEUDO_DIR/inference/<dataset>."""
+        from PIL import Image
+        folder = os.path.join(self.cfg.PSEUDO_DIR, "inference", self.cfg.DATASETS.TEST)
+        os.makedirs(folder, exist_ok=True)
+        mask = Image.fromarray(output.cpu().numpy().squeeze().argmax(0).astype("uint8"))
+        mask.putpalette(list(self.palette))
+        mask.save(os.path.join(folder, name[0] + ".png"))
+
+    def predict(self, x, hw):
+        """softmax(upsample(res2, label size)) [B,K,h,w] fp32 (gald_tester.py:59-69)."""
+        with torch.no_grad():
+            res2 = self.decoder(x, self.encoder(x))[3]
+            nhwc = res2.float().permute(0, 2, 3, 1).contiguous()
+            if tuple(nhwc.shape[1:3]) != tuple(hw):
+                nhwc = gk.gresize(nhwc, hw, False)
+            return torch.softmax(nhwc, dim=3).permute(0, 3, 1, 2)
+
+    def test(self):
+        num_classes = self.cfg.MODEL.NUM_CLASSES
+        self.encoder.eval()
+        self.decoder.eval()
+        self.meter = AverageMeter()
+        cmt = torch.zeros(num_classes, num_classes, dtype=torch.int64)
+        for x, y, name in self.test_loader:
+            x = x.to(self.device, non_blocking=True)
+            y = y.to(self.device, non_blocking=True).long()
+            output = self.predict(x, tuple(y.shape[-2:]))
+            pred = output.max(1)[1]
+            if self.saveres:
+                self.save_distill(output, name)
+            cmt = cmt + confusion_matrix(self.cfg, torch.flatten(pred), torch.flatten(y))
+            inter, union, target, res = intersectionAndUnionGPU(pred, y, num_classes, self.cfg.INPUT.IGNORE_LABEL)
+            self.meter.update(*[t.cpu().numpy() for t in (inter, union, target, res)])
+        self.meter.summary(self.logger, num_classes)
+        names = list(self.trainid2name.values()) if self.trainid2name else [str(i) for i in range(num_classes)]
+        os.makedirs(self.cfg.OUTPUT_DIR, exist_ok=True)
+        dump_json(os.path.join(self.cfg.OUTPUT_DIR, "gald_confusion_matrix.json"), {"cmt": cmt.tolist(), "classes": names})
+        return cmt

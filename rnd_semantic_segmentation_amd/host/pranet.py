@@ -186,10 +186,35 @@ class _Run:
         return _Var(t, needs and self.rec)
 
     def tap(self, name, v):
-        """Diagnostics (tools/dbg): keep a named intermediate when the module has a `_taps` dict."""
-        taps = getattr(self.net, "_taps", None)
-        if taps is not None:
+        """Named intermediates.  A module with a `_taps` dict keeps them (tools/dbg, tests).  Teacher forcing (tests): a module with a `_force` dict
+        has the named activations REPLACED in place - after the engine's own value went to `_taps` - by the given tensors, and one with a
+        `_force_grad` dict has d loss / d (that activation) replaced - after the engine's own accumulated gradient went to `_gtaps` - before the
+        producer's backward runs.  The tests feed every block the oracle's activation and upstream gradient and compare what the block makes of
+        them with the oracle's next activation / gradients: an error is attributed to the block that makes it instead of being amplified through
+        the rest of the net.  Forced tensors are NCHW (any float dtype, on the module's device)."""
+        net = self.net
+        taps, force = getattr(net, "_taps", None), getattr(net, "_force", None)
+        if force is not None and name in force:
+            if taps is not None:
+                taps[name] = _Var(v.t.clone(), False)
+            f = force[name]
+            v.t.copy_(f.permute(0, 2, 3, 1) if f.dim() == 4 else f)
+        elif taps is not None:
             taps[name] = v
+        gtaps, fgrad = getattr(net, "_gtaps", None), getattr(net, "_force_grad", None)
+        if self.rec and (gtaps is not None or fgrad is not None):
+            def back():                 # runs after every consumer's backward and before the producer's
+                if gtaps is not None and v.g is not None:
+                    gtaps[name] = v.g.clone()
+                if fgrad is not None and name in fgrad:
+                    f = fgrad[name]
+                    f = (f.permute(0, 2, 3, 1) if f.dim() == 4 else f).to(v.t.dtype)
+                    if v.want is not None:
+                        v.want.copy_(f)
+                        v.g, v.own = v.want, True
+                    else:
+                        v.g, v.own = f.contiguous(), True
+            self.record(back)
         return v
 
     # ---- conv (+ bias) + BatchNorm2d (+ add) (+ ReLU | ReLU6): BasicConv2d of PraNet_Res2Net.py:7-20, the conv/bn pairs of Res2Net_v1b.py,
@@ -519,8 +544,8 @@ class _Engine(nn.Module):
         for u in order:
             if isinstance(u, tuple):
                 key, value = u
-                parent, leaf = key.rsplit(".", 1)
-                setattr(arch.node_at(self, parent), leaf, nn.Parameter(value))
+                parent, leaf = key.rsplit(".", 1) if "." in key else ("", key)
+                setattr(arch.node_at(self, parent) if parent else self, leaf, nn.Parameter(value))
                 continue
             node = arch.node_at(self, u.key)
             kh, kw = u.geom[0], u.geom[1]
@@ -784,9 +809,8 @@ class PraNet(_Engine):
         if x.t.shape[1] % 32 or x.t.shape[2] % 32:
             raise _lib.MiError("PraNet input sides must be multiples of 32 (the reverse-attention branches resize by exact factors), got %s" % (tuple(x.t.shape),))
         s = self._stem
-        y = run.conv_bn(x, s[0], True)
-        y = run.conv_bn(y, s[1], True)
-        run.tap("stem1", y)
+        y = run.tap("stem0", run.conv_bn(x, s[0], True))
+        y = run.tap("stem1", run.conv_bn(y, s[1], True))
         y = run.tap("stem", run.stem_tail(y, s[2]))
         ends = {}
         for blk in self._blocks:
@@ -800,13 +824,13 @@ class PraNet(_Engine):
         coarse = run.tap("coarse", _aggregation(run, self._agg, self.channel, x4r, x3r, x2r))           # ra5_feat: 1/8 resolution, one channel, fp32
         rs = lambda v, f: run.resize(v, f, False)                                    # F.interpolate(..., mode='bilinear'): align_corners False
         maps = [rs(coarse, 8)]
-        g = _reverse_branch(run, rs(coarse, 0.25), x4, self._ra[4])
+        g = run.tap("ra4", _reverse_branch(run, rs(coarse, 0.25), x4, self._ra[4]))
         maps.append(rs(g, 32))
-        g = _reverse_branch(run, rs(g, 2), x3, self._ra[3])
+        g = run.tap("ra3", _reverse_branch(run, rs(g, 2), x3, self._ra[3]))
         maps.append(rs(g, 16))
-        g = _reverse_branch(run, rs(g, 2), x2, self._ra[2])
+        g = run.tap("ra2", _reverse_branch(run, rs(g, 2), x2, self._ra[2]))
         maps.append(rs(g, 8))
-        return maps
+        return [run.tap("map%d" % i, m) for i, m in enumerate(maps)]
 
 
 # ------------------------------------------------------------------------------------------------ optimizer / schedule / trainer / tester

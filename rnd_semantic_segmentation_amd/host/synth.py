@@ -79,6 +79,11 @@ def formula_tensor(key, shape):
     leaf = key.rsplit(".", 1)[-1]
     parent = key.rsplit(".", 1)[0]
     is_bn = parent.rsplit(".", 1)[-1].startswith("bn") or ".downsample.1" in key
+    # BatchNorm tensors are 1-D; any 1-D `weight` / running statistic is one whatever its module is called (`norm` in HarDNet's ConvLayer, an index
+    # inside a Sequential: resnet.conv1.1, downsample.2 of Res2Net, conva.1, dconvN.1).  The name rules alone had taken Res2Net's 4-D
+    # `downsample.1` CONV weight for a BatchNorm gain (every weight ~0.5: all output channels of the shortcut nearly equal - a rank-one trunk that
+    # amplified rounding tenfold) and left those BatchNorms with gains of +-0.05 and running variances of either sign (eval(): NaN).
+    is_bn = (is_bn or leaf in ("running_mean", "running_var") or leaf == "weight") and len(shape) == 1
     if is_bn:
         stem = ".layer" not in "." + key and parent.endswith("bn1")
         if leaf == "weight":
@@ -98,15 +103,27 @@ def formula_tensor(key, shape):
     return (0.1 * u).astype(np.float32)
 
 
-def load_formula_weights(module, prefix=""):
-    """Fill every parameter and buffer of `module` with formula_tensor(prefix+key)."""
+COND_BN_BIAS = 2.0
+
+
+def load_formula_weights(module, prefix="", bn_bias=0.0):
+    """Fill every parameter and buffer of `module` with formula_tensor(prefix+key).
+
+    bn_bias: added to the bias of every BatchNorm (a `.bias` whose sibling `.running_mean` exists).  COND_BN_BIAS is the CONDITIONED regime of the
+    whole-network parity fixtures of the BatchNorm-on-batch-statistics nets (PraNet, GALD): with zero-mean pre-activations half of every layer's
+    units sit at the ReLU kink, a deep batch-normalised random net is chaotic (rounding doubles per 16-layer HarDBlock: the reference's own
+    bf16-autocast run ends 40 % away from its fp32 run, gradient directions 1 - cos = 0.75) and no implementation can be compared with another
+    through 70 layers; with the pre-activations centred two standard deviations above the kink (2.3 % of the units inactive) the same nets are
+    well-conditioned (autocast: outputs 1-5 %, 1 - cos 1e-3 .. 1e-2) and every conv / link / resize / attention is exercised all the same."""
     import torch
 
     sd = module.state_dict()
     new = {}
     for k, v in sd.items():
-        t = torch.from_numpy(formula_tensor(prefix + k, v.shape))
-        new[k] = t.to(v.dtype)
+        a = formula_tensor(prefix + k, v.shape)
+        if bn_bias and k.endswith(".bias") and k[:-5] + ".running_mean" in sd:
+            a = (a + np.float32(bn_bias)).astype(np.float32)
+        new[k] = torch.from_numpy(a).to(v.dtype)
     module.load_state_dict(new)
     return module
 

@@ -23,8 +23,11 @@ def test(cfg, config, args):
     if name.startswith("pranet"):                            # reference test.py:35-36
         from core.testers.pranet_tester import PranetTester
         tester = PranetTester(cfg, device, loader, logger)
+    elif name.startswith("gald"):                            # reference test.py:39-40
+        from core.testers.gald_tester import GALDTester
+        tester = GALDTester(cfg, device, loader, logger, config["palette"], saveres=args.saveres, trainid2name=config.get("trainid2name"))
     elif not name.startswith("aspp"):
-        raise NotImplementedError("tester %r: 'aspp*' and 'pranet*' are on the MI355X engine" % name)
+        raise NotImplementedError("tester %r: 'aspp*', 'pranet*' and 'gald*' are on the MI355X engine" % name)
     else:
         tester = ASPPTester(cfg, device, loader, logger, config["palette"], config["trainid2name"], saveres=args.saveres)
     if cfg.resume:

@@ -52,3 +52,22 @@ def upsample_case():
 def net_inputs(batch, size, seed):
     h, w = size if isinstance(size, tuple) else (size, size)
     return synth.synth_image(batch, h, w, seed=seed), synth.synth_label(batch, h, w, 19, seed=seed)
+
+
+def pranet160_inputs():
+    """(x [8,3,160,160], gt [8,1,160,160], fixture) of g12_pranet_160: regenerated from the formulas make_golden.py used."""
+    import torch
+    import torch.nn.functional as F
+    g = load("g12_pranet_160")
+    B, S = 8, 160
+    x = synth.synth_image(B, S, S, seed=int(g["x_seed"]))
+    blob = synth.uniform("pn.gt", (B, 1, S // 8, S // 8))
+    gt = F.avg_pool2d(torch.from_numpy(np.kron((blob > 0.1).astype(np.float32), np.ones((8, 8), np.float32))), 5, 1, 2).numpy()
+    assert sha(gt) == str(g["gt_sha"]), "input formulas drifted from the fixture"
+    return x, gt, g
+
+
+def gald352_inputs():
+    """(x [4,3,352,352], labels [4,352,352] float, fixture) of g13_gald_352."""
+    g = load("g13_gald_352")
+    return synth.synth_image(4, 352, 352, seed=int(g["x_seed"])), synth.synth_label(4, 352, 352, 19, seed=int(g["x_seed"])), g

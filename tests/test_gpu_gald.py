@@ -80,156 +80,144 @@ def test_depthwise_conv_forward_statistics_and_gradients(gk, C, H, W, stride, pa
     assert torch.equal(dw, dw2) and torch.equal(db, db2)                     # fixed-order reduction
 
 
-def _conv1x1(gk, x, w, b):
-    wp, wpt = gk.gconv_pack(w)
-    y, _ = gk.gconv(x, wp, w.shape[0], (1, 1, 1, 1, 0, 0, 1, 1), bias=b)
-    return y, wpt
-
-
-def test_criss_cross_attention_composed_from_kernels_vs_reference_golden(gk):
-    """CrissCrossAttention(64) on 2 x 64 x 5 x 7 (g13 `cca`): q / k / v projections by the general conv (with bias), the attention core by
-    mi_gcca_fwd / mi_gcca_bwd, gamma * agg + x by mi_gbn_apply; backward by hand in the order autograd takes."""
+# ------------------------------------------------------------------------------------------------ the product's own building blocks
+# host/gald.py's HarDBlock / FAM / CrissCrossAttention / LocalAttenModule are the graph functions GCPAEncoder / GCPADecoder are made of
+# (_hard_block, _fam_block, _GaldRun.criss_cross, _local_attention) behind the reference's constructor signatures; each runs here on the inputs
+# of the reference's own module fixture (g13_gald_modules: hdb_*, fam_*, cca_*, lam_*) and is compared with the reference's fp32 run: train-mode
+# output, every input gradient, every parameter gradient's norm AND direction (the directions against the oracle's tensors, whose norms are
+# pinned to the fixture in the same test).  bf16 engine vs fp32 reference, one block deep: bars = 3x the value measured on the MI355X.
+def _gald_cases():
     from oracle import ref_gald as rg
+    from rnd_semantic_segmentation_amd.host import gald
+    two = lambda m: (setattr(m, "recurrence", 2), m)[1]
+
+    class Twice(torch.nn.Module):          # the oracle's module applied twice with shared parameters, as gcpa_cc2.py:56-57 does
+        def __init__(self):
+            super().__init__()
+            self.m = rg.CrissCross(64)
+
+        def forward(self, x):
+            return self.m(self.m(x))
+
+        def state_dict(self, *a, **k):
+            return self.m.state_dict(*a, **k)
+
+        def load_state_dict(self, sd, *a, **k):
+            return self.m.load_state_dict(sd, *a, **k)
+
+        def named_parameters(self, *a, **k):
+            return self.m.named_parameters(*a, **k)
+    return [
+        ("hdb", "hdb", lambda: gald.HarDBlock(64, 14, 1.7, 8), lambda: rg.HarDBlock(64, 14, 1.7, 8), [np.maximum(_u("hdb.x", (2, 64, 12, 12), 3), 0)]),
+        ("fam", "fam", lambda: gald.FAM(24, 32, 32, 32), lambda: rg.FAM(24, 32, 32, 32),
+         [_u("fam.left", (2, 24, 12, 12), 2), _u("fam.down", (2, 32, 6, 6), 2), _u("fam.right", (2, 32, 6, 6), 2)]),
+        ("cca", "cca", lambda: gald.CrissCrossAttention(64), lambda: rg.CrissCross(64), [_u("cca.x", (2, 64, 5, 7), 3)]),
+        ("lam", "lam", lambda: gald.LocalAttenModule(32), lambda: rg.LocalAtten(32), [_u("lam.x", (2, 32, 19, 17), 3)]),
+        # no reference fixture (the oracle's single application is pinned by `cca`): the same module twice in ONE graph, gradients of the two
+        # applications accumulating in the same slots - what GCPADecoder does with long_relation
+        ("cca_twice", "cca", lambda: two(gald.CrissCrossAttention(64)), Twice, [_u("cca.x", (2, 64, 5, 7), 3)]),
+        # the decoder's real widths: 64-multiples on >= 16 384 pixels take the MFMA-tile kernels (mi_conv_gemm / mi_conv_wgrad, BatchNorm sums from
+        # their epilogue), the resized 48 x 48 branches the general kernel
+        ("fam_wide", "famw", lambda: gald.FAM(128, 256, 256, 256), lambda: rg.FAM(128, 256, 256, 256),
+         [np.maximum(_u("famw.left", (2, 128, 96, 96), 3), 0), np.maximum(_u("famw.down", (2, 256, 48, 48), 3), 0), np.maximum(_u("famw.right", (2, 256, 48, 48), 3), 0)]),
+        # HarDNet-68's third block: 16 layers, growth 20 (widths 20 .. 160, inputs up to 466 channels: 4-byte aligned slices everywhere)
+        ("hdb_16", "hdb16", lambda: gald.HarDBlock(256, 20, 1.7, 16), lambda: rg.HarDBlock(256, 20, 1.7, 16), [np.maximum(_u("hdb16.x", (2, 256, 22, 22), 3), 0)]),
+    ]
+
+
+# measured on the MI355X (round 4; the printed line of each case): out / dx / |grad| / 1 - cos
+_GALD_BARS = {"hdb": (3e-2, 6e-2, 6e-2, 2e-2), "fam": (3e-2, 6e-2, 6e-2, 2e-2), "cca": (1.5e-2, 3e-2, 6e-2, 6e-3), "lam": (1.5e-2, 6e-2, 0.1, 2e-2),
+              "cca_twice": (3e-2, 6e-2, 0.1, 2e-2), "fam_wide": (3e-2, 6e-2, 6e-2, 2e-2), "hdb_16": (6e-2, 0.12, 0.1, 5e-2)}
+
+
+@pytest.mark.parametrize("idx", range(7))
+def test_gald_product_modules_vs_reference_golden(idx):
+    import _parity as P
+    tag, prefix, make, make_ref, inputs = _gald_cases()[idx]
+    mod, refm = make(), make_ref()
+    shift = synth.COND_BN_BIAS if tag in ("fam_wide", "hdb_16") else 0.0          # (the reference's fixtures were written in the zero-mean regime)
+    synth.load_formula_weights(mod, prefix=prefix + ".", bn_bias=shift)
+    synth.load_formula_weights(refm, prefix=prefix + ".", bn_bias=shift)
+    assert list(mod.state_dict().keys()) == list(refm.state_dict().keys())
+    if tag == "cca_twice":             # (the formula's gamma is 0.1 u: make the attention term count)
+        with torch.no_grad():
+            mod.gamma.fill_(0.7)
+            dict(refm.named_parameters())["gamma"].fill_(0.7)
+    mod.cuda().train()
+    refm.train()
+    loss_of = lambda outs: sum(o.square().mean() + o.mean() for o in outs)
+    # oracle (fp32) and, for the printed yardstick only, the oracle under CPU autocast
+    xs = [torch.from_numpy(a).requires_grad_(True) for a in inputs]
+    y = refm(*xs)
+    loss_of([y]).backward()
+    want_pg = {k: p.grad.numpy().copy() for k, p in refm.named_parameters() if p.grad is not None}
     g = _cases.load("g13_gald_modules")
-    x0 = _u("cca.x", (2, 64, 5, 7), 3)
-    ref = rg.CrissCross(64)
-    synth.load_formula_weights(ref, prefix="cca.")
-    P = {k: v.detach().cuda() for k, v in ref.named_parameters()}
-    x = _nhwc(_bf(torch.from_numpy(x0))).cuda()
-    B, H, W, C = x.shape
-    q, wq_t = _conv1x1(gk, x, P["query_conv.weight"], P["query_conv.bias"])
-    k, wk_t = _conv1x1(gk, x, P["key_conv.weight"], P["key_conv.bias"])
-    v, wv_t = _conv1x1(gk, x, P["value_conv.weight"], P["value_conv.bias"])
-    agg, att = gk.gcca_fwd(q, k, v)
-    gamma = P["gamma"].expand(C).contiguous()
-    out = gk.gbn_apply(agg, gamma, torch.zeros(C, device="cuda"), False, add=x)
+    if tag in ("hdb", "fam", "cca", "lam"):      # the oracle's fp32 run IS the reference's
+        assert P.rel(y.detach().numpy(), g[tag + "_out"]) < 2e-5
+        for i, x in enumerate(xs):
+            assert P.rel(x.grad.numpy(), g["%s_dx%d" % (tag, i)]) < 2e-4
+        names = [str(n) for n in g[tag + "_pnames"]]
+        assert np.allclose([np.linalg.norm(want_pg[k].astype(np.float64)) for k in names], g[tag + "_pgrad"], rtol=2e-3, atol=1e-7)
+    # engine
+    ex = [torch.from_numpy(a).cuda().requires_grad_(True) for a in inputs]
+    ey = mod(*ex)
+    loss_of([ey.float()]).backward()
     torch.cuda.synchronize()
-    assert abs(float(att.sum()) - B * H * W) < 1e-3 and float(att[:, torch.arange(H), :, torch.arange(H)].abs().max()) == 0.0      # rows sum to 1; own column position masked
-    e_out = rel(out.permute(0, 3, 1, 2).float().cpu().numpy(), g["cca_out"])
-    # the loss of the fixture: mean(y^2) + mean(y)
-    n = out.numel()
-    dout = _bf((2.0 * out.float() + 1.0) / n)
-    dagg = gk.gbn_apply(dout, gamma, torch.zeros(C, device="cuda"), False)
-    dgam_c = torch.empty(C, device="cuda")
-    gk.gbn_bwd_sums(dout, agg, None, torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), torch.empty(C, device="cuda"), dgam_c)
-    dq, dk, dv = gk.gcca_bwd(q, k, v, att, dagg)
-    grads, dx = {"gamma": dgam_c.sum().reshape(1)}, dout.float()
-    geom = (1, 1, 1, 1, 0, 0, 1, 1)
-    for name, d, wt in (("query_conv", dq, wq_t), ("key_conv", dk, wk_t), ("value_conv", dv, wv_t)):
-        dw = torch.empty_like(P[name + ".weight"])
-        gk.gconv_wgrad(d, x, dw, geom)
-        db = torch.empty_like(P[name + ".bias"])
-        gk.gbn_bwd_sums(d, None, None, None, None, db, None)
-        grads[name + ".weight"], grads[name + ".bias"] = dw, db
-        dxi, _ = gk.gconv(d, wt, C, geom, mode=gk.GATHER_DGRAD, out_hw=(H, W))
-        dx = dx + dxi.float()
-    torch.cuda.synchronize()
-    e_dx = rel2(dx.permute(0, 3, 1, 2).cpu().numpy(), g["cca_dx0"])
-    # oracle tensors for the directions
-    ref.train()
-    rx = torch.from_numpy(x0).requires_grad_(True)
-    ry = ref(rx)
-    (ry.square().mean() + ry.mean()).backward()
-    # (key_conv.bias shifts every affinity of a query by the same q . b: the softmax does not see it and its exact gradient is zero - the
-    # reference holds 1e-10 of rounding there; tensors below 1e-3 of the largest gradient are left out of the relative comparisons)
-    rgd = {k: p.grad for k, p in ref.named_parameters()}
-    gmax = max(float(v.norm()) for v in rgd.values())
-    live = [k for k, v in rgd.items() if float(v.norm()) > 1e-3 * gmax]
-    assert "key_conv.bias" not in live and float(grads["key_conv.bias"].norm()) < 1e-2 * gmax
-    worst = max(1 - _cos(grads[k].cpu().numpy(), rgd[k].numpy()) for k in live)
-    names = [str(s) for s in g["cca_pnames"]]
-    assert np.allclose([float(rgd[k].double().norm()) for k in names], g["cca_pgrad"], rtol=2e-3, atol=1e-7)       # the oracle's gradients are the reference's
-    e_norm = max(abs(float(grads[k].double().norm()) / float(rgd[k].double().norm()) - 1) for k in live)
-    print("\n[cca] out %.2e  dx %.2e  |grad| %.2e  1-cos %.2e" % (e_out, e_dx, e_norm, worst))
-    assert e_out < 1.5e-2 and e_dx < 3e-2 and e_norm < 6e-2 and worst < 6e-3      # bars 3x measured (see the printed line)
-
-
-def test_local_attention_module_composed_from_kernels_vs_reference_golden(gk):
-    """LocalAttenModule(32) on 2 x 32 x 19 x 17 (g13 `lam`): two depthwise stride-2 convs (bias) each with BatchNorm on batch statistics (tile
-    statistics from the conv, mi_gbn_finalize / mi_gbn_apply) and ReLU, bilinear align_corners=True back to 19 x 17, sigmoid gate."""
-    from oracle import ref_gald as rg
-    g = _cases.load("g13_gald_modules")
-    x0 = _u("lam.x", (2, 32, 19, 17), 3)
-    ref = rg.LocalAtten(32)
-    synth.load_formula_weights(ref, prefix="lam.")
-    P = {k: v.detach().cuda() for k, v in ref.state_dict().items()}
-    x = _nhwc(_bf(torch.from_numpy(x0))).cuda()
-    B, H, W, C = x.shape
-
-    def unit(inp, i):
-        y, st = gk.gdwconv(inp, P["dconv%d.0.weight" % i], P["dconv%d.0.bias" % i], 2, 0, stats=True)
-        M = y.shape[0] * y.shape[1] * y.shape[2]
-        fin = gk.gbn_finalize(st, C, M, P["dconv%d.1.weight" % i], P["dconv%d.1.bias" % i], P["dconv%d.1.running_mean" % i].clone(), P["dconv%d.1.running_var" % i].clone(), 0.1, 1e-5)
-        return y, fin, gk.gbn_apply(y, fin[2], fin[3], True), M
-    y1, f1, a1, M1 = unit(x, 1)
-    y2, f2, a2, M2 = unit(a1, 2)
-    up = gk.gresize(a2, (H, W), True)
-    out = gk.ggate(x, up)
-    torch.cuda.synchronize()
-    e_out = rel(out.permute(0, 3, 1, 2).float().cpu().numpy(), g["lam_out"])
-    dout = _bf((2.0 * out.float() + 1.0) / out.numel())
-    dx_gate, dup = gk.ggate_bwd(x, up, dout)
-    da2 = gk.gresize_bwd(dup, (a2.shape[1], a2.shape[2]), True)
-    grads = {}
-
-    def unit_back(gout, y, fin, act, inp, i, M, need_dx):
-        db, dg = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
-        gk.gbn_bwd_sums(gout, y, act, fin[0], fin[1], db, dg)
-        dy = gk.gbn_bwd_apply(gout, y, act, fin[0], fin[1], P["dconv%d.1.weight" % i], db, dg, M)
-        dw, dbias = torch.empty_like(P["dconv%d.0.weight" % i]), torch.empty(C, device="cuda")
-        dxi = gk.gdwconv_backward(dy, inp, P["dconv%d.0.weight" % i], dw, dbias, 2, 0, need_dx=need_dx)
-        grads.update({"dconv%d.1.bias" % i: db, "dconv%d.1.weight" % i: dg, "dconv%d.0.weight" % i: dw, "dconv%d.0.bias" % i: dbias})
-        return dxi
-    da1 = unit_back(da2, y2, f2, a2, a1, 2, M2, True)
-    dx1 = unit_back(da1, y1, f1, a1, x, 1, M1, True)
-    dx = dx_gate.float() + dx1.float()
-    torch.cuda.synchronize()
-    e_dx = rel2(dx.permute(0, 3, 1, 2).cpu().numpy(), g["lam_dx0"])
-    ref.train()
-    rx = torch.from_numpy(x0).requires_grad_(True)
-    ry = ref(rx)
-    (ry.square().mean() + ry.mean()).backward()
-    rg_ = {k: p.grad for k, p in ref.named_parameters() if p.grad is not None}
-    gmax = max(float(v.norm()) for v in rg_.values())
-    live = [k for k, v in rg_.items() if float(v.norm()) > 1e-3 * gmax]          # (a conv bias in front of BatchNorm has a zero gradient)
-    worst = max(1 - _cos(grads[k].cpu().numpy(), rg_[k].numpy()) for k in live)
-    e_norm = max(abs(float(grads[k].double().norm()) / float(rg_[k].double().norm()) - 1) for k in live)
-    print("\n[lam] out %.2e  dx %.2e  |grad| %.2e  1-cos %.2e" % (e_out, e_dx, e_norm, worst))
-    assert e_out < 1.5e-2 and e_dx < 6e-2 and e_norm < 0.1 and worst < 2e-2
+    got_pg = {k: p.grad.detach().cpu().numpy().copy() for k, p in mod.named_parameters() if p.grad is not None}
+    live = P.live(want_pg)
+    assert all(k in got_pg for k in live), [k for k in live if k not in got_pg]
+    e_out = P.rel(ey.detach().float().cpu().numpy(), y.detach().numpy())
+    e_dx = max(P.rel2(a.grad.cpu().numpy(), b.grad.numpy()) for a, b in zip(ex, xs))
+    e_norm = max(abs(float(np.linalg.norm(got_pg[k]) / np.linalg.norm(want_pg[k])) - 1) for k in live)
+    e_cos = max(1 - P.cos(got_pg[k], want_pg[k]) for k in live)
+    print("\n[gald %s] out %.2e  dx %.2e  |grad| %.2e  1-cos %.2e  (%d live parameter tensors)" % (tag, e_out, e_dx, e_norm, e_cos, len(live)))
+    b = _GALD_BARS[tag]
+    assert e_out < b[0] and e_dx < b[1] and e_norm < b[2] and e_cos < b[3], (tag, e_out, e_dx, e_norm, e_cos)
 
 
 # ------------------------------------------------------------------------------------------------ the whole network on the HIP engine
-def _deviation(got, want):
-    o, pg = got
-    o0, pg0 = want
-    gmax = max(np.linalg.norm(v) for v in pg0.values())
-    big = [k for k, v in pg0.items() if np.linalg.norm(v) > 1e-3 * gmax]
-    return dict(out=max(rel2(a, b) for a, b in zip(o, o0)), norm=max(abs(np.linalg.norm(pg[k]) / np.linalg.norm(pg0[k]) - 1) for k in big),
-                cos=max(1 - _cos(pg[k], pg0[k]) for k in big), cos_median=float(np.median([1 - _cos(pg[k], pg0[k]) for k in big])))
+def _gald_pair():
+    from oracle import ref_gald as rg
+    from rnd_semantic_segmentation_amd.host import gald
+    enc, dec = gald.GCPAEncoder(), gald.GCPADecoder()
+    renc, rdec = rg.GCPAEncoder(), rg.GCPADecoder()
+    for m, r, pre in ((enc, renc, "gald.enc."), (dec, rdec, "gald.dec.")):
+        synth.load_formula_weights(m, prefix=pre, bn_bias=synth.COND_BN_BIAS)          # the conditioned regime of the whole-net fixtures (host/synth.py)
+        synth.load_formula_weights(r, prefix=pre, bn_bias=synth.COND_BN_BIAS)
+        m.cuda().train()
+        r.train()
+    return enc, dec, renc, rdec
 
 
-def test_gald_whole_net_224_vs_reference_golden(golden_dir):
-    """GCPAEncoder (HarDNet-68) + GCPADecoder on the HIP engine at 2 x 3 x 224 x 224 against the reference's own run (g13_gald_224): state_dict
-    keys, feature shapes, the four class-logit outputs, the four cross-entropies and their weighted sum (gald_trainer.py:66-84), every
-    parameter gradient (norm and direction against the oracle's tensors) - with the reference's own bf16-autocast run as the yardstick for
-    the bf16 regime (tests/test_gpu_pranet.py explains why): the engine may deviate from the fp32 reference at most 2x as far as that run does."""
+def test_gald_whole_net_352_vs_reference_golden(golden_dir):
+    """GCPAEncoder (HarDNet-68) + GCPADecoder on the HIP engine at 4 x 3 x 352 x 352 against the reference's own run (g13_gald_352, conditioned
+    regime): state_dict keys, feature shapes, the four class-logit outputs, the four cross-entropies and their weighted sum (gald_trainer.py:66-84),
+    every parameter gradient (norm and direction against the oracle's tensors, which the same test pins to the fixture).  Free-running bf16 engine
+    vs fp32 reference through ~80 convolutions: bounded by 2x what the reference's own modules deviate under torch.autocast(bfloat16), and by
+    CEILINGS whatever that yardstick says (outputs 0.1, 1 - cos 0.05)."""
     import json
     import os
+    import _parity as P
     from oracle import ref_gald as rg
     from rnd_semantic_segmentation_amd.host import gald
     keys = json.load(open(os.path.join(golden_dir, "g8_gald_keys.json")))
-    enc, dec = gald.GCPAEncoder(), gald.GCPADecoder()
-    renc, rdec = rg.GCPAEncoder(), rg.GCPADecoder()
+    enc, dec, renc, rdec = _gald_pair()
     assert list(enc.state_dict().keys()) == keys["encoder"] and list(dec.state_dict().keys()) == keys["decoder"]
-    for m, r, pre in ((enc, renc, "gald.enc."), (dec, rdec, "gald.dec.")):
-        synth.load_formula_weights(m, prefix=pre)
-        synth.load_formula_weights(r, prefix=pre)
-        m.cuda().train()
-        r.train()
-    g = _cases.load("g13_gald_224")
-    x = torch.from_numpy(synth.synth_image(2, 224, 224, seed=51))
-    lab = torch.from_numpy(synth.synth_label(2, 224, 224, 19, seed=51)).long()
-    # engine
+    x, lab, g = _cases.gald352_inputs()
+    x, lab = torch.from_numpy(x), torch.from_numpy(lab).long()
+    losses = {}
+
+    def loss_of(tag):
+        def f(outs):
+            ls, loss = rg.gald_losses(outs, lab)
+            losses[tag] = [float(l) for l in ls]
+            return loss
+        return f
+    want = P.oracle_run([renc, rdec], lambda: rdec(x, renc(x)), loss_of("fp32"))
+    auto = P.oracle_run([renc, rdec], lambda: rdec(x, renc(x)), loss_of("autocast"), autocast=True)
+    assert np.allclose(losses["fp32"], g["losses"], rtol=2e-5)                          # the oracle's fp32 run IS the reference's
+    for i in range(4):
+        assert P.rel(want[0][i][:, :, ::16, ::16], g["out%d_crop" % i]) < 1e-4
     crit = gald.CrossEntropyNHWC(255)
     feats = enc(x.cuda())
     assert [list(f.shape) for f in feats] == g["feat_shapes"].tolist()
@@ -237,42 +225,88 @@ def test_gald_whole_net_224_vs_reference_golden(golden_dir):
     ls = [crit(o, lab.cuda()) for o in outs]
     (ls[3] * 1 + ls[2] * 0.8 + ls[1] * 0.6 + ls[0] * 0.4).backward()
     torch.cuda.synchronize()
-    ours = ([o.detach().float().cpu().numpy() for o in outs],
-            {pre + k: p.grad.detach().cpu().numpy().copy() for pre, m in (("e.", enc), ("d.", dec)) for k, p in m.named_parameters() if p.grad is not None})
-    e_loss = float(np.abs(np.array([float(l) for l in ls]) / g["losses"] - 1).max())
+    got_o = [o.detach().float().cpu().numpy() for o in outs]
+    got_pg = {"%d.%s" % (i, k): p.grad.detach().cpu().numpy().copy() for i, m in enumerate((enc, dec)) for k, p in m.named_parameters() if p.grad is not None}
 
-    def oracle(autocast):
-        for m in (renc, rdec):
-            m.zero_grad()
-        sd = [{k: v.clone() for k, v in m.state_dict().items()} for m in (renc, rdec)]
-        if autocast:
-            with torch.autocast("cpu", dtype=torch.bfloat16):
-                o = rdec(x, renc(x))
-        else:
-            o = rdec(x, renc(x))
-        o = [t.float() for t in o]
-        losses, loss = rg.gald_losses(o, lab)
-        loss.backward()
-        res = ([t.detach().numpy() for t in o], {pre + k: p.grad.numpy().copy() for pre, m in (("e.", renc), ("d.", rdec)) for k, p in m.named_parameters() if p.grad is not None})
-        for m, s in zip((renc, rdec), sd):
-            m.load_state_dict(s)
-        return res, [float(l) for l in losses]
-    want, l32 = oracle(False)
-    auto, l16 = oracle(True)
-    assert np.allclose(l32, g["losses"], rtol=2e-5)                                      # the oracle's fp32 run IS the reference's
-    for i in range(4):
-        assert rel(want[0][i][:, :, ::16, ::16], g["out%d_crop" % i]) < 1e-4
-    y_loss = float(np.abs(np.array(l16) / g["losses"] - 1).max())
-    unused = [k for k in want[1] if k not in ours[1]]
-    assert not unused, unused[:5]
-    dev, yard = _deviation(ours, want), _deviation(auto, want)
-    print("\n[gald 224] losses: engine %.2e, autocast %.2e\n[gald 224] engine   out %.2e |grad| %.2e 1-cos %.2e (median %.2e)\n[gald 224] autocast out %.2e |grad| %.2e 1-cos %.2e (median %.2e)" % (
+    def deviation(o, pg):
+        names = P.live(want[1])
+        assert all(k in pg for k in names), [k for k in names if k not in pg][:5]
+        cs = [1 - P.cos(pg[k], want[1][k]) for k in names]
+        return dict(out=max(P.rel2(a, b) for a, b in zip(o, want[0])), norm=max(abs(float(np.linalg.norm(pg[k]) / np.linalg.norm(want[1][k])) - 1) for k in names),
+                    cos=max(cs), cos_median=float(np.median(cs)))
+    dev, yard = deviation(got_o, got_pg), deviation(auto[0], auto[1])
+    e_loss = float(np.abs(np.array([float(l) for l in ls]) / g["losses"] - 1).max())
+    y_loss = float(np.abs(np.array(losses["autocast"]) / g["losses"] - 1).max())
+    print("\n[gald 352] losses: engine %.2e, autocast %.2e\n[gald 352] engine   out %.2e |grad| %.2e 1-cos %.2e (median %.2e)\n[gald 352] autocast out %.2e |grad| %.2e 1-cos %.2e (median %.2e)" % (
         e_loss, y_loss, dev["out"], dev["norm"], dev["cos"], dev["cos_median"], yard["out"], yard["norm"], yard["cos"], yard["cos_median"]))
-    assert e_loss <= max(2 * y_loss, 2e-2)
-    for k, floor in (("out", 2e-2), ("norm", 3e-2), ("cos", 2e-3), ("cos_median", 1e-3)):
-        assert dev[k] <= max(2 * yard[k], floor), (k, dev[k], yard[k])
+    assert e_loss <= max(2 * y_loss, 2e-3)
+    for k, floor, ceiling in (("out", 1e-2, 0.1), ("norm", 2e-2, 0.1), ("cos", 2e-3, 0.2), ("cos_median", 1e-3, 0.05)):
+        assert dev[k] <= min(max(2 * yard[k], floor), ceiling), (k, dev[k], yard[k])
     # dconv3 of the local attention modules and the ImageNet head are never run: no gradient in either implementation
     assert float(dec.local_attention_4.dconv3._modules["0"].weight.grad.abs().max() if dec.local_attention_4.dconv3._modules["0"].weight.grad is not None else 0.0) == 0.0
+
+
+# measured on the MI355X (round 4): worst activation / upstream gradient / |grad| / 1 - cos over the blocks of the net
+_GALD_FORCED_BARS = dict(act=4e-2, grd=1e-1, nrm=1e-1, dirn=5e-2)
+
+
+def test_gald_teacher_forced_every_block_vs_oracle():
+    """Every tapped block of GCPAEncoder / GCPADecoder (the 16 modules of hardnet.base, conva, both criss-cross applications, the three local attention
+    modules, the three FAMs, the four heads and their upsampling) is fed the ORACLE's fp32 activation at its input and the oracle's gradient at its
+    output (tests/_parity.py); what it makes of them - its output, the gradient it hands upstream, and EVERY parameter gradient of the two modules
+    (norm and direction) - is compared with the oracle's, one block deep.  The oracle run is the reference's (pinned by g13_gald_352 here)."""
+    import _parity as P
+    from oracle import ref_gald as rg
+    from rnd_semantic_segmentation_amd.host import gald
+    enc, dec, renc, rdec = _gald_pair()
+    x, lab, g = _cases.gald352_inputs()
+    x, lab = torch.from_numpy(x), torch.from_numpy(lab).long()
+    seen = {}
+
+    def ref_loss(outs):
+        ls, loss = rg.gald_losses(outs, lab)
+        seen["fp32"] = [float(l) for l in ls]
+        return loss
+    o, want_pg, taps, tgrads = P.oracle_run([renc, rdec], lambda: rdec(x, renc(x)), ref_loss)
+    assert np.allclose(seen["fp32"], g["losses"], rtol=2e-5)
+    crit = gald.CrossEntropyNHWC(255)
+    xc, labc = x.cuda(), lab.cuda()
+
+    def eng_loss(outs):
+        ls = [crit(v, labc) for v in outs]
+        return ls[3] * 1 + ls[2] * 0.8 + ls[1] * 0.6 + ls[0] * 0.4
+    own, gown, pg = P.engine_forced([enc, dec], lambda: dec(xc, enc(xc)), eng_loss, taps, tgrads)
+    assert len(own) == len(taps) == 16 + 1 + 2 + 3 + 3 + 4 + 4 and len(gown) == len(tgrads)
+    r = P.forced_report("gald 352", own, gown, pg, taps, tgrads, want_pg)
+    assert not r["missing"], r["missing"][:5]
+    for k, bar in _GALD_FORCED_BARS.items():
+        assert r[k + "_worst"] < bar, (k, r[k + "_worst"], sorted(r[k].items(), key=lambda kv: -kv[1])[:5])
+
+
+def test_gald_trainer_refuses_out_of_range_labels(tmp_path):
+    """gald_trainer.py:107 builds torch.nn.CrossEntropyLoss(ignore_index=255), which device-asserts on a label outside [0, K) that is not 255; the
+    fused heads skip AND count such pixels, and GALDTrainer raises where it fetches the loss."""
+    import logging
+    from rnd_semantic_segmentation_amd.host import config as hc, gald
+    cfg = hc.CfgNode(hc.default_tree())
+    cfg.merge_from_list(["OUTPUT_DIR", str(tmp_path), "SOLVER.EPOCHS", 1, "SOLVER.BASE_LR", 1e-4, "SOLVER.CHECKPOINT_PERIOD", 100])
+    cfg.freeze()
+    x = torch.from_numpy(synth.synth_image(2, 224, 224, seed=5))
+    good = torch.from_numpy(synth.synth_label(2, 224, 224, 19, seed=5))
+    bad = good.clone()
+    bad[0, 100, 100] = 50
+    log = logging.getLogger("gald_bad_labels")
+    log.addHandler(logging.NullHandler())
+    for loader, raises in (([(x, good, None), (x, bad, None)], True), ([(x, good, None)] * 2, False)):
+        tr = gald.GALDTrainer("gald", cfg, loader, 0, logger=log)
+        tr.encoder.train()
+        tr.decoder.train()
+        if raises:
+            with pytest.raises(ValueError, match="outside"):
+                tr._train_epoch(1)
+        else:
+            tr._train_epoch(1)
+            assert len(tr.loss_data) == 2 and all(np.isfinite(tr.loss_data))
 
 
 @pytest.mark.parametrize("h,w,H,W", [(7, 7, 224, 224), (23, 40, 90, 160), (12, 9, 24, 18)])

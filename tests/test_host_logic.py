@@ -130,6 +130,11 @@ def test_dropin_import_surface():
     from core.models.classifiers.pranet.PraNet_Res2Net import PraNet  # noqa: F401
     from core.utils.utils import AvgMeter, clip_gradient  # noqa: F401
     assert issubclass(pt.PraNetTrainer, BaseTrainer) and issubclass(gt.GALDTrainer, BaseTrainer)
+    from core.models.classifiers.gcpacc.contextagg.ccnet import CrissCrossAttention  # noqa: F401   (the GALD building blocks and the tester)
+    from core.models.classifiers.gcpacc.contextagg.GALDNet import LocalAttenModule  # noqa: F401
+    from core.models.classifiers.gcpacc.encoders.hardnet_68 import HarDBlock  # noqa: F401
+    from core.models.classifiers.gcpacc.gcpa_gald import FAM  # noqa: F401
+    from core.testers.gald_tester import GALDTester  # noqa: F401
     g = _cases.load("g4_frozenbn")
     bn = FrozenBatchNorm2d(96)
     bn.load_state_dict({k: torch.from_numpy(g[k]) for k in ("weight", "bias", "running_mean", "running_var")})

@@ -374,18 +374,17 @@ def test_pranet_modules_restatement_vs_reference_golden():
 
 
 def test_pranet_whole_net_restatement_vs_reference_golden(golden_dir):
-    """oracle PraNet (Res2Net-50 v1b 26w x 4s + RFB + partial decoder + reverse attention) against the reference's own run at 2 x 3 x 96 x 96
-    (g12): state_dict keys / parameter count, the four train-mode side outputs, the structure-loss sum of pranet_trainer.py:50-56, every
-    parameter-gradient norm, running statistics after 121 train-mode forwards and the eval-mode outputs on them."""
+    """oracle PraNet (Res2Net-50 v1b 26w x 4s + RFB + partial decoder + reverse attention) against the reference's own run at 8 x 3 x 160 x 160
+    (g12_pranet_160): state_dict keys / parameter count, the four train-mode side outputs, the structure-loss sum of pranet_trainer.py:50-56, every
+    parameter-gradient norm, running statistics after 41 train-mode forwards, the eval-mode outputs on them and the mask PranetTester derives."""
     from oracle import ref_pranet as rp
     keys = json.load(open(os.path.join(golden_dir, "g8_pranet_keys.json")))
     net = rp.PraNet()
     assert list(net.state_dict().keys()) == keys["keys"] and len(keys["keys"]) == 922
     assert sum(p.numel() for p in net.parameters()) == keys["n_params"] == 32547319 and len(list(net.parameters())) == keys["n_tensors"]
-    g = _cases.load("g12_pranet_96")
-    synth.load_formula_weights(net, prefix="pranet.")
-    x = torch.from_numpy(synth.synth_image(2, 96, 96, seed=31))
-    gt = torch.from_numpy(g["gt"])
+    x, gt, g = _cases.pranet160_inputs()
+    x, gt = torch.from_numpy(x), torch.from_numpy(gt)
+    synth.load_formula_weights(net, prefix="pranet.", bn_bias=synth.COND_BN_BIAS)
     net.train()
     outs = net(x)
     losses = [rp.structure_loss(o, gt) for o in outs]
@@ -394,28 +393,40 @@ def test_pranet_whole_net_restatement_vs_reference_golden(golden_dir):
     assert np.allclose([l.item() for l in losses], g["train_losses"], rtol=2e-5)
     assert abs(loss.item() - float(g["train_loss"])) < 2e-5 * float(g["train_loss"])
     for i, o in enumerate(outs):
-        assert rel(o.detach().numpy()[:, :, ::4, ::4], g["train_map%d_crop" % i]) < 1e-4, i
+        assert rel(o.detach().numpy()[:, :, ::8, ::8], g["train_map%d_crop" % i]) < 1e-4, i
     gn = {k: float(p.grad.double().norm()) for k, p in net.named_parameters() if p.grad is not None}
     names = [str(n) for n in g["pnames"]]
     assert sorted(gn) == names                                        # resnet.fc.* get no gradient in either implementation
     ours = np.array([gn[k] for k in names])
     big = g["pgrad"] > 1e-6 * g["pgrad"].max()
     assert np.abs(ours[big] / g["pgrad"][big] - 1).max() < 5e-3
-    with torch.no_grad():
-        for _ in range(120):
-            net(x)
+    maps, pred, margin = pranet_eval_after_warmup(net, x, 40)
     sd = net.state_dict()
-    assert int(sd["resnet.bn1.num_batches_tracked"]) == int(g["num_batches_tracked"]) == 121
+    assert int(sd["resnet.bn1.num_batches_tracked"]) == int(g["num_batches_tracked"]) == 41
     for k in ("resnet.bn1", "resnet.layer2.0.bns.1", "rfb3_1.conv_cat.bn", "ra2_conv3.bn"):
         tag = k.replace(".", "_")
         assert rel(sd[k + ".running_mean"].numpy(), g["stat_" + tag + "_mean"]) < 1e-4, k
         assert rel(sd[k + ".running_var"].numpy(), g["stat_" + tag + "_var"]) < 1e-4, k
+    for i, m in enumerate(maps):
+        assert rel(m[:, :, ::8, ::8], g["eval_map%d_crop" % i]) < 1e-3, i
+    assert rel(maps[3][:2], g["eval_map3_full01"]) < 1e-3
+    want = np.unpackbits(g["eval_mask_bits"])[:pred.size].reshape(g["eval_mask_shape"])
+    flips = np.flatnonzero(pred.reshape(-1) != want.reshape(-1))
+    assert all(margin[i] < 1e-4 for i in flips), (len(flips), [float(margin[i]) for i in flips[:5]])      # a flip only where the reference decides by < 1e-4
+
+
+def pranet_eval_after_warmup(net, x, n):
+    """n more train-mode forwards (the running statistics move towards the batch statistics), then eval(): the four maps, the mask
+    PranetTester.test derives from lateral_map_2 (pranet_tester.py:37-46) and every pixel's decision margin |2 p - 1|."""
+    with torch.no_grad():
+        for _ in range(n):
+            net(x)
     net.eval()
     with torch.no_grad():
-        maps = net(x)
-    for i, m in enumerate(maps):
-        assert rel(m.numpy()[:, :, ::4, ::4], g["eval_map%d_crop" % i]) < 1e-3, i
-
+        maps = [m.numpy() for m in net(x)]
+    p = torch.from_numpy(maps[3]).sigmoid().numpy().squeeze(1)
+    p = (p - p.min()) / (p.max() - p.min() + 1e-8)
+    return maps, (p > 1 - p).astype(np.uint8), np.abs(2.0 * p.astype(np.float64) - 1.0).reshape(-1)
 
 
 # ------------------------------------------------------------------------------------------------ GALD / GCPA (SURVEY 8f row N4)
@@ -452,19 +463,18 @@ def test_gald_modules_restatement_vs_reference_golden():
 
 
 def test_gald_whole_net_restatement_vs_reference_golden(golden_dir):
-    """oracle GCPAEncoder (HarDNet-68) + GCPADecoder against the reference's own run at 2 x 3 x 224 x 224 (g13_gald_224): state_dict keys and
+    """oracle GCPAEncoder (HarDNet-68) + GCPADecoder against the reference's own run at 4 x 3 x 352 x 352 (g13_gald_352): state_dict keys and
     parameter counts, feature shapes / norms, the four outputs, the four cross-entropies and their weighted sum (gald_trainer.py:66-84),
-    every parameter-gradient norm."""
+    every parameter-gradient norm; running statistics after 13 train-mode forwards, the eval-mode res2 and the argmax mask GALDTester derives."""
     from oracle import ref_gald as rg
     keys = json.load(open(os.path.join(golden_dir, "g8_gald_keys.json")))
     enc, dec = rg.GCPAEncoder(), rg.GCPADecoder()
     assert list(enc.state_dict().keys()) == keys["encoder"] and list(dec.state_dict().keys()) == keys["decoder"]
     assert sum(p.numel() for p in enc.parameters()) == keys["n_enc"] and sum(p.numel() for p in dec.parameters()) == keys["n_dec"]
-    g = _cases.load("g13_gald_224")
-    synth.load_formula_weights(enc, prefix="gald.enc.")
-    synth.load_formula_weights(dec, prefix="gald.dec.")
-    x = torch.from_numpy(synth.synth_image(2, 224, 224, seed=51))
-    lab = torch.from_numpy(synth.synth_label(2, 224, 224, 19, seed=51)).long()
+    x, lab, g = _cases.gald352_inputs()
+    x, lab = torch.from_numpy(x), torch.from_numpy(lab).long()
+    synth.load_formula_weights(enc, prefix="gald.enc.", bn_bias=synth.COND_BN_BIAS)
+    synth.load_formula_weights(dec, prefix="gald.dec.", bn_bias=synth.COND_BN_BIAS)
     enc.train()
     dec.train()
     feats = enc(x)
@@ -484,3 +494,25 @@ def test_gald_whole_net_restatement_vs_reference_golden(golden_dir):
         want = g[tag + "_pgrad"]
         big = want > 1e-6 * want.max()
         assert np.abs(np.array([gn[k] for k in names])[big] / want[big] - 1).max() < 5e-3, tag
+    res2, pred, margin = gald_eval_after_warmup(enc, dec, x, 12)
+    sde, sdd = enc.state_dict(), dec.state_dict()
+    assert int(sdd["conva.1.num_batches_tracked"]) == int(g["num_batches_tracked"]) == 13
+    for tag, sd_, k in (("enc", sde, "hardnet.base.8.layers.3.norm"), ("enc", sde, "hardnet.base.15.norm"), ("dec", sdd, "fam34.bn3"), ("dec", sdd, "local_attention_3.dconv2.1")):
+        assert rel(sd_[k + ".running_mean"].numpy(), g["stat_%s_%s_mean" % (tag, k.replace(".", "_"))]) < 1e-4, k
+        assert rel(sd_[k + ".running_var"].numpy(), g["stat_%s_%s_var" % (tag, k.replace(".", "_"))]) < 1e-4, k
+    assert rel(res2[:, :, ::16, ::16], g["eval_res2_crop"]) < 1e-3
+    flips = np.flatnonzero(pred[0].reshape(-1) != g["eval_pred0"].reshape(-1))
+    assert all(margin[i] < 1e-4 for i in flips), (len(flips), [float(margin[i]) for i in flips[:5]])
+
+
+def gald_eval_after_warmup(enc, dec, x, n):
+    """n more train-mode forwards, then eval(): res2 at the input size (gald_tester.py:56-68), its argmax and every pixel's top-2 logit margin."""
+    with torch.no_grad():
+        for _ in range(n):
+            dec(x, enc(x))
+    enc.eval()
+    dec.eval()
+    with torch.no_grad():
+        res2 = dec(x, enc(x))[3]
+    top2 = torch.topk(res2, 2, dim=1).values
+    return res2.numpy(), res2.argmax(1).numpy().astype(np.uint8), (top2[:, 0] - top2[:, 1]).double().reshape(-1).numpy()
