@@ -406,6 +406,30 @@ int mi_gcca_bwd(const void* q, long ldq, const void* k, long ldk, const void* v,
  * o1 = d loss / d x = dout * (1 + s), o2 = d loss / d g = dout * x * s * (1 - s). */
 int mi_ggate(const void* x, long ldx, const void* g, long ldg, const void* dout, long lddo, void* o1, long ld1, void* o2, long ld2, long M, int C, void* stream);
 
+/* ---- the general family in the reference's precision (csrc/gf32.hip): evaluation forward of PraNet / GALD in fp32 ------------------------
+ * Replaces the eval()-mode forward of core/testers/pranet_tester.py:36 (`self.model(x)`) and core/testers/gald_tester.py:56-57
+ * (`self.encoder(x)`, `self.decoder(x, ...)`), whose masks the testers threshold: fp32 NHWC views (pointer to channel 0 + floats per pixel
+ * row), weights read from the fp32 OIHW masters, fp32 accumulation on v_mfma_f32_16x16x4_f32 (exact fp32 products: BASELINE's 1e-3 / identical
+ * argmax bar).  Forward only.
+ * mi_gconv_f32: out = act(((conv(a, w) + bias) * scale + shift) + add): nn.Conv2d (any taps, per-axis stride / padding / dilation) + its bias,
+ * BatchNorm2d in eval() as the affine of mi_gbn_fold (scale / shift NULL: none), the residual view (NULL: none), act 0 none | 1 ReLU | 2 ReLU6 -
+ * the order of Res2Net_v1b.py:86-92 / PraNet_Res2Net.py:17-20,57-58 / hardnet_68.py:56-80. */
+int mi_gconv_f32(const float* a, long lda, const float* w_oihw, const float* bias, const float* scale, const float* shift, const float* add, long ldadd, int act,
+                 float* out, long ldo, int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                 void* stream);
+/* mode 0: AvgPool2d(k, stride, pad), count_include_pad=True (Res2Net_v1b.py:40); 1: AvgPool2d(stride, stride, ceil_mode=True,
+ * count_include_pad=False) (Res2Net_v1b.py:122-123); 2: MaxPool2d(k, stride, pad) (Res2Net_v1b.py:152, hardnet_68.py:213,233) */
+int mi_gpool_f32(const float* x, long ldx, float* out, long ldo, int B, int H, int W, int C, int Ho, int Wo, int k, int stride, int pad, int mode, void* stream);
+/* depthwise 3x3 + bias + eval()-BatchNorm affine + activation (GALDNet.py:127-141) */
+int mi_gdwconv_f32(const float* x, long ldx, const float* w, const float* bias, const float* scale, const float* shift, int act, float* out, long ldo, int B, int H,
+                   int W, int C, int Ho, int Wo, int stride, int pad, void* stream);
+/* criss-cross attention core (ccnet.py:56-127), forward: out = sum_j softmax_j(q . k_j) v_j over the pixel's column (own position masked) and row */
+int mi_gcca_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, float* out, long ldo, int B, int H, int W, int Cq, int C, void* stream);
+/* pointwise: op 0 out = act(a * scale[c] + shift[c] (+ b)) (gamma * agg + x of ccnet.py:127); 1 out = (1 - sigmoid(b[m])) * a, b one value per pixel
+ * (PraNet_Res2Net.py:131-133); 2 out = a + a * sigmoid(b) (GALDNet.py:150-157); 3 out = relu(a * b) (gcpa_gald.py:88-101) */
+int mi_gpoint_f32(int op, const float* a, long lda, const float* b, long ldb, const float* scale, const float* shift, int act, float* out, long ldo, long M, int C,
+                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

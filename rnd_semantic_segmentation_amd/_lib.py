@@ -103,6 +103,11 @@ SIGNATURES = {
     "mi_gcca_fwd": (I, [P, L, P, L, P, L, P, P, L] + [I] * 5 + [P]),
     "mi_gcca_bwd": (I, [P, L, P, L, P, L, P, P, L, P, P, L, P, L, P, L] + [I] * 5 + [P]),
     "mi_ggate": (I, [P, L, P, L, P, L, P, L, P, L, L, I, P]),
+    "mi_gconv_f32": (I, [P, L, P, P, P, P, P, L, I, P, L] + [I] * 15 + [P]),
+    "mi_gpool_f32": (I, [P, L, P, L] + [I] * 10 + [P]),
+    "mi_gdwconv_f32": (I, [P, L, P, P, P, P, I, P, L] + [I] * 8 + [P]),
+    "mi_gcca_f32": (I, [P, L, P, L, P, L, P, L] + [I] * 5 + [P]),
+    "mi_gpoint_f32": (I, [I, P, L, P, L, P, P, I, P, L, L, I, P]),
 }
 
 _lib = None

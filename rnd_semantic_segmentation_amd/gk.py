@@ -389,3 +389,77 @@ def gce(logits, labels, ignore_index=255, want_grad=True, grad_scale=1.0):
     d = torch.empty((B, H, W, Kc), dtype=torch.float32, device=logits.device) if want_grad else None
     check(L.mi_gce(pl, ld, _p(labels), B * H * W, Kc, int(ignore_index), _p(out), _p(d), Kc, ctypes.c_float(grad_scale), _p(ws), ws.numel(), _stream()), "mi_gce")
     return out, d
+
+
+# ---------------------------------------------------------------------------------------------- the family in fp32 (csrc/gf32.hip): evaluation forward
+F32 = torch.float32
+ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
+PW_AFFINE, PW_REVERSE, PW_GATE, PW_MULRELU = 0, 1, 2, 3
+
+
+def _act(relu):
+    return ACT_RELU6 if relu == 6 else (ACT_RELU if relu else ACT_NONE)
+
+
+def gconv_f32(x, w, geom, bias=None, scale=None, shift=None, add=None, relu=False, out=None):
+    """act(((conv(x, w) + bias) * scale + shift) + add) in fp32: x [B,H,W,Cin] fp32 view, w the fp32 OIHW master weight."""
+    kh, kw, sh, sw, ph, pw, dh, dw = geom
+    B, Ha, Wa, Ca = x.shape
+    N = w.shape[0]
+    Ho, Wo = conv_out_hw(Ha, Wa, *geom)
+    if out is None:
+        out = new(B, Ho, Wo, N, x.device, F32)
+    if tuple(out.shape) != (B, Ho, Wo, N) or tuple(w.shape) != (N, Ca, kh, kw) or not w.is_contiguous() or w.dtype != F32:
+        raise _lib.MiError("gconv_f32: out %s / weight %s do not fit input %s, taps %dx%d" % (tuple(out.shape), tuple(w.shape), tuple(x.shape), kh, kw))
+    px, ldx = view(x, F32)
+    po, ldo = view(out, F32)
+    pa, lda = view(add, F32) if add is not None else (None, 0)
+    check(_L().mi_gconv_f32(px, ldx, _p(w), _p(bias), _p(scale), _p(shift), pa, lda, _act(relu), po, ldo, B, Ha, Wa, Ca, Ho, Wo, N, kh, kw, sh, sw, ph, pw, dh, dw,
+                            _stream()), "mi_gconv_f32")
+    return out
+
+
+def gpool_f32(x, k, stride, pad, mode, out_hw=None, out=None):
+    """mode 0 / 1: the two AvgPool2d conventions of Res2Net_v1b.py:40,122 (out_hw given by the caller for the ceil_mode one); 2: MaxPool2d."""
+    B, H, W, C = x.shape
+    Ho, Wo = out_hw if out_hw is not None else ((H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1)
+    if out is None:
+        out = new(B, Ho, Wo, C, x.device, F32)
+    (px, ldx), (po, ldo) = view(x, F32), view(out, F32)
+    check(_L().mi_gpool_f32(px, ldx, po, ldo, B, H, W, C, Ho, Wo, k, stride, pad, mode, _stream()), "mi_gpool_f32")
+    return out
+
+
+def gdwconv_f32(x, w, bias, stride, pad, scale=None, shift=None, relu=False):
+    B, H, W, C = x.shape
+    Ho, Wo = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
+    out = new(B, Ho, Wo, C, x.device, F32)
+    (px, ldx), (po, ldo) = view(x, F32), view(out, F32)
+    check(_L().mi_gdwconv_f32(px, ldx, _p(w), _p(bias), _p(scale), _p(shift), _act(relu), po, ldo, B, H, W, C, Ho, Wo, stride, pad, _stream()), "mi_gdwconv_f32")
+    return out
+
+
+def gcca_f32(q, k, v):
+    B, H, W, Cq = q.shape
+    C = v.shape[-1]
+    out = new(B, H, W, C, q.device, F32)
+    (pq, ldq), (pk, ldk), (pv, ldv), (po, ldo) = view(q, F32), view(k, F32), view(v, F32), view(out, F32)
+    check(_L().mi_gcca_f32(pq, ldq, pk, ldk, pv, ldv, po, ldo, B, H, W, Cq, C, _stream()), "mi_gcca_f32")
+    return out
+
+
+def gpoint_f32(op, a, b=None, scale=None, shift=None, relu=False, out=None):
+    B, H, W, C = a.shape
+    if out is None:
+        out = new(B, H, W, C, a.device, F32)
+    (pa, lda), (po, ldo) = view(a, F32), view(out, F32)
+    if b is None:
+        pb, ldb = None, 0
+    elif op == PW_REVERSE:
+        if not (b.dtype == F32 and b.is_contiguous() and b.numel() == B * H * W):
+            raise _lib.MiError("gpoint_f32: the reverse-attention gate must be contiguous fp32 with one value per pixel")
+        pb, ldb = ctypes.c_void_p(b.data_ptr()), 1
+    else:
+        pb, ldb = view(b, F32)
+    check(_L().mi_gpoint_f32(op, pa, lda, pb, ldb, _p(scale), _p(shift), _act(relu), po, ldo, B * H * W, C, _stream()), "mi_gpoint_f32")
+    return out

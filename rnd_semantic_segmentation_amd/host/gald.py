@@ -32,6 +32,8 @@ from .pranet import FlatAdam, _acc, _Engine, _grad_target, _Run, _Unit
 class _GaldRun(_Run):
     def maxpool(self, x, k, stride, pad):
         H, W = x.t.shape[1], x.t.shape[2]
+        if self.f32:
+            return self.var(gk.gpool_f32(x.t, k, stride, pad, 2), False)
         o, idx = gk.gmaxpool(x.t, k, stride, pad)
         ov = self.var(o)
 
@@ -47,8 +49,10 @@ class _GaldRun(_Run):
         net, bn = self.net, u.bn
         C = u.cout
         if not self.train:
-            y, _ = gk.gdwconv(x.t, u.weight.detach(), u.bias.detach(), 2, 0)
             sc, sh = net._eval_fold(u)
+            if self.f32:
+                return self.var(gk.gdwconv_f32(x.t, u.weight.detach(), u.bias.detach(), 2, 0, scale=sc, shift=sh, relu=True), False)
+            y, _ = gk.gdwconv(x.t, u.weight.detach(), u.bias.detach(), 2, 0)
             return self.var(gk.gbn_apply(y, sc, sh, 1), False)
         y, st = gk.gdwconv(x.t, u.weight.detach(), u.bias.detach(), 2, 0, stats=True)
         M = y.shape[0] * y.shape[1] * y.shape[2]
@@ -72,6 +76,8 @@ class _GaldRun(_Run):
 
     def gate(self, x, g):
         """x + x * sigmoid(g) (GALDNet.py:150-157)"""
+        if self.f32:
+            return self.var(gk.gpoint_f32(gk.PW_GATE, x.t, g.t), False)
         ov = self.var(gk.ggate(x.t, g.t))
 
         def back():
@@ -86,6 +92,8 @@ class _GaldRun(_Run):
 
     def mulrelu(self, a, b, out=None):
         """relu(a * b) (gcpa_gald.py:88-101)"""
+        if self.f32:
+            return self.var(gk.gpoint_f32(gk.PW_MULRELU, a.t, b.t, out=out), False)
         o = gk.gbinary(gk.OP_MULRELU, a.t, b.t, out=out)
         ov = self.var(o)
 
@@ -118,6 +126,9 @@ class _GaldRun(_Run):
         """CrissCrossAttention.forward (ccnet.py:56-127): gamma * aggregate + x."""
         net = self.net
         q, k, v = self.conv_bias(x, uq, out_f32=False), self.conv_bias(x, uk, out_f32=False), self.conv_bias(x, uv, out_f32=False)
+        if self.f32:
+            C = v.t.shape[-1]
+            return self.var(gk.gpoint_f32(gk.PW_AFFINE, gk.gcca_f32(q.t, k.t, v.t), x.t, scale=gamma.detach().expand(C).contiguous(), shift=net._zeros(C)), False)
         agg, att = gk.gcca_fwd(q.t, k.t, v.t)
         C = agg.shape[-1]
         gvec = gamma.detach().expand(C).contiguous()
@@ -577,6 +588,9 @@ class GALDTester:
         self.decoder = GCPADecoder(cfg.MODEL.NUM_CLASSES) if cfg.MODEL.NUM_CLASSES != 19 else GCPADecoder()
         self.encoder.to(device)
         self.decoder.to(device)
+        precision = cfg.TEST.PRECISION if "PRECISION" in cfg.TEST else "fp32"      # 'fp32': the reference's precision (csrc/gf32.hip); 'bf16': the training regime
+        self.encoder.set_precision(precision)
+        self.decoder.set_precision(precision)
 
     def _load_checkpoint(self):
         self.logger.info("Loading checkpoint from {}".format(self.cfg.resume))

@@ -177,6 +177,11 @@ class _Run:
 
     def __init__(self, net, train, rec):
         self.net, self.train, self.rec, self.tape, self.side = net, train, rec, [], None
+        # fp32: the evaluation forward in the reference's precision (csrc/gf32.hip; _Engine.set_precision): every activation fp32, every conv with
+        # its eval()-BatchNorm affine, residual and activation in one launch
+        self.f32 = (not train) and getattr(net, "precision", "bf16") == "fp32"
+        if self.f32 and rec:
+            raise _lib.MiError("precision 'fp32' is the evaluation forward (no backward kernels exist in fp32): run under torch.no_grad(), or set_precision('bf16')")
 
     def record(self, fn):
         if self.rec:
@@ -224,8 +229,10 @@ class _Run:
         act = 2 if relu == 6 else int(bool(relu))
         bias = None if u.bias is None else u.bias.detach()
         if not self.train:
-            y, _ = _conv_forward(x.t, u, bias, False, net=net)
             sc, sh = net._eval_fold(u)
+            if self.f32:
+                return self.var(gk.gconv_f32(x.t, u.weight.detach(), u.geom, bias=bias, scale=sc, shift=sh, add=None if add is None else add.t, relu=relu, out=out), False)
+            y, _ = _conv_forward(x.t, u, bias, False, net=net)
             return self.var(gk.gbn_apply(y, sc, sh, act, add=None if add is None else add.t, out=out, out_f32=out_f32), False)
         y, st = _conv_forward(x.t, u, bias, True, net=net)
         M = y.shape[0] * y.shape[1] * y.shape[2]
@@ -290,8 +297,10 @@ class _Run:
         in ONE pass (mi_stem_pool_fwd with the batch affine); backward: pooled gradient routed by the stored argmax, then BatchNorm backward."""
         net, bn = self.net, u.bn
         if not self.train:
-            y, _ = gk.gconv(x.t, u.wp, u.cout, u.geom)
             sc, sh = net._eval_fold(u)
+            if self.f32:
+                return self.var(gk.gpool_f32(gk.gconv_f32(x.t, u.weight.detach(), u.geom, scale=sc, shift=sh, relu=True), 3, 2, 1, 2), False)
+            y, _ = gk.gconv(x.t, u.wp, u.cout, u.geom)
             return self.var(K.stem_pool_fwd(y, sc, sh)[0], False)
         y, st = gk.gconv(x.t, u.wp, u.cout, u.geom, stats=True)
         M = y.shape[0] * y.shape[1] * y.shape[2]
@@ -312,6 +321,8 @@ class _Run:
     def conv_bias(self, x, u, out_f32=True):
         """nn.Conv2d with bias and no BatchNorm: the one-channel / class-logit heads in fp32 (agg1.conv5, PraNet_Res2Net.py:77; linear2..5,
         gcpa_cc2.py:37-40) or a bf16 feature conv (conv_d1 / conv_d2 / conv_l of FAM, gcpa_gald.py:66-74; the q / k / v projections of ccnet.py:43-51)."""
+        if self.f32:
+            return self.var(gk.gconv_f32(x.t, u.weight.detach(), u.geom, bias=u.bias.detach()), False)
         o, _ = _conv_forward(x.t, u, u.bias.detach(), False, out_f32=out_f32, net=self.net)
         ov = self.var(o)
 
@@ -359,6 +370,8 @@ class _Run:
             Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
         else:
             Ho, Wo = -(-H // stride), -(-W // stride)
+        if self.f32:
+            return self.var(gk.gpool_f32(x.t, k, stride, pad, 0 if include_pad else 1, (Ho, Wo), out=out), False)
         ov = self.var(gk.gavgpool(x.t, k, stride, pad, include_pad, (Ho, Wo), out=out))
 
         def back():
@@ -384,6 +397,8 @@ class _Run:
         return ov
 
     def reverse_attention(self, gate, feat):
+        if self.f32:
+            return self.var(gk.gpoint_f32(gk.PW_REVERSE, feat.t, gate.t), False)
         ov = self.var(gk.gra_fwd(gate.t, feat.t))
 
         def back():
@@ -453,7 +468,7 @@ def _bottle2neck(run, x, blk):
     groups, slots = run.split(o1, w, 4)
     B, H, W, _ = o1.t.shape
     Ho, Wo = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
-    cat = gk.new(B, Ho, Wo, 4 * w, x.t.device)
+    cat = gk.new(B, Ho, Wo, 4 * w, x.t.device, x.t.dtype)
     pieces, prev, sums = [], None, []
     for i in range(3):
         if i == 0 or stage:
@@ -482,7 +497,7 @@ def _bottle2neck(run, x, blk):
 def _rfb_block(run, x, units, c):
     """RFB_modified.forward (PraNet_Res2Net.py:50-59); BasicConv2d applies no ReLU (:17-20)."""
     B, H, W, _ = x.t.shape
-    cat = gk.new(B, H, W, 4 * c, x.t.device)
+    cat = gk.new(B, H, W, 4 * c, x.t.device, x.t.dtype)
     pieces = []
     for i in range(4):
         y = x
@@ -500,8 +515,8 @@ def _aggregation(run, a, c, x1, x2, x3):
     mul = lambda p, q, out=None: run.binary(gk.OP_MUL, p, q, out=out)
     B, H2, W2, _ = x2.t.shape
     _, H3, W3, _ = x3.t.shape
-    cat2 = gk.new(B, H2, W2, 2 * c, x1.t.device)
-    cat3 = gk.new(B, H3, W3, 3 * c, x1.t.device)
+    cat2 = gk.new(B, H2, W2, 2 * c, x1.t.device, x1.t.dtype)
+    cat3 = gk.new(B, H3, W3, 3 * c, x1.t.device, x1.t.dtype)
     up1 = up(x1)
     x2_1 = mul(run.conv_bn(up1, a["up1"], False), x2, out=cat2[..., :c])
     x3_1 = mul(mul(run.conv_bn(up(up1), a["up2"], False), run.conv_bn(up(x2), a["up3"], False)), x3, out=cat3[..., :c])
@@ -589,6 +604,10 @@ class _Engine(nn.Module):
         """running_mean / running_var of every BatchNorm2d as views of one buffer, num_batches_tracked likewise: the counter of all the
         layers advances with ONE add per training forward."""
         bns = [u.bn for u in self._units if u.bn is not None]
+        if not bns:                                          # a module without BatchNorm (CrissCrossAttention)
+            self._stat_flat, self._nbt = torch.empty(0, dtype=torch.float32, device=dev), torch.zeros(0, dtype=torch.int64, device=dev)
+            self._stat_gen += 1
+            return
         n = sum(b.num_features for b in bns)
         flat = torch.empty(2 * n, dtype=torch.float32, device=dev)
         nbt = torch.empty(len(bns), dtype=torch.int64, device=dev)
@@ -607,7 +626,9 @@ class _Engine(nn.Module):
         self._stat_gen += 1
 
     def _buffers_intact(self, dev):
-        u = next(x for x in self._units if x.bn is not None)
+        u = next((x for x in self._units if x.bn is not None), None)
+        if u is None:
+            return self._stat_flat is not None and self._stat_flat.device == dev
         return self._stat_flat is not None and self._stat_flat.device == dev and u.bn.running_mean.data_ptr() == self._stat_flat.data_ptr()
 
     def _build_pack_plan(self, dev):
@@ -633,7 +654,8 @@ class _Engine(nn.Module):
         st = self.ensure_flat()
         sig = (st.generation, sum(u.weight._version for u in self._units), st.data.data_ptr())
         if sig != self._pack_sig:
-            gk.gconv_pack_multi(st.data, self._wp_flat, self._wpt_flat, self._pack_table, self._pack_n, self._pack_blocks)
+            if self._pack_n:                                 # (a module of depthwise convs only has nothing to pack: LocalAttenModule)
+                gk.gconv_pack_multi(st.data, self._wp_flat, self._wpt_flat, self._pack_table, self._pack_n, self._pack_blocks)
             self._pack_sig = sig
         return st
 
@@ -678,6 +700,17 @@ class _Engine(nn.Module):
             self._eval_cache[u.key] = hit
         return hit[1]
 
+    precision = "bf16"
+
+    def set_precision(self, precision):
+        """'bf16': the training engine's regime in eval() too (bf16 activations and operands, fp32 accumulation).  'fp32': eval() forwards run in
+        the reference's precision (csrc/gf32.hip) - what the testers use by default (TEST.PRECISION), so that the masks they threshold are the
+        reference's.  train() forwards are bf16 either way."""
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32', got %r" % (precision,))
+        self.precision = precision
+        return self
+
     def _graph(self, run, *inputs):
         raise NotImplementedError
 
@@ -688,7 +721,8 @@ class _Engine(nn.Module):
                                    % (type(self).__name__, x.device))
         self._prepare()
         run = self.RUN(self, self.training, rec)
-        ins = [run.var(x.detach().permute(0, 2, 3, 1).to(torch.bfloat16).contiguous(), need) for x, need in zip(xs, in_needs)]      # NHWC bf16
+        dt = torch.float32 if run.f32 else torch.bfloat16
+        ins = [run.var(x.detach().permute(0, 2, 3, 1).to(dt).contiguous(), need) for x, need in zip(xs, in_needs)]      # NHWC bf16 (fp32 evaluation: fp32)
         outs = self._graph(run, *ins)
         if self.training:
             self._nbt.add_(1)
@@ -1089,6 +1123,9 @@ class PranetTester:
         self.cfg, self.logger, self.test_loader, self.device = cfg, logger, test_loader, device
         self.model = PraNet()
         self.model.to(device)
+        # The reference thresholds an fp32 forward (pranet_tester.py:36-46): TEST.PRECISION 'fp32' (default) evaluates in the reference's precision
+        # (csrc/gf32.hip: maps within 1e-5 of the reference's, masks identical), 'bf16' in the training engine's regime (faster).
+        self.model.set_precision(cfg.TEST.PRECISION if "PRECISION" in cfg.TEST else "fp32")
 
     def _load_checkpoint(self):
         self.logger.info("Loading checkpoint from {}".format(self.cfg.resume))
@@ -1097,7 +1134,7 @@ class PranetTester:
 
     def predict(self, x, hw):
         with torch.no_grad():
-            res2 = self.model(x)[3]
+            res2 = self.model(x)[3].float()
             out = gk.gresize(res2.permute(0, 2, 3, 1).contiguous(), hw, False).permute(0, 3, 1, 2)
             p = out.sigmoid().squeeze(1)
             p = (p - p.min()) / (p.max() - p.min() + 1e-8)

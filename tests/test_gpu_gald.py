@@ -125,9 +125,11 @@ def _gald_cases():
     ]
 
 
-# measured on the MI355X (round 4; the printed line of each case): out / dx / |grad| / 1 - cos
-_GALD_BARS = {"hdb": (3e-2, 6e-2, 6e-2, 2e-2), "fam": (3e-2, 6e-2, 6e-2, 2e-2), "cca": (1.5e-2, 3e-2, 6e-2, 6e-3), "lam": (1.5e-2, 6e-2, 0.1, 2e-2),
-              "cca_twice": (3e-2, 6e-2, 0.1, 2e-2), "fam_wide": (3e-2, 6e-2, 6e-2, 2e-2), "hdb_16": (6e-2, 0.12, 0.1, 5e-2)}
+# 3x the values measured on the MI355X (round 4; each case prints its line): out / dx / |grad| / 1 - cos.  The four fixture cases run in the
+# zero-mean regime the reference's fixtures were written in (half of the units at the ReLU kink: a flipped mask switches an input-gradient element
+# on or off, hence dx ~ 1e-1 eight layers deep - the reference's own autocast run measures the same); the oracle-only cases in the conditioned one.
+_GALD_BARS = {"hdb": (2.8e-2, 0.3, 6e-2, 2.7e-2), "fam": (1.9e-2, 0.33, 6.2e-2, 2.2e-2), "cca": (1.5e-2, 3e-2, 6e-2, 6e-3), "lam": (1.5e-2, 6e-2, 0.1, 2e-2),
+              "cca_twice": (3e-2, 6e-2, 0.1, 2e-2), "fam_wide": (1.6e-2, 6e-2, 6e-2, 2e-2), "hdb_16": (2.5e-2, 6e-2, 6e-2, 2e-2)}
 
 
 @pytest.mark.parametrize("idx", range(7))
@@ -145,7 +147,18 @@ def test_gald_product_modules_vs_reference_golden(idx):
             dict(refm.named_parameters())["gamma"].fill_(0.7)
     mod.cuda().train()
     refm.train()
-    loss_of = lambda outs: sum(o.square().mean() + o.mean() for o in outs)
+    if shift:
+        # (behind a train-mode BatchNorm whose units are nearly all active, mean(y^2) + mean(y) is a function of the normalised tensor's first two
+        # moments only - its gradient lies in the null space of the BatchNorm backward; a fixed random projection is not)
+        R = {}
+
+        def loss_of(outs):
+            o = outs[0]
+            if "r" not in R:
+                R["r"] = torch.from_numpy(_u(prefix + ".R", tuple(o.shape)))
+            return (o * R["r"].to(o.device)).mean()
+    else:
+        loss_of = lambda outs: sum(o.square().mean() + o.mean() for o in outs)          # the fixtures' loss (make_golden.py: run())
     # oracle (fp32) and, for the printed yardstick only, the oracle under CPU autocast
     xs = [torch.from_numpy(a).requires_grad_(True) for a in inputs]
     y = refm(*xs)
@@ -247,7 +260,10 @@ def test_gald_whole_net_352_vs_reference_golden(golden_dir):
 
 
 # measured on the MI355X (round 4): worst activation / upstream gradient / |grad| / 1 - cos over the blocks of the net
-_GALD_FORCED_BARS = dict(act=4e-2, grd=1e-1, nrm=1e-1, dirn=5e-2)
+_GALD_FORCED_BARS = dict(act=2e-2, grd=9e-2, nrm=5e-3, dirn=2e-3)          # 3x measured: 6.6e-3 / 2.8e-2 / 1.4e-3 / 6.4e-4
+# the inputs of the four max pools: bf16 values tie inside a 3 x 3 / 2 x 2 window far more often than fp32 ones, the pool backward then routes the
+# gradient to another (equal) element than the fp32 oracle's - same values, another position: measured 9e-2 .. 1.1e-1 in relative L2
+_GALD_POOL_INPUTS = ("base.1", "base.4", "base.9", "base.12")
 
 
 def test_gald_teacher_forced_every_block_vs_oracle():
@@ -279,8 +295,11 @@ def test_gald_teacher_forced_every_block_vs_oracle():
     assert len(own) == len(taps) == 16 + 1 + 2 + 3 + 3 + 4 + 4 and len(gown) == len(tgrads)
     r = P.forced_report("gald 352", own, gown, pg, taps, tgrads, want_pg)
     assert not r["missing"], r["missing"][:5]
+    pool = {k: r["grd"].pop(k) for k in _GALD_POOL_INPUTS}
+    assert max(pool.values()) < 0.33, pool
     for k, bar in _GALD_FORCED_BARS.items():
-        assert r[k + "_worst"] < bar, (k, r[k + "_worst"], sorted(r[k].items(), key=lambda kv: -kv[1])[:5])
+        worst = max(r[k].values())
+        assert worst < bar, (k, worst, sorted(r[k].items(), key=lambda kv: -kv[1])[:5])
 
 
 def test_gald_trainer_refuses_out_of_range_labels(tmp_path):
@@ -289,7 +308,7 @@ def test_gald_trainer_refuses_out_of_range_labels(tmp_path):
     import logging
     from rnd_semantic_segmentation_amd.host import config as hc, gald
     cfg = hc.CfgNode(hc.default_tree())
-    cfg.merge_from_list(["OUTPUT_DIR", str(tmp_path), "SOLVER.EPOCHS", 1, "SOLVER.BASE_LR", 1e-4, "SOLVER.CHECKPOINT_PERIOD", 100])
+    cfg.merge_from_list(["OUTPUT_DIR", str(tmp_path), "MODEL.NUM_CLASSES", 19, "SOLVER.EPOCHS", 1, "SOLVER.BASE_LR", 1e-4, "SOLVER.CHECKPOINT_PERIOD", 100])
     cfg.freeze()
     x = torch.from_numpy(synth.synth_image(2, 224, 224, seed=5))
     good = torch.from_numpy(synth.synth_label(2, 224, 224, 19, seed=5))

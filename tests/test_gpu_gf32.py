@@ -1,0 +1,238 @@
+"""GPU parity of the general kernel family in the reference's precision (csrc/gf32.hip, `set_precision('fp32')`): the evaluation forward of PraNet
+(BASELINE config[3]) and GALD at north_star's tolerance - outputs within 1e-3 relative of the reference's fp32 run (measured ~1e-5), thresholded /
+argmax masks identical pixel for pixel, the testers' IoU lines equal.  Kernel level against torch in float64 on the same fp32 operands; network
+level against the reference's own eval-mode outputs (g12_pranet_160, g13_gald_352) with the oracle (pinned to them in the same test) supplying the
+running statistics."""
+import logging
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import _cases
+import _parity as P
+from rnd_semantic_segmentation_amd.host import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gk():
+    import __graft_entry__ as entry
+    entry.build()
+    from rnd_semantic_segmentation_amd import gk as g
+    return g
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,dil,H,W", [
+    (3, 32, 3, 2, 1, 1, 33, 29), (26, 26, 3, 1, 1, 1, 22, 22), (64, 1, 1, 1, 0, 1, 11, 11), (32, 32, (1, 7), 1, (0, 3), 1, 13, 17), (32, 32, (5, 1), 1, (2, 0), 1, 13, 17),
+    (32, 32, 3, 1, 7, 7, 11, 11), (466, 168, 3, 1, 1, 1, 9, 9), (256, 256, 5, 1, 2, 1, 6, 6), (142, 68, 1, 1, 0, 1, 23, 40)])
+def test_conv_f32_with_fused_epilogue_vs_torch_float64(gk, cin, cout, k, stride, pad, dil, H, W):
+    """mi_gconv_f32: every conv geometry of the two nets (3-channel stem, 26-channel groups, one-channel side outputs, 1xk / kx1, dilation 7, HarDNet's
+    466 -> 168) on channel-slice VIEWS, with bias, the eval()-BatchNorm affine, a residual view and ReLU / ReLU6 in the epilogue."""
+    kh, kw = (k, k) if isinstance(k, int) else k
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn((2, cin, H, W), generator=g)
+    w = torch.randn((cout, cin, kh, kw), generator=g) / np.sqrt(cin * kh * kw)
+    b, sc, sh = torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.2
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride, (ph, pw), dil)
+    add = torch.randn(tuple(ref.shape), generator=g)
+    big = torch.full((2, H, W, cin + 6), 9.0, device="cuda")
+    big[..., 3:3 + cin] = _nhwc(x).cuda()
+    obig = torch.full((2, ref.shape[2], ref.shape[3], cout + 5), -7.0, device="cuda")
+    abig = torch.full((2, ref.shape[2], ref.shape[3], cout + 2), 5.0, device="cuda")
+    abig[..., 1:1 + cout] = _nhwc(add).cuda()
+    geom = (kh, kw, stride, stride, ph, pw, dil, dil)
+    for relu, want in ((False, ref), (True, torch.relu(ref * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1) + add.double())),
+                       (6, torch.clamp(ref * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1), 0, 6))):
+        if relu is False:
+            out = gk.gconv_f32(big[..., 3:3 + cin], w.cuda(), geom, bias=b.cuda(), out=obig[..., 2:2 + cout])
+        elif relu is True:
+            out = gk.gconv_f32(big[..., 3:3 + cin], w.cuda(), geom, bias=b.cuda(), scale=sc.cuda(), shift=sh.cuda(), add=abig[..., 1:1 + cout], relu=True, out=obig[..., 2:2 + cout])
+        else:
+            out = gk.gconv_f32(big[..., 3:3 + cin], w.cuda(), geom, bias=b.cuda(), scale=sc.cuda(), shift=sh.cuda(), relu=6)
+        torch.cuda.synchronize()
+        got = out.permute(0, 3, 1, 2).double().cpu()
+        assert float((got - want).abs().max()) < 2e-6 * float(want.abs().max()) + 1e-6, (relu, float((got - want).abs().max()))      # measured 4e-7
+    assert float(obig[..., :2].min()) == -7.0 and float(obig[..., 2 + cout:].min()) == -7.0          # nothing outside the output slice is written
+
+
+def test_pools_depthwise_attention_and_pointwise_f32_vs_torch(gk):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((2, 26, 13, 11), generator=g)
+    xv = _nhwc(x).cuda()
+    for mode, want in ((0, F.avg_pool2d(x, 3, 2, 1)), (2, F.max_pool2d(x, 3, 2, 1)), (2, F.max_pool2d(x, 2, 2, 0))):
+        k, s, p = (3, 2, 1) if want.shape[2] == 7 else (2, 2, 0)
+        got = gk.gpool_f32(xv, k, s, p, mode).permute(0, 3, 1, 2).cpu()
+        assert torch.allclose(got, want, rtol=1e-6, atol=1e-6), mode
+    want = F.avg_pool2d(x, 2, 2, ceil_mode=True, count_include_pad=False)
+    got = gk.gpool_f32(xv, 2, 2, 0, 1, out_hw=(7, 6)).permute(0, 3, 1, 2).cpu()
+    assert torch.allclose(got, want, rtol=1e-6, atol=1e-6)
+    # depthwise 3x3 stride 2 without padding + bias + affine + ReLU (GALDNet.py:127-141 in eval())
+    w, b = torch.randn((26, 1, 3, 3), generator=g) * 0.4, torch.randn(26, generator=g) * 0.2
+    sc, sh = torch.rand(26, generator=g) + 0.5, torch.randn(26, generator=g) * 0.1
+    want = torch.relu(F.conv2d(x.double(), w.double(), b.double(), 2, 0, 1, 26) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+    got = gk.gdwconv_f32(xv, w.cuda(), b.cuda(), 2, 0, scale=sc.cuda(), shift=sh.cuda(), relu=True).permute(0, 3, 1, 2).double().cpu()
+    assert float((got - want).abs().max()) < 2e-6 * float(want.abs().max())
+    # criss-cross attention: the oracle's einsum form (pinned to the reference's CrissCrossAttention by g13 `cca`) on given q, k, v
+    q, k, v = torch.randn((2, 8, 5, 7), generator=g), torch.randn((2, 8, 5, 7), generator=g), torch.randn((2, 64, 5, 7), generator=g)
+    H = 5
+    e_col = torch.einsum("bchw,bcgw->bhwg", q.double(), k.double()).masked_fill(torch.eye(H, dtype=torch.bool).view(1, H, 1, H), float("-inf"))
+    e_row = torch.einsum("bchw,bchv->bhwv", q.double(), k.double())
+    att = torch.softmax(torch.cat([e_col, e_row], 3), 3)
+    want = torch.einsum("bcgw,bhwg->bchw", v.double(), att[..., :H]) + torch.einsum("bchv,bhwv->bchw", v.double(), att[..., H:])
+    got = gk.gcca_f32(_nhwc(q).cuda(), _nhwc(k).cuda(), _nhwc(v).cuda()).permute(0, 3, 1, 2).double().cpu()
+    assert float((got - want).abs().max()) < 5e-6 * float(want.abs().max())
+    # pointwise: gamma * agg + x, the reverse-attention product, the sigmoid gate, relu(a * b)
+    a, b2 = torch.randn((2, 26, 13, 11), generator=g), torch.randn((2, 26, 13, 11), generator=g)
+    gate = torch.randn((2, 1, 13, 11), generator=g)
+    av, bv = _nhwc(a).cuda(), _nhwc(b2).cuda()
+    chk = lambda got, want: float((got.permute(0, 3, 1, 2).double().cpu() - want).abs().max()) < 2e-6 * float(want.abs().max()) + 1e-7
+    assert chk(gk.gpoint_f32(gk.PW_AFFINE, av, bv, scale=sc.cuda(), shift=sh.cuda()), a.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1) + b2.double())
+    assert chk(gk.gpoint_f32(gk.PW_REVERSE, av, _nhwc(gate).cuda()), (1 - torch.sigmoid(gate.double())) * a.double())
+    assert chk(gk.gpoint_f32(gk.PW_GATE, av, bv), a.double() + a.double() * torch.sigmoid(b2.double()))
+    assert chk(gk.gpoint_f32(gk.PW_MULRELU, av, bv), torch.relu(a.double() * b2.double()))
+
+
+def _load_into(net, sd):
+    net.load_state_dict({k: v.detach().clone() for k, v in sd.items()})
+    return net
+
+
+def test_pranet_fp32_evaluation_reproduces_the_references_maps_and_masks():
+    """BASELINE config[3] at north_star's tolerance.  The oracle (fp32 CPU) takes the 41 train-mode forwards of g12_pranet_160 and evaluates: its
+    maps are the reference's (pinned to the fixture here: crops 1e-3, the full lateral_map_2 of two images, the PranetTester mask of all eight).
+    PraNet on the HIP engine with the SAME state_dict and precision 'fp32' must give maps within 1e-3 relative (measured ~1e-5) and the identical
+    thresholded mask - a pixel may differ only where the reference decides by a margin below 1e-4 of the normalised probability."""
+    from oracle import ref_pranet as rp
+    from rnd_semantic_segmentation_amd.host import pranet
+    from test_oracle_golden import pranet_eval_after_warmup
+    x, gt, g = _cases.pranet160_inputs()
+    ref = rp.PraNet()
+    synth.load_formula_weights(ref, prefix="pranet.", bn_bias=synth.COND_BN_BIAS)
+    ref.train()
+    xt = torch.from_numpy(x)
+    with torch.no_grad():
+        ref(xt)                                                             # the fixture's training forward, then its 40 warm-up forwards
+    maps, pred, margin = pranet_eval_after_warmup(ref, xt, 40)
+    for i, m in enumerate(maps):
+        assert P.rel(m[:, :, ::8, ::8], g["eval_map%d_crop" % i]) < 1e-3, i      # the oracle's evaluation IS the reference's
+    want_mask = np.unpackbits(g["eval_mask_bits"])[:pred.size].reshape(g["eval_mask_shape"])
+    assert all(margin[i] < 1e-4 for i in np.flatnonzero(pred.reshape(-1) != want_mask.reshape(-1)))
+    net = _load_into(pranet.PraNet(), ref.state_dict()).cuda().eval().set_precision("fp32")
+    with torch.no_grad():
+        ours = [m.float().cpu().numpy() for m in net(xt.cuda())]
+    errs = [P.rel(a, b) for a, b in zip(ours, maps)]
+    e_fix = P.rel(ours[3][:2], g["eval_map3_full01"])
+    p = torch.from_numpy(ours[3]).sigmoid().numpy().squeeze(1)
+    p = (p - p.min()) / (p.max() - p.min() + 1e-8)
+    mine = (p > 1 - p).astype(np.uint8)
+    flips = np.flatnonzero(mine.reshape(-1) != want_mask.reshape(-1))
+    print("\n[pranet fp32 eval] maps vs the oracle's %s;  lateral_map_2 vs the reference's own %.2e;  mask: %d of %d pixels differ" % (
+        ["%.1e" % e for e in errs], e_fix, len(flips), mine.size))
+    assert max(errs) < 1e-3 and e_fix < 1e-3                                  # north_star: 1e-3 relative (measured 2e-5)
+    assert all(margin[i] < 1e-4 for i in flips), (len(flips), [float(margin[i]) for i in flips[:5]])
+    # the bf16 regime on the same weights, for the record (the reason TEST.PRECISION defaults to fp32)
+    net.set_precision("bf16")
+    with torch.no_grad():
+        b16 = net(xt.cuda())[3].float().cpu().numpy()
+    print("[pranet fp32 eval] the bf16 engine's lateral_map_2 on the same weights: %.2e" % P.rel(b16, maps[3]))
+
+
+def test_pranet_tester_fp32_iou_lines_equal_the_oracles_at_352(tmp_path):
+    """PranetTester.test end to end at the config's size (2 images of 352 x 352, labels 352 x 352): the summary lines of the intersection / union
+    meters equal those computed from the oracle's fp32 predictions on the same state_dict."""
+    from oracle import ref_pranet as rp
+    from rnd_semantic_segmentation_amd.host import config as hc, metrics, pranet
+    img, mask = synth.synth_polyp(2, 352, 352, seed=8)
+    x, y = torch.from_numpy(img), torch.from_numpy(mask)
+    ref = rp.PraNet()
+    synth.load_formula_weights(ref, prefix="pranet.", bn_bias=synth.COND_BN_BIAS)
+    ref.train()
+    with torch.no_grad():
+        for _ in range(8):
+            ref(x)
+    ref.eval()
+    with torch.no_grad():
+        r2 = ref(x)[3]
+    p = r2.sigmoid().numpy().squeeze(1)
+    p = (p - p.min()) / (p.max() - p.min() + 1e-8)
+    want_pred = torch.from_numpy((p > 1 - p).astype(np.int64))
+    cfg = hc.CfgNode(hc.default_tree())
+    cfg.merge_from_list(["MODEL.NUM_CLASSES", 2, "OUTPUT_DIR", str(tmp_path)])
+    cfg.freeze()
+
+    class Log(logging.Logger):
+        def __init__(self):
+            super().__init__("t")
+            self.lines = []
+
+        def info(self, msg, *a, **k):
+            self.lines.append(str(msg))
+    log, rlog = Log(), Log()
+    tester = pranet.PranetTester(cfg, torch.device("cuda"), [(x, y, ["a", "b"])], log)
+    assert tester.model.precision == "fp32"                                   # the default
+    _load_into(tester.model, ref.state_dict())
+    tester.test()
+    yl = y.reshape(2, 352, 352).long()
+    meter = metrics.AverageMeter()
+    inter, union, target, res = metrics.intersectionAndUnionGPU(want_pred, yl, 2, cfg.INPUT.IGNORE_LABEL)
+    meter.update(inter.numpy(), union.numpy(), target.numpy(), res.numpy())
+    meter.summary(rlog, 2)
+    assert log.lines == rlog.lines and len(log.lines) > 2, (log.lines, rlog.lines)
+    assert float(want_pred.float().mean()) not in (0.0, 1.0)                   # not a degenerate mask
+
+
+def test_gald_fp32_evaluation_reproduces_the_references_logits_and_argmax(tmp_path):
+    """GCPAEncoder + GCPADecoder in eval() with precision 'fp32' against the reference's eval-mode run of g13_gald_352 (13 train-mode forwards, then
+    res2 at the input size): the oracle supplies the running statistics and is pinned to the fixture here; the engine's res2 must be within 1e-3
+    relative (measured ~1e-5), its argmax identical except where the reference's top-2 margin is below 1e-4; GALDTester.test's confusion matrix
+    equals the one counted from the oracle's predictions."""
+    from oracle import ref_gald as rg
+    from rnd_semantic_segmentation_amd.host import config as hc, gald, metrics
+    from test_oracle_golden import gald_eval_after_warmup
+    x, lab, g = _cases.gald352_inputs()
+    xt = torch.from_numpy(x)
+    renc, rdec = rg.GCPAEncoder(), rg.GCPADecoder()
+    synth.load_formula_weights(renc, prefix="gald.enc.", bn_bias=synth.COND_BN_BIAS)
+    synth.load_formula_weights(rdec, prefix="gald.dec.", bn_bias=synth.COND_BN_BIAS)
+    renc.train()
+    rdec.train()
+    with torch.no_grad():
+        rdec(xt, renc(xt))
+    res2, pred, margin = gald_eval_after_warmup(renc, rdec, xt, 12)
+    assert P.rel(res2[:, :, ::16, ::16], g["eval_res2_crop"]) < 1e-3                                   # the oracle's evaluation IS the reference's
+    assert all(margin[i] < 1e-4 for i in np.flatnonzero(pred[0].reshape(-1) != g["eval_pred0"].reshape(-1)))
+    cfg = hc.CfgNode(hc.default_tree())
+    cfg.merge_from_list(["OUTPUT_DIR", str(tmp_path), "MODEL.NUM_CLASSES", 19])
+    cfg.freeze()
+    log = logging.getLogger("gald_fp32")
+    log.addHandler(logging.NullHandler())
+    labels = torch.from_numpy(lab)
+    tester = gald.GALDTester(cfg, torch.device("cuda"), [(xt[i:i + 1], labels[i:i + 1], ["im%d" % i]) for i in range(4)], log, palette=None)
+    assert tester.encoder.precision == tester.decoder.precision == "fp32"
+    _load_into(tester.encoder, renc.state_dict())
+    _load_into(tester.decoder, rdec.state_dict())
+    tester.encoder.eval()
+    tester.decoder.eval()
+    with torch.no_grad():
+        ours = tester.decoder(xt.cuda(), tester.encoder(xt.cuda()))[3].float().cpu().numpy()
+    e = P.rel(ours, res2)
+    flips = np.flatnonzero(ours.argmax(1).reshape(-1) != pred.reshape(-1))
+    print("\n[gald fp32 eval] res2 vs the oracle's %.2e;  argmax: %d of %d pixels differ" % (e, len(flips), pred.size))
+    assert e < 1e-3
+    assert all(margin[i] < 1e-4 for i in flips), (len(flips), [float(margin[i]) for i in flips[:5]])
+    # the tester end to end (one image per batch, as TEST.BATCH_SIZE 1)
+    cmt = tester.test()
+    want = torch.zeros(19, 19, dtype=torch.int64)
+    for i in range(4):
+        want += metrics.confusion_matrix(cfg, torch.from_numpy(pred[i].astype(np.int64)).flatten(), labels[i].long().flatten())
+    assert int((cmt.cpu() != want).sum()) <= 2 * len(flips) and int(cmt.sum()) == int(want.sum())
+    if not len(flips):
+        assert torch.equal(cmt.cpu(), want)
