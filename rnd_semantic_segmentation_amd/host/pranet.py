@@ -730,6 +730,7 @@ class _Engine(nn.Module):
         return run, ins, outs
 
     def forward(self, *xs):
+        self._grad_mode = torch.is_grad_enabled()          # (inside Function.forward grad mode is always off: ask here whether a tape is wanted at all)
         out = _EngineFn.apply(self, len(xs), *xs, *[p for _, p in self.engine_parameters()])
         return out[0] if len(out) == 1 else out
 
@@ -742,7 +743,7 @@ class _EngineFn(torch.autograd.Function):
     def forward(ctx, net, n_in, *args):
         xs = args[:n_in]
         in_needs = ctx.needs_input_grad[2:2 + n_in]
-        rec = any(ctx.needs_input_grad[2:])
+        rec = any(ctx.needs_input_grad[2:]) and getattr(net, "_grad_mode", True)
         run, ins, outs = net._run(xs, rec, in_needs)
         ctx.run, ctx.ins, ctx.outs, ctx.n_in, ctx.in_dtypes = run, ins, outs, n_in, [x.dtype for x in xs]
         return tuple(o.t.permute(0, 3, 1, 2) if o.t.dim() == 4 else o.t for o in outs)          # NCHW-shaped views of NHWC memory (or scalars: losses)
