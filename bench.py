@@ -121,11 +121,12 @@ def aux_workload(args, device):
             opt.step()
             return ls[3]
         graphed = None
-        if os.environ.get("MI_GRAPH", "1") == "1":        # the trainer's MI_GRAPH mode: the whole step as one HIP graph (bit-equal to eager: tests/test_gpu_pranet.py)
+        if pranet.graph_mode_default():                   # PraNetTrainer's default: the whole optimizer step as one HIP graph (bit-equal to eager: tests/test_gpu_pranet.py); MI_GRAPH=0: eager
             graphed = pranet.GraphedStep(net, opt, x, gt)
         runner = (lambda: graphed()[3]) if graphed else step
-        metric = "train images/sec at %dx%d bf16 (PraNet Res2Net-50, BASELINE config[3])" % (H, W)
-        workload = "configs/pranet_src_polyp.yaml: PraNet, one optimizer step (the rate-1 pass of the three-scale loop), B=%d %dx%d" % (B, H, W)
+        metric = "train images/sec at %dx%d bf16 (PraNet Res2Net-50, BASELINE config[3]; one step = ONE of the three passes of a reference iteration)" % (H, W)
+        workload = ("configs/pranet_src_polyp.yaml: PraNet, one optimizer step = forward, four structure losses, backward, clamped Adam on B=%d %dx%d - the "
+                    "reference's iteration (pranet_trainer.py:44-61) runs three such steps per batch (its three 'scales' all resize to trainsize)" % (B, H, W))
     else:
         B, H, W = args.batch or 6, 720, 1280
         enc, dec = gald.GCPAEncoder().to(device).train(), gald.GCPADecoder().to(device).train()
@@ -160,6 +161,16 @@ def aux_workload(args, device):
     out = {"metric": metric, "value": round(B / dt, 2), "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
            "data": "synthetic, random-init weights", "config": {"workload": workload, "hip_graph": bool(graphed)}, "loss": round(float(loss), 4)}
+    if graphed:                                           # the same step eagerly (what MI_GRAPH=0 runs): both numbers in one line
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(max(3, args.steps // 2)):
+            step()
+        torch.cuda.synchronize()
+        de = (time.perf_counter() - t0) / max(3, args.steps // 2)
+        out["eager"] = {"value": round(B / de, 2), "ms_per_step": round(de * 1e3, 3)}
     if not args.no_kernel_events:
         note("instrumented steps (eager, HIP events per launch)")
         events = []
@@ -189,12 +200,37 @@ def aux_workload(args, device):
                       file=sys.stderr)
         dom = max(by, key=lambda k: by[k][0])
         tsec, fl, n = by[dom]
-        out["roofline"] = {"kernel": dom, "bound": "mfma" if fl else "hbm", "achieved": round(fl / tsec / 1e12, 2) if fl else None, "peak": PEAK_BF16_TFLOPS if fl else PEAK_HBM_TBS,
-                           "unit": "TFLOP/s" if fl else "TB/s", "frac": round(fl / tsec / 1e12 / PEAK_BF16_TFLOPS, 4) if fl else None, "traffic": None,
-                           "launches_per_step": n // INST, "avg_launch_us": round(1e6 * tsec / n, 2), "ms_per_step_in_kernel": round(1e3 * tsec / INST, 3),
-                           "note": "dominant = largest total launch time over %d eager instrumented steps after the timed region; algorithmic FLOPs = 2 * pixels * "
-                                   "C_out * C_in * taps per launch (SURVEY 8d); the convs of this net are short contractions (26 .. 512 channels) at 22 .. 176 "
-                                   "pixels a side: launch-latency and HBM-bound, far from the MFMA peak" % INST}
+        # counters of the dominant kernel class from the separate rocprofv3 --pmc passes of tools/profile_aux.sh (profiles/pmc_<workload>.json,
+        # written by profiles/make_pmc_any.py: FETCH_SIZE x 2 x 1024, WRITE_SIZE x 1024): they say which resource the class is nearer to
+        pmc_class = {"gconv": "gconv_kernel", "gconv_wgrad": "gwgrad_kernel", "gbn_bwd_sums": "gcolsum_partial_kernel", "gbn_bwd_apply": "gbn_bwd_apply_kernel",
+                     "gbn_apply": "gbn_apply_kernel", "gbinary": "gbinary_kernel", "gbn_finalize": "gbn_finalize_kernel"}.get(dom, dom)
+        traffic = hbm_frac = busy = src = whole = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_%s.json" % args.workload)))
+            e = pmc[pmc_class]
+            traffic, hbm_frac, busy = e.get("hbm_bytes_per_launch"), e.get("hbm_frac_of_peak"), e.get("mfma_busy_frac")
+            src = {"file": "profiles/pmc_%s.json" % args.workload, "class": pmc_class, "profiled_commit": pmc["_meta"].get("commit"), "round": pmc["_meta"].get("round"),
+                   "avg_launch_us_under_counters": e.get("avg_launch_us"), "l2_hit_frac": e.get("l2_hit_frac")}
+            whole = {k: pmc["_meta"].get(k) for k in ("kernel_ms_per_step", "launches_per_step", "hbm_read_gb_per_step", "hbm_write_gb_per_step", "hbm_tb_s_over_kernel_time")}
+        except (OSError, KeyError, ValueError):
+            pass
+        mfma_frac = fl / tsec / 1e12 / PEAK_BF16_TFLOPS if fl else 0.0
+        bound = "hbm" if (hbm_frac is not None and hbm_frac > max(mfma_frac, busy or 0.0)) or not fl else "mfma"
+        alg_tbs = None
+        if bound == "hbm":
+            out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(hbm_frac * PEAK_HBM_TBS, 3) if hbm_frac is not None else None, "peak": PEAK_HBM_TBS, "unit": "TB/s",
+                               "frac": hbm_frac, "traffic": traffic}
+        else:
+            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(fl / tsec / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(mfma_frac, 4),
+                               "traffic": traffic}
+        out["roofline"].update({"mfma_frac_algorithmic": round(mfma_frac, 4) if fl else None, "mfma_busy_frac_counters": busy, "hbm_frac_counters": hbm_frac, "traffic_source": src,
+                                "launches_per_step": n // INST, "avg_launch_us": round(1e6 * tsec / n, 2), "ms_per_step_in_kernel": round(1e3 * tsec / INST, 3),
+                                "note": "dominant = largest total launch time over %d eager instrumented steps after the timed region; algorithmic FLOPs = 2 * pixels * "
+                                        "C_out * C_in * taps per launch (SURVEY 8d); `bound` = the resource whose counter fraction is larger for that kernel class "
+                                        "(HBM bytes per launch / launch time against 8 TB/s, vs MFMA-busy cycles); with both fractions low the class is bound by "
+                                        "neither: short contractions (26 .. 512 channels) whose K steps each cost one memory round trip" % INST})
+        if whole:
+            out["step_counters"] = whole
         out["whole_step_mfma_frac"] = round(conv_fl / INST / dt / 1e12 / PEAK_BF16_TFLOPS, 4)
         out["conv_gflop_per_step"] = round(conv_fl / INST / 1e9, 1)
         out["kernels"] = {k: {"ms_per_step": round(1e3 * v[0] / INST, 3), "launches_per_step": v[2] // INST, "share": round(v[0] / tot, 3),

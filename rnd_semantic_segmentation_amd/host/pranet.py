@@ -984,6 +984,12 @@ class GraphedStep:
         return self.losses
 
 
+def graph_mode_default():
+    """PraNetTrainer replays its optimizer step as a HIP graph unless MI_GRAPH=0: ~1 300 launches of 3 - 40 us per step leave the host 15 - 20 % behind the
+    GPU when enqueued one by one (bench.py prints both numbers); the replay is bit-equal to eager (tests/test_gpu_pranet.py)."""
+    return os.environ.get("MI_GRAPH", "1") != "0"
+
+
 def warmup_cosine_lr(base_lr, steps, multiplier=8.0, warm=5, t_max=100):
     """Learning rate after `steps` calls of scheduler.step() in pranet_trainer.py:97-104: GradualWarmupScheduler(multiplier=8, total_epoch=5)
     (core/utils/adapt_lr.py:19-45) climbs linearly from base_lr to 8 * base_lr over 5 epochs, then hands over to CosineAnnealingLR(T_max=100,
@@ -1046,8 +1052,8 @@ class PraNetTrainer(BaseTrainer):
 
     def train_step(self, images, gts):
         """One optimizer step (pranet_trainer.py:39-60).  Returns the four losses (lateral 5, 4, 3, 2) as device scalars.
-        MI_GRAPH=1: after three eager steps the step is captured as a HIP graph and replayed while the input shape stays the same."""
-        if os.environ.get("MI_GRAPH") == "1":
+        After three eager steps the step is captured as a HIP graph and replayed while the input shape stays the same (MI_GRAPH=0: always eager)."""
+        if graph_mode_default():
             st = self.__dict__.setdefault("_graph", {"eager": 0, "step": None, "shape": None})
             if st["step"] is not None and st["shape"] == (tuple(images.shape), tuple(gts.shape)):
                 return [l.clone() for l in st["step"](images, gts)]
