@@ -334,8 +334,8 @@ int mi_gconv(const void* a, long lda, const void* wp, void* out, long ldo, int B
 /* dw[o][i][ky][kx] (+)= sum_m dy[m][o] * x[src(m,ky,kx)][i], fp32 OIHW; split-K slabs summed in a fixed order. */
 size_t mi_gconv_wgrad_workspace(int B, int Ho, int Wo, int O, int I, int kh, int kw);
 int mi_gconv_wgrad(const void* dy, long ldy, const void* x, long ldx, float* dw, int B, int Ha, int Wa, int I, int Ho, int Wo, int O,
-                   int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw_, int accumulate, void* workspace, size_t workspace_bytes,
-                   void* stream);
+                   int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw_, int accumulate, void* workspace, size_t workspace_bytes, unsigned* tickets, int n_tickets,
+                   void* stream);      /* tickets: NULL, or n_tickets zeroed words (left zero): with few K splits the slabs are then added inside the first launch (same bits) */
 /* nn.BatchNorm2d in train() from the conv's tile statistics: mean, invstd = rsqrt(biased var + eps), scale = gamma * invstd,
  * shift = beta - mean * scale, and the running-statistics update (momentum; unbiased variance), all per channel.  count = pixels. */
 int mi_gbn_finalize(const float* partials, int tiles, int C, long count, const float* gamma, const float* beta, float* running_mean, float* running_var,
@@ -351,7 +351,8 @@ int mi_gbn_apply(const void* y, long ldy, const float* scale, const float* shift
  * bit 1 = the mask is a ReLU6 output (the gradient passes where 0 < mask < 6).  The same flags in mi_gbn_bwd_apply. */
 size_t mi_gcolsum_workspace(long M, int C);
 int mi_gbn_bwd_sums(const void* g, long ldg, int g_f32, const void* y, long ldy, const void* mask, long ldm, int mask_f32, const float* mean,
-                    const float* invstd, long M, int C, float* dbeta, float* dgamma, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+                    const float* invstd, long M, int C, float* dbeta, float* dgamma, int accumulate, void* workspace, size_t workspace_bytes, unsigned* ticket,
+                    void* stream);      /* ticket: NULL, or one zeroed word (left zero): small reductions then finish inside the first launch (same bits) */
 /* dy = gamma * invstd * (g' - dbeta * inv_count - xhat * dgamma * inv_count) */
 int mi_gbn_bwd_apply(const void* g, long ldg, int g_f32, const void* y, long ldy, const void* mask, long ldm, int mask_f32, const float* mean,
                      const float* invstd, const float* gamma, const float* dbeta, const float* dgamma, float inv_count, void* dy, long lddy, long M, int C,
@@ -405,6 +406,15 @@ int mi_gcca_bwd(const void* q, long ldq, const void* k, long ldk, const void* v,
 /* Sigmoid gate of the local attention module (GALDNet.py:150-157).  dout == NULL: o1 = x + x * sigmoid(g).  Otherwise the backward:
  * o1 = d loss / d x = dout * (1 + s), o2 = d loss / d g = dout * x * s * (1 - s). */
 int mi_ggate(const void* x, long ldx, const void* g, long ldg, const void* dout, long lddo, void* o1, long ld1, void* o2, long ld2, long M, int C, void* stream);
+
+/* mi_gconv (forward, bf16 out, tile statistics) with BatchNorm2d's finalize done by the launch's last workgroup instead of a second launch
+ * (mi_gbn_finalize's arithmetic and results: mean, invstd, scale, shift into fin_out[4][N], running statistics updated), for convs of at most
+ * mi_gconv_bn_inlaunch_max_pixels() output pixels - the small maps of the deep stages, where the extra launch cost as much as the conv.
+ * tickets: one zeroed 32-bit word per 32 output channels, owned by the caller, left zero by the launch (reusable on the same stream). */
+int mi_gconv_bn_inlaunch_max_pixels(void);
+int mi_gconv_bn(const void* a, long lda, const void* wp, void* out, long ldo, int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N,
+                int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, const float* bias, float* stats, unsigned* tickets, const float* gamma,
+                const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* fin_out, void* stream);
 
 /* ---- the general family in the reference's precision (csrc/gf32.hip): evaluation forward of PraNet / GALD in fp32 ------------------------
  * Replaces the eval()-mode forward of core/testers/pranet_tester.py:36 (`self.model(x)`) and core/testers/gald_tester.py:56-57

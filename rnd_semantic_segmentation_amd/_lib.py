@@ -80,12 +80,12 @@ SIGNATURES = {
     "mi_gconv_stats_elems": (Z, [I] * 4),
     "mi_gconv": (I, [P, L, P, P, L] + [I] * 16 + [P, P, I, P]),
     "mi_gconv_wgrad_workspace": (Z, [I] * 7),
-    "mi_gconv_wgrad": (I, [P, L, P, L, P] + [I] * 16 + [P, Z, P]),
+    "mi_gconv_wgrad": (I, [P, L, P, L, P] + [I] * 16 + [P, Z, P, I, P]),
     "mi_gbn_finalize": (I, [P, I, I, L, P, P, P, P, F, F, P, P, P, P, P]),
     "mi_gbn_fold": (I, [P, P, P, P, F, P, P, I, P]),
     "mi_gbn_apply": (I, [P, L, P, P, P, L, P, L, I, L, I, I, P]),
     "mi_gcolsum_workspace": (Z, [L, I]),
-    "mi_gbn_bwd_sums": (I, [P, L, I, P, L, P, L, I, P, P, L, I, P, P, I, P, Z, P]),
+    "mi_gbn_bwd_sums": (I, [P, L, I, P, L, P, L, I, P, P, L, I, P, P, I, P, Z, P, P]),
     "mi_gbn_bwd_apply": (I, [P, L, I, P, L, P, L, I, P, P, P, P, P, F, P, L, L, I, P]),
     "mi_gbinary": (I, [I, I, P, L, P, L, P, L, L, I, P]),
     "mi_gavgpool": (I, [P, L, P, L] + [I] * 11 + [P]),
@@ -103,6 +103,8 @@ SIGNATURES = {
     "mi_gcca_fwd": (I, [P, L, P, L, P, L, P, P, L] + [I] * 5 + [P]),
     "mi_gcca_bwd": (I, [P, L, P, L, P, L, P, P, L, P, P, L, P, L, P, L] + [I] * 5 + [P]),
     "mi_ggate": (I, [P, L, P, L, P, L, P, L, P, L, L, I, P]),
+    "mi_gconv_bn_inlaunch_max_pixels": (I, []),
+    "mi_gconv_bn": (I, [P, L, P, P, L] + [I] * 15 + [P, P, P, P, P, P, P, F, F, P, P]),
     "mi_gconv_f32": (I, [P, L, P, P, P, P, P, L, I, P, L] + [I] * 15 + [P]),
     "mi_gpool_f32": (I, [P, L, P, L] + [I] * 10 + [P]),
     "mi_gdwconv_f32": (I, [P, L, P, P, P, P, I, P, L] + [I] * 8 + [P]),

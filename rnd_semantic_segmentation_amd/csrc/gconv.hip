@@ -37,6 +37,15 @@ struct GConvP {
     int M, N, Ca, Cpad, Npad, T;
     int Ha, Wa, Ho, Wo;
     int kw, sh, sw, ph, pw, dh, dw, mode, nchunks;
+    // in-launch BatchNorm finalize (fin_out != null; the launch has at most MI_INLAUNCH_MAX_PARTS row tiles): the arguments of mi_gbn_finalize
+    unsigned* fin_ticket;      // one zeroed word per column tile
+    float* fin_out;            // [4][N]: mean, invstd, scale, shift
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    double count;
+    float momentum, eps;
 };
 
 __device__ __attribute__((aligned(256))) uint32_t g_gzero[64];        // source of every padded / out-of-range access (zero-initialised)
@@ -313,8 +322,49 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
                     s2 += red[(g * 2 + 1) * BN + tid];
                 }
                 float* st = p.stats + (long)blockIdx.x * 2 * p.N;
-                st[n0 + tid] = s1;
-                st[p.N + n0 + tid] = s2;
+                if (p.fin_out) {                       // handed to the launch's last workgroup: write-through
+                    mi_st_sc1(st + n0 + tid, s1);
+                    mi_st_sc1(st + p.N + n0 + tid, s2);
+                } else {
+                    st[n0 + tid] = s1;
+                    st[p.N + n0 + tid] = s2;
+                }
+            }
+            if (p.fin_out) {
+                // The column tile's last workgroup turns the row tiles' sums into mean / invstd / folded affine and updates the running statistics:
+                // mi_gbn_finalize's arithmetic in its order (32 lanes take the tiles t = lane, lane + 32, ..., the lanes are added in order, double),
+                // one thread per channel - the same bits as the separate launch, which these small convs no longer pay (6 us + a launch boundary each).
+                if (mi_last_arriver(p.fin_ticket + blockIdx.y, gridDim.x, reinterpret_cast<int*>(smem))) {
+                    const int c = n0 + tid;
+                    if (tid < BN && c < p.N) {
+                        const int tiles = gridDim.x;
+                        double s1 = 0.0, s2 = 0.0;
+                        for (int ry = 0; ry < 32 && ry < tiles; ++ry) {
+                            double a = 0.0, b = 0.0;
+                            for (int t = ry; t < tiles; t += 32) {
+                                a += (double)mi_ld_sc1(p.stats + (long)t * 2 * p.N + c);
+                                b += (double)mi_ld_sc1(p.stats + (long)t * 2 * p.N + p.N + c);
+                            }
+                            s1 += a;
+                            s2 += b;
+                        }
+                        const double mean = s1 / p.count;
+                        double var = s2 / p.count - mean * mean;
+                        if (var < 0.0) var = 0.0;
+                        const float invstd = (float)(1.0 / sqrt(var + (double)p.eps));
+                        const float g = p.gamma ? p.gamma[c] : 1.f, b = p.beta ? p.beta[c] : 0.f;
+                        const float sc = g * invstd;
+                        p.fin_out[c] = (float)mean;
+                        p.fin_out[p.N + c] = invstd;
+                        p.fin_out[2 * p.N + c] = sc;
+                        p.fin_out[3 * p.N + c] = b - (float)mean * sc;
+                        if (p.running_mean) {
+                            p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * (float)mean;
+                            const double unbiased = p.count > 1.0 ? var * p.count / (p.count - 1.0) : var;
+                            p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)unbiased;
+                        }
+                    }
+                }
             }
         }
     }
@@ -380,7 +430,11 @@ struct GWgP {
     int Ho, Wo, Ha, Wa;
     int kw, sh, sw, ph, pw, dh, dw;
     int S, rows_per_split, o_tiles, i_tiles;
+    unsigned* ticket;      // in-launch reduction (S <= GW_INLAUNCH_S): one zeroed word per (tap, output tile); else null
+    float* dwout;
+    int accumulate;
 };
+constexpr int GW_INLAUNCH_S = 16;      // K splits the last workgroup of a tile adds itself (64 KB of slabs at most); more: the reducer launch
 
 template <int VEC>
 __device__ __forceinline__ bf16x8 gload8(const __bf16* src, int c0, int C, bool ok) {
@@ -524,7 +578,48 @@ __global__ __launch_bounds__(256, 4) void gwgrad_kernel(GWgP p) {       // four 
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const int i = i0 + wi * 32 + a * 16 + fq * 4;
-            if (i < Ip) *reinterpret_cast<f32x4*>(slab + (long)o * Ip + i) = acc[a][b];
+            if (i < Ip) {
+                if (p.ticket) {                    // handed to the tile's last workgroup: write-through
+                    mi_st2_sc1(slab + (long)o * Ip + i, acc[a][b][0], acc[a][b][1]);
+                    mi_st2_sc1(slab + (long)o * Ip + i + 2, acc[a][b][2], acc[a][b][3]);
+                } else {
+                    *reinterpret_cast<f32x4*>(slab + (long)o * Ip + i) = acc[a][b];
+                }
+            }
+        }
+    }
+    if (p.ticket) {
+        // few K splits: the (tap, tile)'s last workgroup adds the slabs itself - gwgrad_reduce_kernel's arithmetic in its order (lane l of 8 adds the
+        // splits l, l + 8, ... ascending, the eight sums are combined as the butterfly does: ((0+1)+(2+3))+((4+5)+(6+7))) - the same bits, one launch
+        if (mi_last_arriver(p.ticket + (long)t * tiles + tile, p.S, reinterpret_cast<int*>(smem))) {
+            const long sstride = (long)p.T * p.O * Ip;
+            const float* base = p.slab + (long)t * p.O * Ip;
+            for (int e = tid; e < WTO * (WTI / 2); e += 256) {
+                const int ol = e / (WTI / 2), ip = (e - ol * (WTI / 2)) * 2;
+                const int o = o0 + ol, i = i0 + ip;
+                if (o >= p.O || i >= Ip) continue;
+                float v0[8], v1[8];
+#pragma unroll
+                for (int l = 0; l < 8; ++l) {
+                    v0[l] = v1[l] = 0.f;
+                    for (int sp = l; sp < p.S; sp += 8) {
+                        float x0, x1;
+                        mi_ld2_sc1(base + sp * sstride + (long)o * Ip + i, x0, x1);
+                        v0[l] += x0;
+                        v1[l] += x1;
+                    }
+                }
+                const float r0 = ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v0[4] + v0[5]) + (v0[6] + v0[7]));
+                const float r1 = ((v1[0] + v1[1]) + (v1[2] + v1[3])) + ((v1[4] + v1[5]) + (v1[6] + v1[7]));
+                if (i < p.I) {
+                    float* d = p.dwout + ((long)o * p.I + i) * p.T + t;
+                    *d = p.accumulate ? *d + r0 : r0;
+                }
+                if (i + 1 < p.I) {
+                    float* d = p.dwout + ((long)o * p.I + i + 1) * p.T + t;
+                    *d = p.accumulate ? *d + r1 : r1;
+                }
+            }
         }
     }
 }
@@ -621,9 +716,44 @@ int mi_gconv_pack_multi(const float* wflat, void* wp_bf16, void* wpt_bf16, const
     return MI_OK;
 }
 
+namespace {
+struct GFin {
+    unsigned* ticket;
+    float* out;
+    const float* gamma;
+    const float* beta;
+    float* rm;
+    float* rv;
+    double count;
+    float momentum, eps;
+};
+}
+static int gconv_impl(const void* a, long lda, const void* wp, void* out, long ldo, int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N,
+                      int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int mode, const float* bias, float* stats, int out_f32,
+                      void* stream, const GFin* fin);
+
 int mi_gconv(const void* a, long lda, const void* wp, void* out, long ldo, int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N,
              int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int mode, const float* bias, float* stats, int out_f32,
              void* stream) {
+    return gconv_impl(a, lda, wp, out, ldo, B, Ha, Wa, Ca, Ho, Wo, N, kh, kw, sh, sw, ph, pw, dh, dw, mode, bias, stats, out_f32, stream, nullptr);
+}
+
+int mi_gconv_bn_inlaunch_max_pixels(void) { return MI_INLAUNCH_MAX_PARTS * GBM; }
+
+int mi_gconv_bn(const void* a, long lda, const void* wp, void* out, long ldo, int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N,
+                int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, const float* bias, float* stats, unsigned* tickets, const float* gamma,
+                const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* fin_out, void* stream) {
+    MI_REQUIRE(stats && tickets && fin_out, "mi_gconv_bn: null operand");
+    MI_REQUIRE((long)B * Ho * Wo <= (long)MI_INLAUNCH_MAX_PARTS * GBM, "mi_gconv_bn: %ld pixels are more than %d row tiles - use mi_gconv + mi_gbn_finalize",
+               (long)B * Ho * Wo, MI_INLAUNCH_MAX_PARTS);
+    MI_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "mi_gconv_bn: running_mean and running_var come together");
+    GFin fin{tickets, fin_out, gamma, beta, running_mean, running_var, (double)((long)B * Ho * Wo), momentum, eps};
+    return gconv_impl(a, lda, wp, out, ldo, B, Ha, Wa, Ca, Ho, Wo, N, kh, kw, sh, sw, ph, pw, dh, dw, MI_GATHER_FWD, bias, stats, 0, stream, &fin);
+}
+
+static int gconv_impl(const void* a, long lda, const void* wp, void* out, long ldo, int B, int Ha, int Wa, int Ca, int Ho, int Wo, int N,
+                      int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int mode, const float* bias, float* stats, int out_f32,
+                      void* stream, const GFin* fin) {
     MI_REQUIRE(a && wp && out, "mi_gconv: null operand");
     MI_REQUIRE(B > 0 && Ha > 0 && Wa > 0 && Ho > 0 && Wo > 0 && Ca > 0 && N > 0, "mi_gconv: empty shape");
     MI_REQUIRE(kh > 0 && kw > 0 && sh > 0 && sw > 0 && dh > 0 && dw > 0 && ph >= 0 && pw >= 0, "mi_gconv: bad conv geometry");
@@ -657,6 +787,15 @@ int mi_gconv(const void* a, long lda, const void* wp, void* out, long ldo, int B
     p.kw = kw; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.dh = dh; p.dw = dw;
     p.mode = mode;
     p.nchunks = p.Cpad / 32;
+    p.fin_ticket = fin ? fin->ticket : nullptr;
+    p.fin_out = fin ? fin->out : nullptr;
+    p.gamma = fin ? fin->gamma : nullptr;
+    p.beta = fin ? fin->beta : nullptr;
+    p.running_mean = fin ? fin->rm : nullptr;
+    p.running_var = fin ? fin->rv : nullptr;
+    p.count = fin ? fin->count : 0.0;
+    p.momentum = fin ? fin->momentum : 0.f;
+    p.eps = fin ? fin->eps : 0.f;
     const int avec = view_vec(a, lda, Ca);
     int ovec = 1;
     if (!out_f32) ovec = view_vec(out, ldo, N, false);
@@ -686,7 +825,7 @@ size_t mi_gconv_wgrad_workspace(int B, int Ho, int Wo, int O, int I, int kh, int
 
 int mi_gconv_wgrad(const void* dy, long ldy, const void* x, long ldx, float* dw, int B, int Ha, int Wa, int I, int Ho, int Wo, int O,
                    int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw_, int accumulate, void* workspace, size_t workspace_bytes,
-                   void* stream) {
+                   unsigned* tickets, int n_tickets, void* stream) {
     MI_REQUIRE(dy && x && dw && workspace, "mi_gconv_wgrad: null operand");
     MI_REQUIRE(B > 0 && Ha > 0 && Wa > 0 && Ho > 0 && Wo > 0 && I > 0 && O > 0, "mi_gconv_wgrad: empty shape");
     MI_REQUIRE(ldy >= O && ldx >= I, "mi_gconv_wgrad: a view's row stride is smaller than its channel count");
@@ -710,6 +849,11 @@ int mi_gconv_wgrad(const void* dy, long ldy, const void* x, long ldx, float* dw,
     if (workspace_bytes < need) return mi_set_error(MI_ENOMEM, "mi_gconv_wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
     hipStream_t s = (hipStream_t)stream;
     const int yv = view_vec(dy, ldy, O), xv = view_vec(x, ldx, I);
+    // few K splits: the slabs are added by the last workgroup of each (tap, tile) inside this launch (needs one zeroed ticket word per (tap, tile))
+    const bool inlaunch = tickets && p.S <= GW_INLAUNCH_S && p.o_tiles * p.i_tiles * p.T <= n_tickets;
+    p.ticket = inlaunch ? tickets : nullptr;
+    p.dwout = dw;
+    p.accumulate = accumulate;
     const dim3 grid(p.o_tiles * p.i_tiles * p.T * p.S);
 #define GW(YV, XV) hipLaunchKernelGGL((gwgrad_kernel<YV, XV>), grid, dim3(256), 0, s, p)
     if (yv == 8 && xv == 8) GW(8, 8);
@@ -723,6 +867,7 @@ int mi_gconv_wgrad(const void* dy, long ldy, const void* x, long ldx, float* dw,
     else GW(1, 1);
 #undef GW
     MI_CHECK_LAUNCH("gwgrad_kernel");
+    if (inlaunch) return MI_OK;
     const long n = (long)O * I * p.T;
     const int blocks = (int)((n + 31) / 32 < 4096 ? (n + 31) / 32 : 4096);          // 32 output elements (8 lanes each) per block
     hipLaunchKernelGGL(gwgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slab, dw, O, I, p.T, p.S, accumulate);

@@ -106,3 +106,43 @@ __device__ __forceinline__ int mi_xcd_remap(int bid, int nwg) {
 }
 
 __device__ __forceinline__ float mi_bf16_to_f32(__bf16 v) { return (float)v; }
+
+// ---- in-launch second-level reductions (the last-arriving workgroup of a launch combines the other workgroups' small partial results) ----
+// The sc1 form of the split-K recipe of cdna_hip_programming.md section 5 / section 6 Guideline 16: the XCDs' L2s are not coherent with each
+// other, so every partial value is stored WRITE-THROUGH (agent-scope relaxed atomic store = global_store ... sc1: no release fence, which would
+// write back every dirty line of the XCD's L2 - the launch's own output tiles), every storing wave drains its stores, ONE lane draws a ticket
+// with an agent-scope fetch_add, and the workgroup that draws the last ticket reads every partial value with sc1 loads (which bypass its L1).
+// The ticket word must be zero before the first launch (the host allocates it zeroed); the last arriver resets it, so the buffer is reusable by
+// the next launch on the same stream and under HIP-graph replay.  Only worth it while the partials per reducer are a few tens of KB: the
+// callers fall back to a second launch above that.
+typedef __attribute__((address_space(1))) unsigned mi_gu32;
+typedef __attribute__((address_space(1))) unsigned long long mi_gu64;
+__device__ __forceinline__ void mi_st_sc1(float* p, float v) {
+    __hip_atomic_store((mi_gu32*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float mi_ld_sc1(const float* p) {
+    return __uint_as_float(__hip_atomic_load((mi_gu32*)const_cast<float*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void mi_st2_sc1(float* p, float a, float b) {          // p 8-byte aligned
+    __hip_atomic_store((mi_gu64*)p, ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void mi_ld2_sc1(const float* p, float& a, float& b) {
+    const unsigned long long x = __hip_atomic_load((mi_gu64*)const_cast<float*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a = __uint_as_float((unsigned)x);
+    b = __uint_as_float((unsigned)(x >> 32));
+}
+// Call with every thread of the workgroup, after the workgroup's sc1 stores.  `lds_flag`: one int of LDS nobody else uses around the call.
+// Returns true in every thread of the workgroup that arrived last among `total`.
+__device__ __forceinline__ bool mi_last_arriver(unsigned* ticket, unsigned total, int* lds_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add((mi_gu32*)ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = old == total - 1u;
+        if (last) __hip_atomic_store((mi_gu32*)ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *lds_flag = last ? 1 : 0;
+    }
+    __syncthreads();
+    return *lds_flag != 0;
+}
+constexpr int MI_INLAUNCH_MAX_PARTS = 64;      // partial rows one reducer thread adds per channel

@@ -90,6 +90,50 @@ def gconv(a, wp, N, geom, out=None, mode=GATHER_FWD, out_hw=None, bias=None, sta
     return out, st
 
 
+_tickets = {}
+INLAUNCH = __import__("os").environ.get("MI_INLAUNCH", "1") != "0"      # second-level reductions inside the first launch where they are small
+
+
+def tickets(device, n=256):
+    """Zeroed 32-bit words for the in-launch reductions (mi_common.h: mi_last_arriver), one buffer per (device, stream): launches on one stream
+    are ordered and every launch leaves its words zero; launches on different streams must not share them."""
+    key = (device.index, _stream().value)
+    t = _tickets.get(key)
+    if t is None or t.numel() < n:
+        t = _tickets[key] = torch.zeros(max(n, 256 + 4096), dtype=torch.int32, device=device)
+    return t
+
+
+_inlaunch_px = [None]
+
+
+def gconv_bn_fits(B, Ho, Wo):
+    if _inlaunch_px[0] is None:
+        _inlaunch_px[0] = int(_lib.lib().mi_gconv_bn_inlaunch_max_pixels())
+    return B * Ho * Wo <= _inlaunch_px[0]
+
+
+def gconv_bn(a, wp, N, geom, bn_weight, bn_bias, running_mean, running_var, momentum, eps, bias=None, out=None):
+    """Forward conv + BatchNorm2d statistics AND finalize in one launch (small maps: gconv_bn_fits) -> (y [B,Ho,Wo,N] bf16, fin [4,N]: mean, invstd,
+    scale, shift); the running statistics are updated as torch does."""
+    kh, kw, sh, sw, ph, pw, dh, dw = geom
+    B, Ha, Wa, Ca = a.shape
+    Ho, Wo = conv_out_hw(Ha, Wa, *geom)
+    if out is None:
+        out = new(B, Ho, Wo, N, a.device)
+    pa, lda = view(a, torch.bfloat16)
+    po, ldo = view(out, torch.bfloat16)
+    L = _L()
+    st = torch.empty(int(L.mi_gconv_stats_elems(B, Ho, Wo, N)), dtype=torch.float32, device=a.device)
+    fin = torch.empty((4, N), dtype=torch.float32, device=a.device)
+    tk = tickets(a.device, (N + 31) // 32)
+    if _K.PROFILE is not None:
+        _work[0], _work[1] = 2.0 * B * Ho * Wo * N * Ca * kh * kw, ("gconv", kh, kw, Ca, N, B * Ho * Wo, GATHER_FWD)
+    check(L.mi_gconv_bn(pa, lda, _p(wp), po, ldo, B, Ha, Wa, Ca, Ho, Wo, N, kh, kw, sh, sw, ph, pw, dh, dw, _p(bias), _p(st), _p(tk), _p(bn_weight), _p(bn_bias),
+                        _p(running_mean), _p(running_var), float(momentum), float(eps), _p(fin), _stream()), "mi_gconv_bn")
+    return out, fin
+
+
 def gconv_wgrad(dy, x, dw, geom, accumulate=False):
     """dw [O,I,kh,kw] fp32 (+)= conv weight gradient; dy [B,Ho,Wo,O], x [B,Ha,Wa,I] bf16 views."""
     kh, kw, sh, sw, ph, pw, dh, dw_ = geom
@@ -103,8 +147,9 @@ def gconv_wgrad(dy, x, dw, geom, accumulate=False):
     ws = _workspace(L.mi_gconv_wgrad_workspace(B, Ho, Wo, O, I, kh, kw), dy.device, "gwgrad")
     if _K.PROFILE is not None:
         _work[0], _work[1] = 2.0 * B * Ho * Wo * O * I * kh * kw, ("gwgrad", kh, kw, I, O, B * Ho * Wo, 0)
-    check(L.mi_gconv_wgrad(py, ldy, px, ldx, _p(dw), B, Ha, Wa, I, Ho, Wo, O, kh, kw, sh, sw, ph, pw, dh, dw_, int(accumulate), _p(ws), ws.numel(), _stream()),
-          "mi_gconv_wgrad")
+    tk = tickets(dy.device, 256 + 4096)[256:] if INLAUNCH else None          # (words 0 .. 255: the conv / column-sum reductions)
+    check(L.mi_gconv_wgrad(py, ldy, px, ldx, _p(dw), B, Ha, Wa, I, Ho, Wo, O, kh, kw, sh, sw, ph, pw, dh, dw_, int(accumulate), _p(ws), ws.numel(), _p(tk),
+                           tk.numel() if tk is not None else 0, _stream()), "mi_gconv_wgrad")
     return dw
 
 
@@ -171,8 +216,9 @@ def gbn_bwd_sums(g, y, mask, mean, invstd, dbeta, dgamma, accumulate=False, relu
     py, ldy = view(y, torch.bfloat16) if y is not None else (None, 0)
     L = _L()
     ws = _workspace(L.mi_gcolsum_workspace(M, C), g.device, "gcolsum")
+    tk = tickets(g.device)[255:256] if INLAUNCH else None          # (word 255: the conv's column-tile words come first)
     check(L.mi_gbn_bwd_sums(pg, ldg, gf, py, ldy, pm, ldm, mf, _p(mean), _p(invstd), M, C, _p(dbeta), _p(dgamma), int(accumulate), _p(ws), ws.numel(),
-                            _stream()), "mi_gbn_bwd_sums")
+                            _p(tk), _stream()), "mi_gbn_bwd_sums")
 
 
 def gbn_bwd_apply(g, y, mask, mean, invstd, gamma, dbeta, dgamma, count, out=None, relu6=False):

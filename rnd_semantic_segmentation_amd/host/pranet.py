@@ -234,9 +234,15 @@ class _Run:
                 return self.var(gk.gconv_f32(x.t, u.weight.detach(), u.geom, bias=bias, scale=sc, shift=sh, add=None if add is None else add.t, relu=relu, out=out), False)
             y, _ = _conv_forward(x.t, u, bias, False, net=net)
             return self.var(gk.gbn_apply(y, sc, sh, act, add=None if add is None else add.t, out=out, out_f32=out_f32), False)
-        y, st = _conv_forward(x.t, u, bias, True, net=net)
-        M = y.shape[0] * y.shape[1] * y.shape[2]
-        fin = gk.gbn_finalize(st, u.cout, M, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)      # mean, invstd, scale, shift
+        hw = gk.conv_out_hw(x.t.shape[1], x.t.shape[2], *u.geom)
+        if not _mfma_tile_ok(u, x.t) and gk.gconv_bn_fits(x.t.shape[0], *hw) and os.environ.get("MI_BN_INLAUNCH", "1") != "0":
+            # small maps: the conv's last workgroup finalizes the statistics itself (one launch instead of two)
+            y, fin = gk.gconv_bn(x.t, u.wp, u.cout, u.geom, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, bias=bias)
+            M = y.shape[0] * y.shape[1] * y.shape[2]
+        else:
+            y, st = _conv_forward(x.t, u, bias, True, net=net)
+            M = y.shape[0] * y.shape[1] * y.shape[2]
+            fin = gk.gbn_finalize(st, u.cout, M, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)      # mean, invstd, scale, shift
         o = gk.gbn_apply(y, fin[2], fin[3], act, add=None if add is None else add.t, out=out, out_f32=out_f32)
         ov = self.var(o)
 

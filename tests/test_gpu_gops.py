@@ -90,6 +90,33 @@ def test_gconv_forward_and_batch_statistics(gk, case):
     assert torch.allclose(st[1], (o64 * o64).sum(0), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("case", [CONV_CASES[0], CONV_CASES[4], CONV_CASES[6], CONV_CASES[7], (104, 104, (3, 3), (1, 1), (1, 1), (1, 1), 16, 22, 22, (416, 104), (416, 208))])
+def test_conv_with_in_launch_batchnorm_finalize_equals_the_two_launch_path(gk, case):
+    """mi_gconv_bn (the launch's last workgroup per column tile finalizes the BatchNorm statistics: sc1 hand-off + ticket, mi_common.h) against
+    mi_gconv + mi_gbn_finalize on the same operands: the conv output, mean / invstd / scale / shift and the updated running statistics must be the
+    SAME BITS (same sums in the same order), three times in a row on the same ticket words (they are left zero), incl. a 61-row-tile launch."""
+    Cin, Cout, k, s, p, d, B, H, W, (ldi, offi), (ldo, offo) = case
+    x, w, geom = _conv_setup(case, 300 + Cin)
+    _, xv = _embed(_nhwc(x).cuda(), ldi, offi)
+    wp, _ = gk.gconv_pack(w.cuda())
+    g = torch.Generator().manual_seed(Cout)
+    gamma, beta = (torch.rand(Cout, generator=g) + 0.5).cuda(), (torch.randn(Cout, generator=g) * 0.1).cuda()
+    bias = (torch.randn(Cout, generator=g) * 0.1).cuda() if Cout % 2 else None
+    Ho, Wo = gk.conv_out_hw(H, W, *geom)
+    assert gk.gconv_bn_fits(B, Ho, Wo)
+    rm0, rv0 = torch.randn(Cout, generator=g).cuda(), (torch.rand(Cout, generator=g) + 0.5).cuda()
+    rm_a, rv_a = rm0.clone(), rv0.clone()
+    y_a, st = gk.gconv(xv, wp, Cout, geom, bias=bias, stats=True)
+    fin_a = gk.gbn_finalize(st, Cout, B * Ho * Wo, gamma, beta, rm_a, rv_a, 0.1, 1e-5)
+    for rep in range(3):
+        rm_b, rv_b = rm0.clone(), rv0.clone()
+        y_b, fin_b = gk.gconv_bn(xv, wp, Cout, geom, gamma, beta, rm_b, rv_b, 0.1, 1e-5, bias=bias)
+        torch.cuda.synchronize()
+        assert torch.equal(y_a, y_b) and torch.equal(fin_a, fin_b), (rep, float((fin_a - fin_b).abs().max()))
+        assert torch.equal(rm_a, rm_b) and torch.equal(rv_a, rv_b)
+        assert int(gk.tickets(xv.device).abs().sum()) == 0
+
+
 def test_gconv_fp32_output_with_bias(gk):
     """agg.conv5 = nn.Conv2d(96, 1, 1) with bias (PraNet_Res2Net.py:77) and the one-channel side maps: fp32 store, no rounding."""
     x = _rand((2, 96, 12, 12), 5)
