@@ -351,8 +351,7 @@ int mi_gbn_apply(const void* y, long ldy, const float* scale, const float* shift
  * bit 1 = the mask is a ReLU6 output (the gradient passes where 0 < mask < 6).  The same flags in mi_gbn_bwd_apply. */
 size_t mi_gcolsum_workspace(long M, int C);
 int mi_gbn_bwd_sums(const void* g, long ldg, int g_f32, const void* y, long ldy, const void* mask, long ldm, int mask_f32, const float* mean,
-                    const float* invstd, long M, int C, float* dbeta, float* dgamma, int accumulate, void* workspace, size_t workspace_bytes, unsigned* ticket,
-                    void* stream);      /* ticket: NULL, or one zeroed word (left zero): small reductions then finish inside the first launch (same bits) */
+                    const float* invstd, long M, int C, float* dbeta, float* dgamma, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 /* dy = gamma * invstd * (g' - dbeta * inv_count - xhat * dgamma * inv_count) */
 int mi_gbn_bwd_apply(const void* g, long ldg, int g_f32, const void* y, long ldy, const void* mask, long ldm, int mask_f32, const float* mean,
                      const float* invstd, const float* gamma, const float* dbeta, const float* dgamma, float inv_count, void* dy, long lddy, long M, int C,

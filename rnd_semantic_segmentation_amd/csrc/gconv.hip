@@ -335,19 +335,47 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
                 // mi_gbn_finalize's arithmetic in its order (32 lanes take the tiles t = lane, lane + 32, ..., the lanes are added in order, double),
                 // one thread per channel - the same bits as the separate launch, which these small convs no longer pay (6 us + a launch boundary each).
                 if (mi_last_arriver(p.fin_ticket + blockIdx.y, gridDim.x, reinterpret_cast<int*>(smem))) {
+                    mi_acquire_partials();
+                    // phase A: thread (channel, lane j of L = 256 / BN) forms the partial sums of the strided lanes ry = j, j + L, ... (each lane: the
+                    // tiles ry and ry + 32) - a handful of independent loads per thread, no register arrays that would cost the main loop its occupancy;
+                    // phase B: one thread per channel adds the 32 lanes in order (doubles through LDS, one statistic at a time: 16 KB at BN = 64)
+                    constexpr int L = 256 / BN > 0 ? 256 / BN : 1;
+                    double* lanes = reinterpret_cast<double*>(smem + 16);                     // [32][BN]
+                    const int ch = tid % BN, j = tid / BN, tiles = gridDim.x;
+                    const int cc = n0 + ch;
+                    double tot[2] = {0.0, 0.0};
+#pragma unroll
+                    for (int which = 0; which < 2; ++which) {
+                        if (j < L && cc < p.N) {
+                            float v0[32 / L], v1[32 / L];
+#pragma unroll
+                            for (int q = 0; q < 32 / L; ++q) {
+                                const int ry = j + q * L;
+                                const int t0 = ry < tiles ? ry : tiles - 1, t1 = ry + 32 < tiles ? ry + 32 : tiles - 1;
+                                v0[q] = p.stats[(long)t0 * 2 * p.N + which * p.N + cc];
+                                v1[q] = p.stats[(long)t1 * 2 * p.N + which * p.N + cc];
+                            }
+#pragma unroll
+                            for (int q = 0; q < 32 / L; ++q) {
+                                const int ry = j + q * L;
+                                double a = 0.0;
+                                if (ry < tiles) a += (double)v0[q];
+                                if (ry + 32 < tiles) a += (double)v1[q];
+                                lanes[ry * BN + ch] = a;
+                            }
+                        }
+                        __syncthreads();
+                        if (tid < BN && n0 + tid < p.N) {
+                            double sum = 0.0;
+#pragma unroll
+                            for (int ry = 0; ry < 32; ++ry) sum += lanes[ry * BN + tid];
+                            tot[which] = sum;
+                        }
+                        __syncthreads();
+                    }
                     const int c = n0 + tid;
                     if (tid < BN && c < p.N) {
-                        const int tiles = gridDim.x;
-                        double s1 = 0.0, s2 = 0.0;
-                        for (int ry = 0; ry < 32 && ry < tiles; ++ry) {
-                            double a = 0.0, b = 0.0;
-                            for (int t = ry; t < tiles; t += 32) {
-                                a += (double)mi_ld_sc1(p.stats + (long)t * 2 * p.N + c);
-                                b += (double)mi_ld_sc1(p.stats + (long)t * 2 * p.N + p.N + c);
-                            }
-                            s1 += a;
-                            s2 += b;
-                        }
+                        const double s1 = tot[0], s2 = tot[1];
                         const double mean = s1 / p.count;
                         double var = s2 / p.count - mean * mean;
                         if (var < 0.0) var = 0.0;
@@ -592,22 +620,33 @@ __global__ __launch_bounds__(256, 4) void gwgrad_kernel(GWgP p) {       // four 
         // few K splits: the (tap, tile)'s last workgroup adds the slabs itself - gwgrad_reduce_kernel's arithmetic in its order (lane l of 8 adds the
         // splits l, l + 8, ... ascending, the eight sums are combined as the butterfly does: ((0+1)+(2+3))+((4+5)+(6+7))) - the same bits, one launch
         if (mi_last_arriver(p.ticket + (long)t * tiles + tile, p.S, reinterpret_cast<int*>(smem))) {
+            mi_acquire_partials();
             const long sstride = (long)p.T * p.O * Ip;
             const float* base = p.slab + (long)t * p.O * Ip;
             for (int e = tid; e < WTO * (WTI / 2); e += 256) {
                 const int ol = e / (WTI / 2), ip = (e - ol * (WTI / 2)) * 2;
                 const int o = o0 + ol, i = i0 + ip;
                 if (o >= p.O || i >= Ip) continue;
-                float v0[8], v1[8];
+                float v0[8], v1[8];                                                          // two batches of eight independent loads
 #pragma unroll
                 for (int l = 0; l < 8; ++l) {
-                    v0[l] = v1[l] = 0.f;
-                    for (int sp = l; sp < p.S; sp += 8) {
-                        float x0, x1;
-                        mi_ld2_sc1(base + sp * sstride + (long)o * Ip + i, x0, x1);
-                        v0[l] += x0;
-                        v1[l] += x1;
+                    const int ss = l < p.S ? l : p.S - 1;
+                    const float2 v = *reinterpret_cast<const float2*>(base + ss * sstride + (long)o * Ip + i);
+                    v0[l] = l < p.S ? v.x : 0.f;
+                    v1[l] = l < p.S ? v.y : 0.f;
+                }
+                if (p.S > 8) {
+                    float w0[8], w1[8];
+#pragma unroll
+                    for (int l = 0; l < 8; ++l) {
+                        const int ss = l + 8 < p.S ? l + 8 : p.S - 1;
+                        const float2 v = *reinterpret_cast<const float2*>(base + ss * sstride + (long)o * Ip + i);
+                        w0[l] = v.x;
+                        w1[l] = v.y;
                     }
+#pragma unroll
+                    for (int l = 0; l < 8; ++l)
+                        if (l + 8 < p.S) v0[l] += w0[l], v1[l] += w1[l];
                 }
                 const float r0 = ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v0[4] + v0[5]) + (v0[6] + v0[7]));
                 const float r1 = ((v1[0] + v1[1]) + (v1[2] + v1[3])) + ((v1[4] + v1[5]) + (v1[6] + v1[7]));

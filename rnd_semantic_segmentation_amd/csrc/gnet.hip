@@ -195,8 +195,7 @@ inline ColsumPlan colsum_plan(long M, int C, int vec) {
 }
 template <int VEC, typename TG, typename TM>
 __global__ __launch_bounds__(256) void gcolsum_partial_kernel(const TG* g, long ldg, const __bf16* y, long ldy, const TM* mask, long ldm, const float* mean,
-                                                              const float* invstd, long M, int C, float* partial, int tx_n, int rows_per_block, float hi,
-                                                              unsigned* ticket, float* out1, float* out2, int accumulate) {
+                                                              const float* invstd, long M, int C, float* partial, int tx_n, int rows_per_block, float hi) {
     __shared__ float red[2][256][VEC];
     const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n, ty_n = 256 / tx_n;
     float s1[VEC], s2[VEC];
@@ -273,35 +272,9 @@ __global__ __launch_bounds__(256) void gcolsum_partial_kernel(const TG* g, long 
                     b += red[1][k * tx_n + tx][j];
                 }
                 if (c0 + j < C) {
-                    if (ticket) {                      // handed to the launch's last workgroup: write-through
-                        mi_st_sc1(partial + ((long)blockIdx.x * 2 + 0) * C + c0 + j, a);
-                        mi_st_sc1(partial + ((long)blockIdx.x * 2 + 1) * C + c0 + j, b);
-                    } else {
-                        partial[((long)blockIdx.x * 2 + 0) * C + c0 + j] = a;
-                        partial[((long)blockIdx.x * 2 + 1) * C + c0 + j] = b;
-                    }
+                    partial[((long)blockIdx.x * 2 + 0) * C + c0 + j] = a;
+                    partial[((long)blockIdx.x * 2 + 1) * C + c0 + j] = b;
                 }
-            }
-        }
-    }
-    if (ticket) {
-        // few partial rows: the launch's last workgroup adds them (gcolsum_final_kernel's arithmetic in its order: 32 lanes take the blocks
-        // b = lane, lane + 32, ..., the lanes are added in order, double) - the same bits without the second launch
-        if (mi_last_arriver(ticket, gridDim.x * gridDim.y, reinterpret_cast<int*>(&red[0][0][0]))) {
-            const int blocks = gridDim.x;
-            for (int c = threadIdx.x; c < C; c += 256) {
-                double s1 = 0.0, s2 = 0.0;
-                for (int ry = 0; ry < 32 && ry < blocks; ++ry) {
-                    double a = 0.0, b = 0.0;
-                    for (int k = ry; k < blocks; k += 32) {
-                        a += (double)mi_ld_sc1(partial + ((long)k * 2 + 0) * C + c);
-                        b += (double)mi_ld_sc1(partial + ((long)k * 2 + 1) * C + c);
-                    }
-                    s1 += a;
-                    s2 += b;
-                }
-                if (out1) out1[c] = accumulate ? out1[c] + (float)s1 : (float)s1;
-                if (out2) out2[c] = accumulate ? out2[c] + (float)s2 : (float)s2;
             }
         }
     }
@@ -984,8 +957,7 @@ int mi_gbn_apply(const void* y, long ldy, const float* scale, const float* shift
 size_t mi_gcolsum_workspace(long M, int C) { (void)M; return (size_t)770 * 2 * C * sizeof(float); }      // colsum_plan never uses more than 769 blocks
 
 int mi_gbn_bwd_sums(const void* g, long ldg, int g_f32, const void* y, long ldy, const void* mask, long ldm, int mask_f32, const float* mean,
-                    const float* invstd, long M, int C, float* dbeta, float* dgamma, int accumulate, void* workspace, size_t workspace_bytes, unsigned* ticket,
-                    void* stream) {
+                    const float* invstd, long M, int C, float* dbeta, float* dgamma, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
     MI_REQUIRE(g && workspace && (dbeta || dgamma), "mi_gbn_bwd_sums: null operand");
     MI_REQUIRE(M > 0 && C > 0 && ldg >= C, "mi_gbn_bwd_sums: bad shape");
     MI_REQUIRE(!y || (mean && invstd && ldy >= C), "mi_gbn_bwd_sums: y needs mean / invstd");
@@ -1000,9 +972,7 @@ int mi_gbn_bwd_sums(const void* g, long ldg, int g_f32, const void* y, long ldy,
     const ColsumPlan q = colsum_plan(M, C, vec);
     const int blocks = q.blocks;
     const dim3 grid(blocks, ((C + vec - 1) / vec + q.tx - 1) / q.tx);
-    // in-launch second level (ticket given): while one reducer thread adds at most 128 (partial row, channel) pairs - else the separate launch
-    unsigned* tk = (ticket && blocks <= MI_INLAUNCH_MAX_PARTS && (long)blocks * ((C + 255) / 256) <= 128) ? ticket : nullptr;
-#define CSK(V, TG, TM) hipLaunchKernelGGL((gcolsum_partial_kernel<V, TG, TM>), grid, dim3(256), 0, s, (const TG*)g, ldg, yy, ldy, (const TM*)mask, ldm, mean, invstd, M, C, part, q.tx, q.rows_per_block, hi, tk, dbeta, dgamma, accumulate)
+#define CSK(V, TG, TM) hipLaunchKernelGGL((gcolsum_partial_kernel<V, TG, TM>), grid, dim3(256), 0, s, (const TG*)g, ldg, yy, ldy, (const TM*)mask, ldm, mean, invstd, M, C, part, q.tx, q.rows_per_block, hi)
     if (g_f32 && mask_f32) CSK(1, float, float);
     else if (g_f32) CSK(1, float, __bf16);
     else if (vec == 8) CSK(8, __bf16, __bf16);
@@ -1010,7 +980,6 @@ int mi_gbn_bwd_sums(const void* g, long ldg, int g_f32, const void* y, long ldy,
     else CSK(1, __bf16, __bf16);
 #undef CSK
     MI_CHECK_LAUNCH("gcolsum_partial_kernel");
-    if (tk) return MI_OK;
     hipLaunchKernelGGL(gcolsum_final_kernel, dim3((C + 7) / 8), dim3(256), 0, s, part, blocks, C, dbeta, dgamma, accumulate);
     MI_CHECK_LAUNCH("gcolsum_final_kernel");
     return MI_OK;

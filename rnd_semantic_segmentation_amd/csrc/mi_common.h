@@ -145,4 +145,12 @@ __device__ __forceinline__ bool mi_last_arriver(unsigned* ticket, unsigned total
     __syncthreads();
     return *lds_flag != 0;
 }
+// In the last-arriving workgroup, before it reads the other workgroups' write-through partials with PLAIN loads (which the compiler may issue
+// back to back - a chain of relaxed atomic loads is issued one round trip at a time: measured +16 us on a 61-tile finalize): one agent-scope
+// acquire (buffer_inv sc1) drops this CU's stale lines, then every wave proceeds.
+__device__ __forceinline__ void mi_acquire_partials() {
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
 constexpr int MI_INLAUNCH_MAX_PARTS = 64;      // partial rows one reducer thread adds per channel

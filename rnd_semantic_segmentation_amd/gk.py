@@ -216,9 +216,8 @@ def gbn_bwd_sums(g, y, mask, mean, invstd, dbeta, dgamma, accumulate=False, relu
     py, ldy = view(y, torch.bfloat16) if y is not None else (None, 0)
     L = _L()
     ws = _workspace(L.mi_gcolsum_workspace(M, C), g.device, "gcolsum")
-    tk = tickets(g.device)[255:256] if INLAUNCH else None          # (word 255: the conv's column-tile words come first)
     check(L.mi_gbn_bwd_sums(pg, ldg, gf, py, ldy, pm, ldm, mf, _p(mean), _p(invstd), M, C, _p(dbeta), _p(dgamma), int(accumulate), _p(ws), ws.numel(),
-                            _p(tk), _stream()), "mi_gbn_bwd_sums")
+                            _stream()), "mi_gbn_bwd_sums")
 
 
 def gbn_bwd_apply(g, y, mask, mean, invstd, gamma, dbeta, dgamma, count, out=None, relu6=False):
