@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void gdw_dgrad_kernel(const __bf16* dy, const 
 }
 
 // partial[blk][t][c] (t = 0..8 taps, 9 = bias) over the block's 256 output pixels; fixed order
-constexpr int DWG_ROWS = 256;
+constexpr int DWG_ROWS = 32;       // (256 rows per block left the 6 x 11 x 19 maps of the local attention modules with 20 workgroups: 197 us per launch)
 __global__ __launch_bounds__(256) void gdw_wgrad_partial_kernel(const __bf16* dy, const __bf16* x, float* partial, DwP q) {
     __shared__ float red[10][4][64];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
@@ -118,12 +118,13 @@ __global__ __launch_bounds__(256) void gdw_wgrad_partial_kernel(const __bf16* dy
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int ih = oh * q.stride - q.pad + ky;
-                if ((unsigned)ih >= (unsigned)q.H) continue;
+                const bool okh = (unsigned)ih < (unsigned)q.H;
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
+                for (int kx = 0; kx < 3; ++kx) {                       // unconditional loads at a clamped position: no wait between them
                     const int iw = ow * q.stride - q.pad + kx;
-                    if ((unsigned)iw >= (unsigned)q.W) continue;
-                    s[ky * 3 + kx] += g * (float)x[(((long)b * q.H + ih) * q.W + iw) * q.ldx + c];
+                    const bool ok = okh && (unsigned)iw < (unsigned)q.W;
+                    const float xv = (float)x[(((long)b * q.H + (okh ? ih : 0)) * q.W + ((unsigned)iw < (unsigned)q.W ? iw : 0)) * q.ldx + c];
+                    s[ky * 3 + kx] += ok ? g * xv : 0.f;
                 }
             }
         }

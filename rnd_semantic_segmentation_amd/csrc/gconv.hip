@@ -663,6 +663,182 @@ __global__ __launch_bounds__(256, 4) void gwgrad_kernel(GWgP p) {       // four 
     }
 }
 
+// Fused kernel row (round 4): one workgroup = (K split, kernel row ky, o tile, i tile) computes the THREE taps kx = 0, 1, 2 of that row from ONE staged
+// window of x.  For a stride-1 conv whose output has the input's height and width (pad = dilation: every 3x3 / 1x3 conv of Res2Net, RFB, the partial
+// decoder, HarDNet), the sources of 64 consecutive output pixels for tap (ky, kx) are 64 consecutive input pixels, shifted by kx * dw between the taps: the
+// window of 64 + 2 dw pixel rows is loaded once and the transposed MFMA reads of tap kx start kx * dw rows further down.  What the per-tap kernel got from
+// the zero padding for free - a tap that leaves the image row contributes nothing - is done on the dy side: the loader writes two validity bits per output
+// pixel (left / right tap inside the row), and a lane whose pixel is invalid for the tap reads its dy fragment from a zero row instead.  x rows are valid
+// when they lie in the tensor and the output row they serve (h_src - (ky dh - ph)) lies in the image.  Counters before (profiles/pmc_gald.json,
+// pmc_pranet.json): the per-tap kernel moved 32.6 / 13.3 GB of HBM per step (GALD / PraNet), its L2 hit rate 0.57 / 0.42 - nine re-reads of dy and x.
+constexpr int W3_MAXD = 8;                                  // largest column dilation the window holds
+constexpr int W3_XROWS = WKP + 2 * W3_MAXD;                 // 80 pixel rows of x per stage
+constexpr int W3_STAGE = (W3_XROWS + WKP) * WRS + 64;       // x window | dy tile | 64 flag bytes
+template <int YVEC, int XVEC>
+__global__ __launch_bounds__(256, 2) void gwgrad3_kernel(GWgP p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * W3_STAGE + WRS];      // two stages + one zero row
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles = p.o_tiles * p.i_tiles;
+    const int kh = p.T / 3;
+    int id = blockIdx.x;
+    const int tile = id % tiles;
+    id /= tiles;
+    const int ky = id % kh, split = id / kh;
+    const int ot = tile / p.i_tiles, itile = tile - ot * p.i_tiles;
+    const int o0 = ot * WTO, i0 = itile * WTI;
+    const int m_begin = split * p.rows_per_split;
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+    const int nk = m_end > m_begin ? (m_end - m_begin + WKP - 1) / WKP : 0;
+    const int lpx = tid >> 3, lch = tid & 7;
+    const int hw = p.Ha * p.Wa;
+    const int dyoff = ky * p.dh - p.ph;                      // source row - output row
+    const int xrows = WKP + 2 * p.dw;
+    char* zero_row = smem + 2 * W3_STAGE;
+    if (tid < WRS / 4) reinterpret_cast<uint32_t*>(zero_row)[tid] = 0u;
+
+    // coordinates of this thread's rows, advanced by 64 pixels per call of load(): dy rows lpx, lpx + 32; x window rows lpx, lpx + 32, lpx + 64
+    int yh[2], yw[2], xh[3], xw[3];
+    long xq[3];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int m = m_begin + lpx + 32 * h;
+        const int rem = m % hw;
+        yh[h] = rem / p.Wa;
+        yw[h] = rem - yh[h] * p.Wa;
+    }
+#pragma unroll
+    for (int h = 0; h < 3; ++h) {
+        xq[h] = (long)m_begin + (long)dyoff * p.Wa - p.dw + lpx + 32 * h;
+        const int rem = (int)(((xq[h] % hw) + hw) % hw);
+        xh[h] = rem / p.Wa;
+        xw[h] = rem - xh[h] * p.Wa;
+    }
+    const int step_rows = WKP / p.Wa, step_cols = WKP - step_rows * p.Wa;
+    auto advance = [&](int& hh, int& ww) {
+        ww += step_cols;
+        hh += step_rows;
+        if (ww >= p.Wa) ww -= p.Wa, ++hh;
+        while (hh >= p.Ha) hh -= p.Ha;
+    };
+    bf16x8 ry0[2], rx0[3], ry1[2], rx1[3];
+    uint32_t rf0 = 0, rf1 = 0;                               // validity bits of the two dy rows (byte h)
+    auto load = [&](int kt, bf16x8 (&ry)[2], bf16x8 (&rx)[3], uint32_t& rf) {
+        rf = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = m_begin + kt * WKP + lpx + 32 * h;
+            const bool ok = m < m_end;
+            ry[h] = gload8<YVEC>(p.dY + (long)(ok ? m : 0) * p.ldy, o0 + lch * 8, p.O, ok);
+            const uint32_t f = (yw[h] >= p.dw ? 1u : 0u) | (yw[h] + p.dw < p.Wa ? 2u : 0u);
+            rf |= f << (8 * h);
+            advance(yh[h], yw[h]);
+        }
+#pragma unroll
+        for (int h = 0; h < 3; ++h) {
+            const bool in_window = lpx + 32 * h < xrows;
+            const bool ok = in_window && xq[h] >= 0 && xq[h] < (long)p.M && (unsigned)(xh[h] - dyoff) < (unsigned)p.Ha && kt < nk;
+            rx[h] = gload8<XVEC>(p.X + (ok ? xq[h] : 0L) * p.ldx, i0 + lch * 8, p.I, ok);
+            xq[h] += WKP;
+            advance(xh[h], xw[h]);
+        }
+    };
+    auto stash = [&](int buf, const bf16x8 (&ry)[2], const bf16x8 (&rx)[3], uint32_t rf) {
+        char* sx = smem + buf * W3_STAGE;
+        char* sy = sx + W3_XROWS * WRS;
+#pragma unroll
+        for (int h = 0; h < 3; ++h)
+            if (lpx + 32 * h < W3_XROWS) *reinterpret_cast<bf16x8*>(sx + (lpx + 32 * h) * WRS + lch * 16) = rx[h];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            *reinterpret_cast<bf16x8*>(sy + (lpx + 32 * h) * WRS + lch * 16) = ry[h];
+            if (lch == 0) sy[WKP * WRS + lpx + 32 * h] = (char)((rf >> (8 * h)) & 0xff);
+        }
+    };
+
+    const int wi = wave & 1, wo = wave >> 1;
+    f32x4 acc[3][2][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[t][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int g = lane >> 4, q = (lane & 15) >> 2, pc = lane & 3;
+    const int prow = g * 4 + q;                              // this lane's pixel row within a 16-row half
+    const int row_off = prow * WRS + pc * 8;
+    const int dwrs = p.dw * WRS;
+    auto compute = [&](int buf) {
+        const char* sx0 = smem + buf * W3_STAGE;
+        const char* sy0 = sx0 + W3_XROWS * WRS;
+        const unsigned char* flags = reinterpret_cast<const unsigned char*>(sy0 + WKP * WRS);
+#pragma unroll
+        for (int ks = 0; ks < WKP / 32; ++ks) {
+            const char* sy = sy0 + row_off + ks * 32 * WRS;
+            const unsigned f0 = flags[ks * 32 + prow], f1 = flags[ks * 32 + prow + 16];
+            union { bf16x8 v; s16x4 h[2]; } yf[3][2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int col = (wo * 32 + b * 16) * 2;
+                yf[1][b].h[0] = tr_read(sy + col);
+                yf[1][b].h[1] = tr_read(sy + col + 16 * WRS);
+                const char* z = zero_row + pc * 8 + col;
+                yf[0][b].h[0] = tr_read((f0 & 1u) ? sy + col : z);
+                yf[0][b].h[1] = tr_read((f1 & 1u) ? sy + col + 16 * WRS : z);
+                yf[2][b].h[0] = tr_read((f0 & 2u) ? sy + col : z);
+                yf[2][b].h[1] = tr_read((f1 & 2u) ? sy + col + 16 * WRS : z);
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const char* sx = sx0 + row_off + ks * 32 * WRS + t * dwrs;
+                union { bf16x8 v; s16x4 h[2]; } xf[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const char* base = sx + (wi * 32 + a * 16) * 2;
+                    xf[a].h[0] = tr_read(base);
+                    xf[a].h[1] = tr_read(base + 16 * WRS);
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[t][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[a].v, yf[t][b].v, acc[t][a][b], 0, 0, 0);
+            }
+        }
+    };
+    if (nk > 0) {
+        load(0, ry0, rx0, rf0);
+        load(1, ry1, rx1, rf1);
+        stash(0, ry0, rx0, rf0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt += 2) {
+            load(kt + 2, ry0, rx0, rf0);
+            compute(0);
+            stash(1, ry1, rx1, rf1);
+            __syncthreads();
+            if (kt + 1 >= nk) break;
+            load(kt + 3, ry1, rx1, rf1);
+            compute(1);
+            stash(0, ry0, rx0, rf0);
+            __syncthreads();
+        }
+    }
+    const int Ip = (p.I + 3) & ~3;
+    const int fcol = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        float* slab = p.slab + ((long)(split * p.T + ky * 3 + t) * p.O) * Ip;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int o = o0 + wo * 32 + b * 16 + fcol;
+            if (o >= p.O) continue;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int i = i0 + wi * 32 + a * 16 + fq * 4;
+                if (i < Ip) *reinterpret_cast<f32x4*>(slab + (long)o * Ip + i) = acc[t][a][b];
+            }
+        }
+    }
+}
+
 // dw[o][i][t] (+)= sum over the K splits (bitwise reproducible); 8 lanes per output element (t, o, i: i fastest): lane l adds the splits
 // l, l + 8, ... in ascending order, the eight partial sums are combined by a fixed butterfly
 __global__ __launch_bounds__(256) void gwgrad_reduce_kernel(const float* slab, float* dw, int O, int I, int T, int S, int accumulate) {
@@ -859,6 +1035,9 @@ size_t mi_gconv_wgrad_workspace(int B, int Ho, int Wo, int O, int I, int kh, int
     const long M = (long)B * Ho * Wo;
     if (M <= 0 || M >= (1L << 31)) return 0;          // mi_gconv_wgrad refuses such a shape
     gwgrad_plan((int)M, O, I, kh * kw, &S, &rows, &ot, &it);
+    int S3 = 0;
+    if (kw == 3) gwgrad_plan((int)M, O, I, kh, &S3, &rows, &ot, &it);       // the fused-row kernel splits K for a third of the workgroups
+    if (S3 > S) S = S3;
     return (size_t)S * kh * kw * O * ((I + 3) & ~3) * sizeof(float);
 }
 
@@ -883,11 +1062,36 @@ int mi_gconv_wgrad(const void* dy, long ldy, const void* x, long ldx, float* dw,
     p.O = O; p.I = I; p.T = kh * kw;
     p.Ho = Ho; p.Wo = Wo; p.Ha = Ha; p.Wa = Wa;
     p.kw = kw; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.dh = dh; p.dw = dw_;
-    gwgrad_plan(p.M, O, I, p.T, &p.S, &p.rows_per_split, &p.o_tiles, &p.i_tiles);
+    // fused kernel row (gwgrad3_kernel): three-column kernels at stride 1 whose output has the input's height and width
+    const bool fused = kw == 3 && sh == 1 && sw == 1 && pw == dw_ && Ho == Ha && Wo == Wa && dw_ <= W3_MAXD && mi_sw().gwgrad3;
+    gwgrad_plan(p.M, O, I, fused ? kh : p.T, &p.S, &p.rows_per_split, &p.o_tiles, &p.i_tiles);
     const size_t need = (size_t)p.S * p.T * O * ((I + 3) & ~3) * sizeof(float);
     if (workspace_bytes < need) return mi_set_error(MI_ENOMEM, "mi_gconv_wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
     hipStream_t s = (hipStream_t)stream;
     const int yv = view_vec(dy, ldy, O), xv = view_vec(x, ldx, I);
+    if (fused) {
+        p.ticket = nullptr;
+        p.dwout = dw;
+        p.accumulate = accumulate;
+        const dim3 grid3(p.o_tiles * p.i_tiles * kh * p.S);
+#define GW3(YV, XV) hipLaunchKernelGGL((gwgrad3_kernel<YV, XV>), grid3, dim3(256), 0, s, p)
+        if (yv == 8 && xv == 8) GW3(8, 8);
+        else if (yv == 8 && xv == 4) GW3(8, 4);
+        else if (yv == 8) GW3(8, 1);
+        else if (yv == 4 && xv == 8) GW3(4, 8);
+        else if (yv == 4 && xv == 4) GW3(4, 4);
+        else if (yv == 4) GW3(4, 1);
+        else if (xv == 8) GW3(1, 8);
+        else if (xv == 4) GW3(1, 4);
+        else GW3(1, 1);
+#undef GW3
+        MI_CHECK_LAUNCH("gwgrad3_kernel");
+        const long n3 = (long)O * I * p.T;
+        const int blocks3 = (int)((n3 + 31) / 32 < 4096 ? (n3 + 31) / 32 : 4096);
+        hipLaunchKernelGGL(gwgrad_reduce_kernel, dim3(blocks3), dim3(256), 0, s, p.slab, dw, O, I, p.T, p.S, accumulate);
+        MI_CHECK_LAUNCH("gwgrad_reduce_kernel");
+        return MI_OK;
+    }
     // few K splits: the slabs are added by the last workgroup of each (tap, tile) inside this launch (needs one zeroed ticket word per (tap, tile))
     const bool inlaunch = tickets && p.S <= GW_INLAUNCH_S && p.o_tiles * p.i_tiles * p.T <= n_tickets;
     p.ticket = inlaunch ? tickets : nullptr;

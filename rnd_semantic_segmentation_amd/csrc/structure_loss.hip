@@ -12,7 +12,6 @@
 
 namespace {
 
-constexpr int SL_BLOCKS = 64;      // partial-sum workgroups per image
 
 __global__ __launch_bounds__(256) void sl_hbox_kernel(const float* __restrict__ mask, float* __restrict__ tmp, int B, int H, int W) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -31,28 +30,37 @@ __global__ __launch_bounds__(256) void sl_hbox_kernel(const float* __restrict__ 
     tmp[idx] = s;
 }
 
-// weit, and per-workgroup partial sums {bce, inter, union} over a contiguous pixel range of ONE image
+// weit, and per-workgroup partial sums {bce, inter, union} over a 32 x 64 pixel tile of ONE image.  The tile's 62 x 64 window of row sums goes through
+// LDS once (the first version read its 31 rows per pixel from global memory: 212 MB of HBM traffic and 97 us per launch for 16 maps of 352 x 352 -
+// counters of profiles/pmc_pranet.json); every pixel then adds its 31 taps from LDS in the same order as before.
+constexpr int SLT_H = 32, SLT_W = 64;
 __global__ __launch_bounds__(256) void sl_terms_kernel(const float* __restrict__ pred, const float* __restrict__ mask, const float* __restrict__ tmp,
-                                                       float* __restrict__ weit, float* __restrict__ partial, int H, int W, int per_block) {
+                                                       float* __restrict__ weit, float* __restrict__ partial, int H, int W) {
+    __shared__ float win[(SLT_H + 30) * SLT_W];
     __shared__ float red[3][256];
-    const int b = blockIdx.y;
-    const int HW = H * W;
-    const int p0 = blockIdx.x * per_block, p1 = min(HW, p0 + per_block);
-    const long base = (long)b * HW;
+    const int b = blockIdx.z;
+    const int h0 = blockIdx.y * SLT_H, w0 = blockIdx.x * SLT_W;
+    const long base = (long)b * H * W;
+    for (int e = threadIdx.x; e < (SLT_H + 30) * SLT_W; e += 256) {
+        const int r = e / SLT_W, c = e - r * SLT_W;
+        const int hh = h0 - 15 + r, ww = w0 + c;
+        const float v = tmp[base + (long)min(max(hh, 0), H - 1) * W + min(ww, W - 1)];          // unconditional load, then select
+        win[e] = ((unsigned)hh < (unsigned)H && ww < W) ? v : 0.f;
+    }
+    __syncthreads();
+    const int cx = threadIdx.x & (SLT_W - 1), ry = threadIdx.x / SLT_W;
     float a_bce = 0.f, a_int = 0.f, a_uni = 0.f;
-    for (int p = p0 + threadIdx.x; p < p1; p += 256) {
-        const int h = p / W, w = p - h * W;
+    for (int r = ry; r < SLT_H; r += 256 / SLT_W) {
+        const int h = h0 + r, w = w0 + cx;
+        if (h >= H || w >= W) continue;
         float box = 0.f;
 #pragma unroll
-        for (int dy = -15; dy <= 15; ++dy) {
-            const int hh = h + dy;
-            const float v = tmp[base + (long)min(max(hh, 0), H - 1) * W + w];
-            box += (unsigned)hh < (unsigned)H ? v : 0.f;
-        }
+        for (int dy = 0; dy <= 30; ++dy) box += win[(r + dy) * SLT_W + cx];       // rows h - 15 .. h + 15 (zeros outside the image)
         box *= (1.0f / 961.0f);
-        const float z = mask[base + p], x = pred[base + p];
+        const long p = base + (long)h * W + w;
+        const float z = mask[p], x = pred[p];
         const float wt = 1.0f + 5.0f * fabsf(box - z);
-        weit[base + p] = wt;
+        weit[p] = wt;
         // max(x, 0) - x z + log(1 + exp(-|x|)): torch's stable form of the logistic loss
         a_bce += fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x)));
         const float s = 1.0f / (1.0f + expf(-x));
@@ -66,7 +74,7 @@ __global__ __launch_bounds__(256) void sl_terms_kernel(const float* __restrict__
     if (threadIdx.x < 3) {
         float s = 0.f;
         for (int k = 0; k < 256; ++k) s += red[threadIdx.x][k];              // fixed order
-        partial[((long)b * gridDim.x + blockIdx.x) * 3 + threadIdx.x] = s;
+        partial[((long)b * gridDim.x * gridDim.y + blockIdx.y * gridDim.x + blockIdx.x) * 3 + threadIdx.x] = s;
     }
 }
 
@@ -114,8 +122,10 @@ __global__ __launch_bounds__(256) void sl_bwd_kernel(const float* __restrict__ p
 
 }  // namespace
 
+static inline int sl_tiles(int H, int W) { return ((H + SLT_H - 1) / SLT_H) * ((W + SLT_W - 1) / SLT_W); }
+
 extern "C" size_t mi_structure_loss_workspace(int B, int H, int W) {
-    return ((size_t)2 * B * H * W + (size_t)B * SL_BLOCKS * 3) * sizeof(float);
+    return ((size_t)2 * B * H * W + (size_t)B * sl_tiles(H, W) * 3) * sizeof(float);
 }
 
 extern "C" int mi_structure_loss(const float* pred, const float* mask, int B, int H, int W, float* out, float* grad, float grad_scale,
@@ -128,14 +138,11 @@ extern "C" int mi_structure_loss(const float* pred, const float* mask, int B, in
     float* weit = tmp + n;
     float* partial = weit + n;
     const int HW = H * W;
-    int nblk = (HW + 1023) / 1024;                       // at least 1024 pixels per partial workgroup
-    if (nblk > SL_BLOCKS) nblk = SL_BLOCKS;
-    const int per_block = (HW + nblk - 1) / nblk;
-    nblk = (HW + per_block - 1) / per_block;
+    const int nblk = sl_tiles(H, W);
     const float inv_pixels = 1.0f / (float)n;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(sl_hbox_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mask, tmp, B, H, W);
-    hipLaunchKernelGGL(sl_terms_kernel, dim3(nblk, B), dim3(256), 0, st, pred, mask, tmp, weit, partial, H, W, per_block);
+    hipLaunchKernelGGL(sl_terms_kernel, dim3((W + SLT_W - 1) / SLT_W, (H + SLT_H - 1) / SLT_H, B), dim3(256), 0, st, pred, mask, tmp, weit, partial, H, W);
     hipLaunchKernelGGL(sl_final_kernel, dim3(1), dim3(256), 0, st, partial, out, B, nblk, inv_pixels);
     if (grad)
         hipLaunchKernelGGL(sl_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pred, mask, weit, out, grad, B, HW, inv_pixels,
