@@ -1063,7 +1063,10 @@ int mi_gconv_wgrad(const void* dy, long ldy, const void* x, long ldx, float* dw,
     p.Ho = Ho; p.Wo = Wo; p.Ha = Ha; p.Wa = Wa;
     p.kw = kw; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.dh = dh; p.dw = dw_;
     // fused kernel row (gwgrad3_kernel): three-column kernels at stride 1 whose output has the input's height and width
-    const bool fused = kw == 3 && sh == 1 && sw == 1 && pw == dw_ && Ho == Ha && Wo == Wa && dw_ <= W3_MAXD && mi_sw().gwgrad3;
+    // (measured, bench.py --workload gald / pranet: GALD's weight gradients 9.96 -> 8.90 ms per step with every eligible conv fused, PraNet's 5.02 -> 5.23:
+    //  on the small maps of the deep stages a third of the workgroups leaves the launch latency-bound on fewer CUs - fused from 65 536 pixels up, or when forced)
+    const bool fused = kw == 3 && sh == 1 && sw == 1 && pw == dw_ && Ho == Ha && Wo == Wa && dw_ <= W3_MAXD &&
+                       (mi_sw().gwgrad3 == 2 || (mi_sw().gwgrad3 == 1 && p.M >= 65536));
     gwgrad_plan(p.M, O, I, fused ? kh : p.T, &p.S, &p.rows_per_split, &p.o_tiles, &p.i_tiles);
     const size_t need = (size_t)p.S * p.T * O * ((I + 3) & ~3) * sizeof(float);
     if (workspace_bytes < need) return mi_set_error(MI_ENOMEM, "mi_gconv_wgrad: workspace %zu < %zu bytes", workspace_bytes, need);

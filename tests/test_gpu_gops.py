@@ -155,6 +155,29 @@ def test_gconv_data_and_weight_gradient(gk, case):
     assert float((dw.double().cpu() - 2 * wd.grad).abs().max()) / float(wd.grad.abs().max()) < 4e-5
 
 
+def test_fused_row_weight_gradient_on_a_large_map(gk):
+    """From 65 536 output pixels up a three-column kernel at stride 1 takes gwgrad3_kernel (one staged x window for the three taps of a kernel row,
+    row-wrap handled by validity bits on the dy side): 2 x 26 x 192 x 200 on channel-slice views, dilation 1 and 3, against torch in float64;
+    bit-reproducible; the per-tap kernel (small maps, MI_GWGRAD3=0) is covered by the cases above and by tests/test_gpu_scripts.py."""
+    for dil in (1, 3):
+        case = (26, 20, (3, 3), (1, 1), (dil, dil), (dil, dil), 2, 192, 200, (104, 26), (52, 12))
+        Cin, Cout, k, s, p, d, B, H, W, (ldi, offi), (ldo, offo) = case
+        x, w, geom = _conv_setup(case, 700 + dil)
+        xd, wd = x.double(), w.to(torch.bfloat16).double().requires_grad_(True)
+        y = F.conv2d(xd, wd, None, s, p, d)
+        dy = _rand(tuple(y.shape), 19)
+        y.backward(dy.double())
+        _, dyv = _embed(_nhwc(dy).cuda(), ldo, offo)
+        _, xv = _embed(_nhwc(x).cuda(), ldi, offi)
+        dw, dw2 = torch.empty_like(w, device="cuda"), torch.empty_like(w, device="cuda")
+        gk.gconv_wgrad(dyv, xv, dw, geom)
+        gk.gconv_wgrad(dyv, xv, dw2, geom)
+        torch.cuda.synchronize()
+        err = float((dw.double().cpu() - wd.grad).abs().max()) / float(wd.grad.abs().max())
+        assert err < 2e-5, (dil, err)
+        assert torch.equal(dw, dw2)
+
+
 def test_gconv_weight_gradient_is_bit_reproducible_and_splits_k(gk):
     """M = 16 x 44 x 44 pixels: several K splits; two runs give the same bits (fixed-order slab reduction)."""
     x = _rand((16, 52, 44, 44), 1)

@@ -125,6 +125,8 @@ def test_opt_in_kernel_variants_and_single_stream_schedule_stay_correct():
                      ({"MI_STEM_CONV": "miopen"}, ["tests/test_gpu_model.py", "-k", "tinynet_three_sgd or tinynet_forward_backward or bit_reproducible"]),   # library stem forward, HIP weight gradient
                      ({"MI_STEM_CONV": "miopen", "MI_STEM_WGRAD": "miopen"}, ["tests/test_gpu_model.py", "-k", "tinynet_three_sgd or tinynet_forward_backward"]),   # the library's stem conv both ways
                      ({"MI_BN_TWO_PASS": "1"}, ["tests/test_gpu_bn.py", "-k", "tinynet_trainable"]),             # BatchNorm statistics as two passes
+                     ({"MI_GWGRAD3": "2"}, ["tests/test_gpu_gops.py", "-k", "weight_gradient"]),                  # general family: fused-row weight gradient forced onto the small shapes
+                     ({"MI_GWGRAD3": "0", "MI_INLAUNCH": "0", "MI_BN_INLAUNCH": "0"}, ["tests/test_gpu_gops.py", "-k", "weight_gradient or batch_statistics"]),   # per-tap kernel, two-launch reductions
                      ({"MI_WGRAD_STREAM": "0", "MI_BATCH_LANES": "1"}, ["tests/test_gpu_model.py", "-k", "tinynet"])):
         r = run(["-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider"] + sel, env)
         assert r.returncode == 0, (env, r.stdout[-3000:])
