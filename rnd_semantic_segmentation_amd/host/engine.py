@@ -368,6 +368,19 @@ class StageEngine:
         g = K.relu_mask(dfeat, fbits)                     # through the last block's ReLU
         store = getattr(self.convs[0].weight, "_mi_store", None)
         side = _SideStream.get(dfeat.device)
+        # MI_BWD_PAIR=1 (experiment, section 8 of DESIGN.md): pair the launches of the two streams by the resource that bounds them.  In stream order a
+        # block is D3 D2 D1 on the main stream (data gradients: MFMA-, MFMA-, HBM-bound) and W3 W2 W1 behind them on the side stream (weight gradients:
+        # HBM-, MFMA-, HBM-bound), i.e. W2 beside D2 (both MFMA-bound) and W1 beside D1 (both HBM-bound).  Deferring W1 to the next block's start puts
+        # W3 + W1' beside D3 D2 and W2 beside D1.
+        pair = side is not None and os.environ.get("MI_BWD_PAIR", "0") == "1"
+        deferred = None
+
+        def hooks(rts_):
+            if store is not None and store.grad_hooks:
+                lo, hi = store.span([rt.weight for rt in rts_])
+                with torch.cuda.stream(side.stream) if side is not None else contextlib.nullcontext():
+                    for hook in store.grad_hooks:         # the all-reduce of this range is ordered after its weight gradients
+                        hook(store, lo, hi)
         for bi in range(len(self.blocks) - 1, -1, -1):
             blk, rts = self.blocks[bi]
             x, a1, a2, xb, b1, b2 = saved[bi]
@@ -375,23 +388,28 @@ class StageEngine:
             hw_in = (x.shape[1], x.shape[2])
             hw_mid = (a1.shape[1], a1.shape[2])
             _off_path(side, lambda: self._wgrad(g, a2, rts[2]), g, a2)
+            if deferred is not None:                      # the previous block's W1 (and its hooks) ride beside this block's D3 / D2
+                dga1, dx_, drts = deferred
+                _off_path(side, lambda: self._wgrad(dga1, dx_, drts[0]), dga1, dx_)
+                hooks(drts)
+                deferred = None
             ga2 = self._dgrad(g, rts[2], (a2.shape[1], a2.shape[2]), bits=b2)
             _off_path(side, lambda: self._wgrad(ga2, a1, rts[1]), ga2, a1)
             ga1 = self._dgrad(ga2, rts[1], hw_mid, bits=b1)
-            _off_path(side, lambda: self._wgrad(ga1, x, rts[0]), ga1, x)
             if blk.down:
                 _off_path(side, lambda: self._wgrad(g, x, rts[3]), g, x)
+            if pair and not first:
+                deferred = (ga1, x, rts)
+            else:
+                _off_path(side, lambda: self._wgrad(ga1, x, rts[0]), ga1, x)
             if first and not need_dx:
                 g = None
             else:
                 skip = self._dgrad(g, rts[3], hw_in) if blk.down else g
                 g = self._dgrad(ga1, rts[0], hw_in, res=skip, bits=None if first else xb)
             saved[bi] = None                              # release activations as we go
-            if store is not None and store.grad_hooks:
-                lo, hi = store.span([rt.weight for rt in rts])
-                with torch.cuda.stream(side.stream) if side is not None else contextlib.nullcontext():
-                    for hook in store.grad_hooks:         # the all-reduce of this range is ordered after its weight gradients
-                        hook(store, lo, hi)
+            if deferred is None:
+                hooks(rts)
         if side is not None:
             side.join()                                   # the optimizer / caller sees complete gradients on its own stream
         return g

@@ -197,3 +197,10 @@ def test_gald_train_src_roundtrip(tmp_path):
     assert set(ck) == {"epoch", "iteration", "encoder", "decoder", "optimizer_enc", "optimizer_dec"} and ck["iteration"] == 3
     assert len(ck["encoder"]) == 404 and len(ck["decoder"]) == 186
     assert int(ck["encoder"]["hardnet.base.0.norm.num_batches_tracked"]) == 3
+    # evaluation through the unchanged script (reference test.py:39-40: a render json whose name starts with "gald" picks GALDTester): fp32 by default
+    r = run(["test.py", "-cfg", "configs/gald_src.yaml", "-c", "renders/cityscapes_gald.json", "OUTPUT_DIR", out, "resume", os.path.join(out, "Gald-1.pth"),
+             "INPUT.INPUT_SIZE_TEST", "(256, 224)"], {"MI_SYNTH_LEN": "2"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "Micro metric, val result: mIoU/mF1" in r.stderr + r.stdout
+    cm = json.load(open(os.path.join(out, "gald_confusion_matrix.json")))
+    assert len(cm["cmt"]) == 19 and len(cm["classes"]) == 19 and sum(map(sum, cm["cmt"])) > 0

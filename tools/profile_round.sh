@@ -14,6 +14,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv 
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $root/gpurun_out/${tag}_pmcC -o bench -- $B > $root/gpurun_out/${tag}_pmcC.log 2>&1 || echo "pmcC failed"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $root/gpurun_out/${tag}_pmcD -o bench -- $B > $root/gpurun_out/${tag}_pmcD.log 2>&1 || echo "pmcD failed"
 grep -h "^{" $root/gpurun_out/${tag}_stats.log $root/gpurun_out/${tag}_stats_1s.log | cut -c1-200
+# device copies inside the loop vs set-up copies (the review's "150 copyBuffer launches per step")
+python3 $root/tools/count_copies.py $root/gpurun_out/${tag}_stats/bench_kernel_trace.csv > $root/gpurun_out/${tag}_copies.txt 2>&1 || echo "count_copies failed"
+cat $root/gpurun_out/${tag}_copies.txt
 # the trace CSVs are large: keep only stats + counter collections
 rm -f $root/gpurun_out/${tag}_*/bench_kernel_trace.csv
 ls -la $root/gpurun_out/${tag}_*/ | head -40
