@@ -24,6 +24,12 @@
 namespace {
 
 constexpr int GBM = 128;       // pixels per tile
+// Register sets of the operand prefetch.  Three sets (a load has two K steps to arrive instead of one; -DMI_GCONV_SETS=3) were measured in round 4: the kernel then
+// holds 96 VGPRs + 96 AGPRs instead of 80 + 48, two workgroups per CU instead of four, and loses - PraNet 795 -> 731 images/s, GALD 130 -> 117 on one box.
+#ifndef MI_GCONV_SETS
+#define MI_GCONV_SETS 2
+#endif
+constexpr int GNS = MI_GCONV_SETS;
 // K chunk per main-loop step: KC = 32 channels (one MFMA k) or 64 (two; half as many steps, twice the bytes in flight per step - the main loop
 // of these small convs is bound by the round trip of a step's loads, not by the matrix pipe); LDS row stride KC + 8 elements (80 / 144 B)
 
@@ -225,20 +231,63 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
     };
     // every load and every LDS write below is issued unconditionally (past the last chunk the lanes read the zero page into a buffer nobody reads): with a
     // branch around an issue the compiler no longer knows how many loads are in flight and falls back to draining them all
-    load(0, ra0, rb0);
-    load(1, ra1, rb1);
-    stash(0, ra0, rb0);
-    __syncthreads();
-    for (int it = 0; it < total; it += 2) {
-        load(it + 2, ra0, rb0);
-        compute(0);
-        stash(1, ra1, rb1);
-        __syncthreads();
-        if (it + 1 >= total) break;
-        load(it + 3, ra1, rb1);
-        compute(1);
+    if constexpr (GNS == 2) {
+        load(0, ra0, rb0);
+        load(1, ra1, rb1);
         stash(0, ra0, rb0);
         __syncthreads();
+        for (int it = 0; it < total; it += 2) {
+            load(it + 2, ra0, rb0);
+            compute(0);
+            stash(1, ra1, rb1);
+            __syncthreads();
+            if (it + 1 >= total) break;
+            load(it + 3, ra1, rb1);
+            compute(1);
+            stash(0, ra0, rb0);
+            __syncthreads();
+        }
+    } else {
+        // three register sets: the loads of chunk c + 3 are issued while chunk c computes, i.e. a load has TWO K steps to arrive before its LDS write
+        // (two sets: one) - the K steps of these convs are bound by the round trip of their loads.  Chunk c lives in LDS buffer c % 2 and came through
+        // register set c % 3: unrolled by six so that both indices are compile-time.
+        bf16x8 ra2[2 * AQ], rb2[BROWS];
+        load(0, ra0, rb0);
+        load(1, ra1, rb1);
+        load(2, ra2, rb2);
+        stash(0, ra0, rb0);
+        __syncthreads();
+        for (int it = 0; it < total; it += 6) {
+            load(it + 3, ra0, rb0);
+            compute(0);
+            stash(1, ra1, rb1);
+            __syncthreads();
+            if (it + 1 >= total) break;
+            load(it + 4, ra1, rb1);
+            compute(1);
+            stash(0, ra2, rb2);
+            __syncthreads();
+            if (it + 2 >= total) break;
+            load(it + 5, ra2, rb2);
+            compute(0);
+            stash(1, ra0, rb0);
+            __syncthreads();
+            if (it + 3 >= total) break;
+            load(it + 6, ra0, rb0);
+            compute(1);
+            stash(0, ra1, rb1);
+            __syncthreads();
+            if (it + 4 >= total) break;
+            load(it + 7, ra1, rb1);
+            compute(0);
+            stash(1, ra2, rb2);
+            __syncthreads();
+            if (it + 5 >= total) break;
+            load(it + 8, ra2, rb2);
+            compute(1);
+            stash(0, ra0, rb0);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: (+ bias) -> LDS image of the tile -> row stores (+ column statistics of the rounded values)
