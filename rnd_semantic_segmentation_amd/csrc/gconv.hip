@@ -824,22 +824,18 @@ __global__ __launch_bounds__(256, 2) void gwgrad3_kernel(GWgP p) {
         for (int ks = 0; ks < WKP / 32; ++ks) {
             const char* sy = sy0 + row_off + ks * 32 * WRS;
             const unsigned f0 = flags[ks * 32 + prow], f1 = flags[ks * 32 + prow + 16];
-            union { bf16x8 v; s16x4 h[2]; } yf[3][2];
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int col = (wo * 32 + b * 16) * 2;
-                yf[1][b].h[0] = tr_read(sy + col);
-                yf[1][b].h[1] = tr_read(sy + col + 16 * WRS);
-                const char* z = zero_row + pc * 8 + col;
-                yf[0][b].h[0] = tr_read((f0 & 1u) ? sy + col : z);
-                yf[0][b].h[1] = tr_read((f1 & 1u) ? sy + col + 16 * WRS : z);
-                yf[2][b].h[0] = tr_read((f0 & 2u) ? sy + col : z);
-                yf[2][b].h[1] = tr_read((f1 & 2u) ? sy + col + 16 * WRS : z);
-            }
+            for (int t = 0; t < 3; ++t) {                    // one tap at a time: its dy fragments (masked for the outer taps), its x fragments, four MFMAs
+                union { bf16x8 v; s16x4 h[2]; } yf[2], xf[2];
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
+                for (int b = 0; b < 2; ++b) {
+                    const int col = (wo * 32 + b * 16) * 2;
+                    const char* z = zero_row + pc * 8 + col;
+                    const bool v0 = t == 1 || (f0 & (t == 0 ? 1u : 2u)), v1 = t == 1 || (f1 & (t == 0 ? 1u : 2u));
+                    yf[b].h[0] = tr_read(v0 ? sy + col : z);
+                    yf[b].h[1] = tr_read(v1 ? sy + col + 16 * WRS : z);
+                }
                 const char* sx = sx0 + row_off + ks * 32 * WRS + t * dwrs;
-                union { bf16x8 v; s16x4 h[2]; } xf[2];
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
                     const char* base = sx + (wi * 32 + a * 16) * 2;
@@ -849,7 +845,7 @@ __global__ __launch_bounds__(256, 2) void gwgrad3_kernel(GWgP p) {
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) acc[t][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[a].v, yf[t][b].v, acc[t][a][b], 0, 0, 0);
+                    for (int b = 0; b < 2; ++b) acc[t][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[a].v, yf[b].v, acc[t][a][b], 0, 0, 0);
             }
         }
     };
