@@ -468,8 +468,18 @@ def main():
             if dom == "bn_kernels":      # MODEL.FREEZE_BN False: the elementwise BatchNorm passes together outweigh any one conv kernel - HBM-bound
                 passes = {0: 1, 1: 2, 2: 2, 3: 3, 4: 1}       # tensor passes of [M, C] bf16 per op (sums 1-2 reads, normalise read + write, input gradient 2 reads + write)
                 nbytes = sum(passes[t[1]] * t[4] * t[2] * 2.0 for nm, _, _, _, t in events if nm == "bn_kernels")
+                bn_traffic, bn_src = None, None
+                try:                 # counters of the BatchNorm kernel classes (profiles/pmc_deeplab_bn.json, tools/profile_aux.sh): HBM bytes per launch, averaged over the classes
+                    pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_deeplab_bn.json")))
+                    cls = {k: v for k, v in pj.items() if k != "_meta" and ("bn_apply" in k or "bn_bwd_apply" in k or "bn_partial" in k)}
+                    gb, ln = sum(v["hbm_gb_per_step"] for v in cls.values()), sum(v["launches_per_step"] for v in cls.values())
+                    bn_traffic = round(gb * 1e9 / ln)
+                    bn_src = {"file": "profiles/pmc_deeplab_bn.json", "classes": sorted(cls), "hbm_gb_per_step": round(gb, 2), "profiled_commit": pj["_meta"].get("commit"),
+                              "hbm_frac_of_peak": {k: v.get("hbm_frac_of_peak") for k, v in cls.items()}}
+                except (OSError, KeyError, ValueError, ZeroDivisionError):
+                    pass
                 out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(nbytes / tsec / 1e12, 3), "peak": PEAK_HBM_TBS, "unit": "TB/s",
-                                   "frac": round(nbytes / tsec / 1e12 / PEAK_HBM_TBS, 4), "traffic": None, "launches_per_step": n // inst_steps,
+                                   "frac": round(nbytes / tsec / 1e12 / PEAK_HBM_TBS, 4), "traffic": bn_traffic, "traffic_source": bn_src, "launches_per_step": n // inst_steps,
                                    "avg_launch_us": round(1e6 * tsec / n, 2), "ms_per_step_in_kernel": round(1e3 * tsec / inst_steps, 3),
                                    "alg_gbytes_per_step": round(nbytes / inst_steps / 1e9, 2),
                                    "note": "the normalise / backward-sums / input-gradient passes of trainable BatchNorm2d (csrc/batchnorm.hip): algorithmic bytes = "
