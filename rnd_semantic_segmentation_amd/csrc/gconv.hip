@@ -379,45 +379,33 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
                     st[p.N + n0 + tid] = s2;
                 }
             }
+            if constexpr (BN <= 64) {
             if (p.fin_out) {
-                // The column tile's last workgroup turns the row tiles' sums into mean / invstd / folded affine and updates the running statistics:
-                // mi_gbn_finalize's arithmetic in its order (32 lanes take the tiles t = lane, lane + 32, ..., the lanes are added in order, double),
-                // one thread per channel - the same bits as the separate launch, which these small convs no longer pay (6 us + a launch boundary each).
+                // The column tile's last workgroup turns the row tiles' sums into mean / invstd / folded affine and updates the running statistics with
+                // mi_gbn_finalize's arithmetic in its order - for at most 128 row tiles every tile is its own lane and the lanes are added in ascending order
+                // (double): the same bits as the separate launch.  The loads of a channel are spread over the L = 256 / BN threads that share it (a few
+                // independent loads each, no register arrays that would cost the main loop its occupancy) and meet in LDS, one statistic at a time
+                // ([64][BN] floats: 16 KB at BN = 64); one thread per channel adds them.
                 if (mi_last_arriver(p.fin_ticket + blockIdx.y, gridDim.x, reinterpret_cast<int*>(smem))) {
                     mi_acquire_partials();
-                    // phase A: thread (channel, lane j of L = 256 / BN) forms the partial sums of the strided lanes ry = j, j + L, ... (each lane: the
-                    // tiles ry and ry + 32) - a handful of independent loads per thread, no register arrays that would cost the main loop its occupancy;
-                    // phase B: one thread per channel adds the 32 lanes in order (doubles through LDS, one statistic at a time: 16 KB at BN = 64)
-                    constexpr int L = 256 / BN > 0 ? 256 / BN : 1;
-                    double* lanes = reinterpret_cast<double*>(smem + 16);                     // [32][BN]
+                    constexpr int L = 256 / BN;
+                    float* lanes = reinterpret_cast<float*>(smem + 16);                       // [MI_INLAUNCH_MAX_PARTS][BN]
                     const int ch = tid % BN, j = tid / BN, tiles = gridDim.x;
                     const int cc = n0 + ch;
                     double tot[2] = {0.0, 0.0};
 #pragma unroll
                     for (int which = 0; which < 2; ++which) {
-                        if (j < L && cc < p.N) {
-                            float v0[32 / L], v1[32 / L];
+                        if (cc < p.N) {
 #pragma unroll
-                            for (int q = 0; q < 32 / L; ++q) {
-                                const int ry = j + q * L;
-                                const int t0 = ry < tiles ? ry : tiles - 1, t1 = ry + 32 < tiles ? ry + 32 : tiles - 1;
-                                v0[q] = p.stats[(long)t0 * 2 * p.N + which * p.N + cc];
-                                v1[q] = p.stats[(long)t1 * 2 * p.N + which * p.N + cc];
-                            }
-#pragma unroll
-                            for (int q = 0; q < 32 / L; ++q) {
-                                const int ry = j + q * L;
-                                double a = 0.0;
-                                if (ry < tiles) a += (double)v0[q];
-                                if (ry + 32 < tiles) a += (double)v1[q];
-                                lanes[ry * BN + ch] = a;
+                            for (int q = 0; q < MI_INLAUNCH_MAX_PARTS / L; ++q) {
+                                const int t = j + q * L;
+                                lanes[t * BN + ch] = p.stats[(long)(t < tiles ? t : tiles - 1) * 2 * p.N + which * p.N + cc];
                             }
                         }
                         __syncthreads();
                         if (tid < BN && n0 + tid < p.N) {
                             double sum = 0.0;
-#pragma unroll
-                            for (int ry = 0; ry < 32; ++ry) sum += lanes[ry * BN + tid];
+                            for (int t = 0; t < tiles; ++t) sum += (double)lanes[t * BN + tid];
                             tot[which] = sum;
                         }
                         __syncthreads();
@@ -442,6 +430,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
                         }
                     }
                 }
+            }
             }
         }
     }
@@ -1067,7 +1056,7 @@ static int gconv_impl(const void* a, long lda, const void* wp, void* out, long l
         glaunch_k<32>(p, avec, 1, true, s);
     } else if (N <= 32) glaunch_k<32>(p, avec, ovec, false, s);
     else if (mt * ((N + 63) / 64) < 256) glaunch_k<32>(p, avec, ovec, false, s);          // few pixels (1/32 resolution): narrower tiles, more workgroups
-    else if (N <= 64 || N % 128 == 64 || mt * ((N + 127) / 128) < 512 || !mi_sw().gconv_bn128) glaunch_k<64>(p, avec, ovec, false, s);
+    else if (N <= 64 || N % 128 == 64 || mt * ((N + 127) / 128) < 512 || !mi_sw().gconv_bn128 || fin) glaunch_k<64>(p, avec, ovec, false, s);      // (the in-launch finalize lives in the 32- / 64-wide instances)
     else glaunch_k<128>(p, avec, ovec, false, s);
     MI_CHECK_LAUNCH("gconv_kernel");
     return MI_OK;

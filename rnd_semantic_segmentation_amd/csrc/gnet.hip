@@ -90,27 +90,31 @@ inline int common_vec(int C, std::initializer_list<std::pair<const void*, long>>
 // partials[tile][2][C] (sum, sum of squares per 128-pixel tile, written by gconv_kernel) -> batch mean / biased variance in double,
 // invstd, the folded affine (scale = gamma * invstd, shift = beta - mean * scale) and torch's running-statistics update
 // (momentum m: running = (1 - m) * running + m * batch, unbiased variance for running_var; nn.BatchNorm2d defaults).
+// Two channels x 128 tile lanes per workgroup: a lane adds the tiles t = lane, lane + 128, ... (its loads independent), the 128 lane sums are added in
+// lane order by one thread per channel (double).  (Round 3 used 8 channels x 32 lanes: 30 dependent round trips per thread on the 968-tile maps, 6 - 12 us per
+// launch for a few KB of data - 153 launches per PraNet step.)  The in-launch finalize of gconv.hip replays this order (tiles <= 64: plain ascending sum).
+constexpr int FIN_LANES = 128;
 __global__ __launch_bounds__(256) void gbn_finalize_kernel(const float* partials, int tiles, int C, double count, const float* gamma, const float* beta,
                                                            float* running_mean, float* running_var, float momentum, float eps, float* mean_out,
                                                            float* invstd_out, float* scale_out, float* shift_out) {
-    __shared__ double red[2][32][8];
-    const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;          // 8 channels x 32 tile lanes: short serial chains, the loads of a lane independent
-    const int c = blockIdx.x * 8 + cx;
+    __shared__ double red[2][2][FIN_LANES];
+    const int cx = threadIdx.x / FIN_LANES, ry = threadIdx.x % FIN_LANES;
+    const int c = blockIdx.x * 2 + cx;
     double s1 = 0.0, s2 = 0.0;
     if (c < C)
-        for (int t = ry; t < tiles; t += 32) {
+        for (int t = ry; t < tiles; t += FIN_LANES) {
             s1 += (double)partials[(long)t * 2 * C + c];
             s2 += (double)partials[(long)t * 2 * C + C + c];
         }
-    red[0][ry][cx] = s1;
-    red[1][ry][cx] = s2;
+    red[0][cx][ry] = s1;
+    red[1][cx][ry] = s2;
     __syncthreads();
     if (ry == 0 && c < C) {
         s1 = s2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            s1 += red[0][k][cx];
-            s2 += red[1][k][cx];
+        const int live = tiles < FIN_LANES ? tiles : FIN_LANES;
+        for (int k = 0; k < live; ++k) {
+            s1 += red[0][cx][k];
+            s2 += red[1][cx][k];
         }
         const double mean = s1 / count;
         double var = s2 / count - mean * mean;
@@ -280,26 +284,27 @@ __global__ __launch_bounds__(256) void gcolsum_partial_kernel(const TG* g, long 
     }
 }
 
-// out1[c] (+)= sum over blocks of partial[blk][0][c], out2 likewise (ascending block order within a lane, lanes combined in order; double)
+// out1[c] (+)= sum over blocks of partial[blk][0][c], out2 likewise: two channels x 128 block lanes per workgroup (lane l adds the blocks l, l + 128, ...; the
+// lane sums are added in lane order; double) - see gbn_finalize_kernel for why not 8 x 32
 __global__ __launch_bounds__(256) void gcolsum_final_kernel(const float* partial, int blocks, int C, float* out1, float* out2, int accumulate) {
-    __shared__ double red[2][32][8];
-    const int cx = threadIdx.x & 7, ry = threadIdx.x >> 3;
-    const int c = blockIdx.x * 8 + cx;
+    __shared__ double red[2][2][FIN_LANES];
+    const int cx = threadIdx.x / FIN_LANES, ry = threadIdx.x % FIN_LANES;
+    const int c = blockIdx.x * 2 + cx;
     double s1 = 0.0, s2 = 0.0;
     if (c < C)
-        for (int b = ry; b < blocks; b += 32) {
+        for (int b = ry; b < blocks; b += FIN_LANES) {
             s1 += (double)partial[((long)b * 2 + 0) * C + c];
             s2 += (double)partial[((long)b * 2 + 1) * C + c];
         }
-    red[0][ry][cx] = s1;
-    red[1][ry][cx] = s2;
+    red[0][cx][ry] = s1;
+    red[1][cx][ry] = s2;
     __syncthreads();
     if (ry == 0 && c < C) {
         s1 = s2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            s1 += red[0][k][cx];
-            s2 += red[1][k][cx];
+        const int live = blocks < FIN_LANES ? blocks : FIN_LANES;
+        for (int k = 0; k < live; ++k) {
+            s1 += red[0][cx][k];
+            s2 += red[1][cx][k];
         }
         if (out1) out1[c] = accumulate ? out1[c] + (float)s1 : (float)s1;
         if (out2) out2[c] = accumulate ? out2[c] + (float)s2 : (float)s2;
@@ -937,7 +942,7 @@ int mi_gbn_finalize(const float* partials, int tiles, int C, long count, const f
     MI_REQUIRE(partials && mean_out && invstd_out && scale_out && shift_out, "mi_gbn_finalize: null operand");
     MI_REQUIRE(tiles > 0 && C > 0 && count > 0, "mi_gbn_finalize: empty shape");
     MI_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "mi_gbn_finalize: running_mean and running_var come together");
-    hipLaunchKernelGGL(gbn_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, partials, tiles, C, (double)count, gamma, beta,
+    hipLaunchKernelGGL(gbn_finalize_kernel, dim3((C + 1) / 2), dim3(256), 0, (hipStream_t)stream, partials, tiles, C, (double)count, gamma, beta,
                        running_mean, running_var, momentum, eps, mean_out, invstd_out, scale_out, shift_out);
     MI_CHECK_LAUNCH("gbn_finalize_kernel");
     return MI_OK;
@@ -994,7 +999,7 @@ int mi_gbn_bwd_sums(const void* g, long ldg, int g_f32, const void* y, long ldy,
     else CSK(1, __bf16, __bf16);
 #undef CSK
     MI_CHECK_LAUNCH("gcolsum_partial_kernel");
-    hipLaunchKernelGGL(gcolsum_final_kernel, dim3((C + 7) / 8), dim3(256), 0, s, part, blocks, C, dbeta, dgamma, accumulate);
+    hipLaunchKernelGGL(gcolsum_final_kernel, dim3((C + 1) / 2), dim3(256), 0, s, part, blocks, C, dbeta, dgamma, accumulate);
     MI_CHECK_LAUNCH("gcolsum_final_kernel");
     return MI_OK;
 }
