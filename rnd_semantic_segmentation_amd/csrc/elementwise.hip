@@ -38,6 +38,7 @@ const MiSwitches& mi_sw() {
         sw.wgrad_s4 = env("MI_WGRAD_S4", 1);
         sw.gconv_bn128 = env("MI_GCONV_BN128", 0);
         sw.gconv_kc = env("MI_GCONV_KC", 0);
+        sw.gconv_remap = env("MI_GCONV_REMAP", 1);
         sw.gwgrad3 = env("MI_GWGRAD3", 1);
         sw.p3_dbg = env("MI_P3_DBG", 0);
         sw.pp_trace_wg = env("MI_PP_TRACE_WG", 0);

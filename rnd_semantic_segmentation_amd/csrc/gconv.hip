@@ -24,12 +24,11 @@
 namespace {
 
 constexpr int GBM = 128;       // pixels per tile
-// Register sets of the operand prefetch.  Three sets (a load has two K steps to arrive instead of one; -DMI_GCONV_SETS=3) were measured in round 4: the kernel then
-// holds 96 VGPRs + 96 AGPRs instead of 80 + 48, two workgroups per CU instead of four, and loses - PraNet 795 -> 731 images/s, GALD 130 -> 117 on one box.
-#ifndef MI_GCONV_SETS
-#define MI_GCONV_SETS 2
-#endif
-constexpr int GNS = MI_GCONV_SETS;
+// Two register sets of operand prefetch: a K step stashes the next chunk into LDS while the chunk after next is in flight.  More sets do not pay: three
+// sets everywhere (96 VGPRs + 96 AGPRs instead of 80 + 48, two workgroups per CU instead of four) took PraNet 795 -> 731 images/s and GALD 130 -> 117,
+// four sets for the launches of at most two workgroups per CU (three K steps for a load to arrive) 819 -> 810: a K step of these launches is not
+// waiting for its loads but for its own serial chain (LDS write -> barrier -> LDS read -> MFMAs -> ~85 address instructions), 600-800 ns with one
+// workgroup per CU (tools/gkshape.py).
 // K chunk per main-loop step: KC = 32 channels (one MFMA k) or 64 (two; half as many steps, twice the bytes in flight per step - the main loop
 // of these small convs is bound by the round trip of a step's loads, not by the matrix pipe); LDS row stride KC + 8 elements (80 / 144 B)
 
@@ -42,7 +41,7 @@ struct GConvP {
     long lda, ldo;
     int M, N, Ca, Cpad, Npad, T;
     int Ha, Wa, Ho, Wo;
-    int kw, sh, sw, ph, pw, dh, dw, mode, nchunks;
+    int kw, sh, sw, ph, pw, dh, dw, mode, nchunks, remap;
     // in-launch BatchNorm finalize (fin_out != null; the launch has at most MI_INLAUNCH_MAX_PARTS row tiles): the arguments of mi_gbn_finalize
     unsigned* fin_ticket;      // one zeroed word per column tile
     float* fin_out;            // [4][N]: mean, invstd, scale, shift
@@ -69,12 +68,15 @@ __device__ __forceinline__ bf16x8 gload8_a4(const __bf16* src, int c0, int C, bo
     const int rem = C - c0;
     const bool live = ok && rem > 0, part = live && rem < 8;
     const __bf16* ptr = live ? (part ? src + C - 8 : src + c0) : reinterpret_cast<const __bf16*>(g_gzero);
-    u32x4 v = *reinterpret_cast<const u32x4_a4*>(ptr);
-    if (part) {
-        const int drop = (8 - rem) >> 1;          // dwords of the window that belong to channels below c0
-        v = drop == 1 ? u32x4{v[1], v[2], v[3], 0u} : (drop == 2 ? u32x4{v[2], v[3], 0u, 0u} : u32x4{v[3], 0u, 0u, 0u});
-    }
-    return __builtin_bit_cast(bf16x8, v);
+    const u32x4 v = *reinterpret_cast<const u32x4_a4*>(ptr);
+    // (selects, no branch: control flow between a load and its use costs the main loop its load counting)
+    const int drop = part ? (8 - rem) >> 1 : 0;          // dwords of the window that belong to channels below c0
+    u32x4 r;
+    r[0] = drop == 0 ? v[0] : (drop == 1 ? v[1] : (drop == 2 ? v[2] : v[3]));
+    r[1] = drop == 0 ? v[1] : (drop == 1 ? v[2] : (drop == 2 ? v[3] : 0u));
+    r[2] = drop == 0 ? v[2] : (drop == 1 ? v[3] : 0u);
+    r[3] = drop == 0 ? v[3] : 0u;
+    return __builtin_bit_cast(bf16x8, r);
 }
 
 template <int VEC>
@@ -110,14 +112,26 @@ struct GSmem {
     static constexpr int BYTES = (AB > CS + RED ? AB : CS + RED);
 };
 
-template <int BN, int KC, int AVEC, int OVEC, bool OUTF32>
+template <int BN, int KC, int AVEC, int OVEC, bool OUTF32, bool GEN = false>
 __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
     constexpr int NT = BN / 16, GRS = KC + 8, AQ = KC / 32;
     __shared__ __attribute__((aligned(16))) char smem[GSmem<BN, KC, OUTF32>::BYTES];
     __bf16* As = reinterpret_cast<__bf16*>(smem);                         // [2][GBM][GRS]
     __bf16* Bs = As + 2 * GBM * GRS;                                      // [2][BN][GRS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * GBM, n0 = blockIdx.y * BN;
+    // Tile order: the hardware dispatches workgroups x-fastest and round-robin over the 8 XCDs (each with its own L2).  Remapped so that one XCD
+    // owns a CONTIGUOUS run of row tiles and walks the column tiles of a row tile back to back: the column tiles' re-reads of the A rows and the
+    // halo rows that neighbouring row tiles of a 3x3 share are served by that XCD's L2 instead of being fetched once per XCD (MI_GCONV_REMAP=0:
+    // the plain (x, y) order).
+    int mt = blockIdx.x, nt = blockIdx.y;
+    const int m_tiles = gridDim.x;
+    if (p.remap) {
+        const int n_tiles = gridDim.y;
+        const int logical = mi_xcd_remap(blockIdx.y * m_tiles + blockIdx.x, m_tiles * n_tiles);
+        mt = logical / n_tiles;
+        nt = logical - mt * n_tiles;
+    }
+    const int m0 = mt * GBM, n0 = nt * BN;
 
     // A loader: thread -> (row, half): KC / 2 channels of one pixel per K chunk
     const int arow = tid >> 1, ahalf = tid & 1;
@@ -141,45 +155,48 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
     // load() is called for it = 0, 1, 2, ... in order: (tap, chunk, ky, kx) advance with it instead of being divided out of it on every call
     // (counters of one launch: 113 VALU + 143 SALU instructions per wave and K step beside 16 MFMAs - the waves were issuing index arithmetic half
     // of their time)
+    // The main loop below is ONE basic block: every tap / chunk counter update, every padding test and every tail is a select, never a branch.
+    // With control flow in the loop (the first version: mode and stride branches around the address arithmetic, a predicated LDS write, a second
+    // loop exit) hipcc split it into 20 blocks, shuffled the accumulators through VGPRs at the block boundaries and - those VGPRs being load
+    // destinations - put s_waitcnt vmcnt(0) at the loop header: the prefetch in flight was drained every second K step.
+    // GEN = false: source pixel = base + tap * step (forward with any stride; data gradient of a stride-1 conv);  GEN = true: data gradient of a
+    // strided conv (the tap's source exists only where the division is exact).
     int l_tap = 0, l_kc = 0, l_ky = 0, l_kx = 0;
-    const bool unit_stride = p.sh == 1 && p.sw == 1;
+    const bool fwd = p.mode == MI_GATHER_FWD;
+    const int th = fwd ? p.dh : -p.dh, tw = fwd ? p.dw : -p.dw;
+    const int base_h = fwd ? aoh * p.sh - p.ph : aoh + p.ph, base_w = fwd ? aow * p.sw - p.pw : aow + p.pw;
     long boff[BROWS];                                      // this thread's weight rows: offset inside a tap's [Npad][Cpad] plane, channel offset, row in range
     int bch8[BROWS];
     bool brow_ok[BROWS];
 #pragma unroll
     for (int j = 0; j < BROWS; ++j) {
-        const int idx = tid + j * 256;
+        const int idx = (tid + j * 256) % BLOADS;          // (BLOADS < 256: the upper threads repeat the lower threads' chunks - same value to the same LDS address)
         const int nr = idx / BCH, ch = idx - nr * BCH;
         bch8[j] = ch * 8;
-        brow_ok[j] = idx < BLOADS && n0 + nr < p.Npad;
+        brow_ok[j] = n0 + nr < p.Npad;
         boff[j] = (long)(n0 + nr) * p.Cpad + ch * 8;
     }
     auto load = [&](int it, bf16x8 (&ra)[2 * AQ], bf16x8 (&rb)[BROWS]) {
         const bool live = it < total;                  // past the end: every lane reads the zero page (cheap, and keeps the issue unconditional)
         const int tap = l_tap, kc = l_kc, ky = l_ky, kx = l_kx;
-        if (++l_kc == p.nchunks) {
-            l_kc = 0;
-            ++l_tap;
-            if (++l_kx == p.kw) l_kx = 0, ++l_ky;
+        {
+            const bool wrap = l_kc + 1 == p.nchunks;
+            const bool roww = wrap && l_kx + 1 == p.kw;
+            l_kc = wrap ? 0 : l_kc + 1;
+            l_tap += wrap ? 1 : 0;
+            l_kx = roww ? 0 : (wrap ? l_kx + 1 : l_kx);
+            l_ky += roww ? 1 : 0;
         }
-        bool ok = am_ok && live;
-        int ih, iw;
-        if (p.mode == MI_GATHER_FWD) {
-            ih = aoh * p.sh + ky * p.dh - p.ph;
-            iw = aow * p.sw + kx * p.dw - p.pw;
-        } else {
-            const int nh = aoh + p.ph - ky * p.dh, nw = aow + p.pw - kx * p.dw;
-            if (unit_stride) {                             // (negative nh / nw fail the unsigned range test below)
-                ih = nh;
-                iw = nw;
-            } else {
-                ih = nh / p.sh;
-                iw = nw / p.sw;
-                ok = ok && nh >= 0 && nw >= 0 && ih * p.sh == nh && iw * p.sw == nw;
-            }
+        bool ok = am_ok & live;                        // (& not &&: a short-circuit chain becomes branches)
+        int ih = base_h + ky * th, iw = base_w + kx * tw;
+        if constexpr (GEN) {
+            const int nh = ih, nw = iw;
+            ih = nh / p.sh;
+            iw = nw / p.sw;
+            ok = ok & (nh >= 0) & (nw >= 0) & (ih * p.sh == nh) & (iw * p.sw == nw);
         }
-        ok = ok && (unsigned)ih < (unsigned)p.Ha && (unsigned)iw < (unsigned)p.Wa;
-        const long pix = ok ? ((long)ab * p.Ha + ih) * p.Wa + iw : 0;
+        ok = ok & ((unsigned)ih < (unsigned)p.Ha) & ((unsigned)iw < (unsigned)p.Wa);
+        const long pix = ((long)ab * p.Ha + min(max(ih, 0), p.Ha - 1)) * p.Wa + min(max(iw, 0), p.Wa - 1);       // always a real pixel; !ok lanes read the zero page
 #pragma unroll
         for (int q = 0; q < AQ; ++q) {
             bf16x8 two[2];
@@ -200,9 +217,9 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
         for (int q = 0; q < 2 * AQ; ++q) *reinterpret_cast<bf16x8*>(a + 8 * q) = ra[q];
 #pragma unroll
         for (int j = 0; j < BROWS; ++j) {
-            const int idx = tid + j * 256;
+            const int idx = (tid + j * 256) % BLOADS;
             const int nr = idx / BCH, ch = idx - nr * BCH;
-            if (idx < BLOADS) *reinterpret_cast<bf16x8*>(Bs + buf * BN * GRS + nr * GRS + ch * 8) = rb[j];
+            *reinterpret_cast<bf16x8*>(Bs + buf * BN * GRS + nr * GRS + ch * 8) = rb[j];
         }
     };
 
@@ -231,60 +248,24 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
     };
     // every load and every LDS write below is issued unconditionally (past the last chunk the lanes read the zero page into a buffer nobody reads): with a
     // branch around an issue the compiler no longer knows how many loads are in flight and falls back to draining them all
-    if constexpr (GNS == 2) {
+    // (the step count is rounded up to the unroll factor: a step past the last chunk multiplies zero-page operands - cheaper than a second loop exit;
+    //  sched_barrier: left alone, hipcc sinks a step's loads below its MFMAs, i.e. right in front of the wait for them)
+    {
         load(0, ra0, rb0);
         load(1, ra1, rb1);
         stash(0, ra0, rb0);
         __syncthreads();
         for (int it = 0; it < total; it += 2) {
             load(it + 2, ra0, rb0);
+            __builtin_amdgcn_sched_barrier(0);
             compute(0);
+            __builtin_amdgcn_sched_barrier(0);
             stash(1, ra1, rb1);
             __syncthreads();
-            if (it + 1 >= total) break;
             load(it + 3, ra1, rb1);
+            __builtin_amdgcn_sched_barrier(0);
             compute(1);
-            stash(0, ra0, rb0);
-            __syncthreads();
-        }
-    } else {
-        // three register sets: the loads of chunk c + 3 are issued while chunk c computes, i.e. a load has TWO K steps to arrive before its LDS write
-        // (two sets: one) - the K steps of these convs are bound by the round trip of their loads.  Chunk c lives in LDS buffer c % 2 and came through
-        // register set c % 3: unrolled by six so that both indices are compile-time.
-        bf16x8 ra2[2 * AQ], rb2[BROWS];
-        load(0, ra0, rb0);
-        load(1, ra1, rb1);
-        load(2, ra2, rb2);
-        stash(0, ra0, rb0);
-        __syncthreads();
-        for (int it = 0; it < total; it += 6) {
-            load(it + 3, ra0, rb0);
-            compute(0);
-            stash(1, ra1, rb1);
-            __syncthreads();
-            if (it + 1 >= total) break;
-            load(it + 4, ra1, rb1);
-            compute(1);
-            stash(0, ra2, rb2);
-            __syncthreads();
-            if (it + 2 >= total) break;
-            load(it + 5, ra2, rb2);
-            compute(0);
-            stash(1, ra0, rb0);
-            __syncthreads();
-            if (it + 3 >= total) break;
-            load(it + 6, ra0, rb0);
-            compute(1);
-            stash(0, ra1, rb1);
-            __syncthreads();
-            if (it + 4 >= total) break;
-            load(it + 7, ra1, rb1);
-            compute(0);
-            stash(1, ra2, rb2);
-            __syncthreads();
-            if (it + 5 >= total) break;
-            load(it + 8, ra2, rb2);
-            compute(1);
+            __builtin_amdgcn_sched_barrier(0);
             stash(0, ra0, rb0);
             __syncthreads();
         }
@@ -370,7 +351,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
                     s1 += red[(g * 2 + 0) * BN + tid];
                     s2 += red[(g * 2 + 1) * BN + tid];
                 }
-                float* st = p.stats + (long)blockIdx.x * 2 * p.N;
+                float* st = p.stats + (long)mt * 2 * p.N;
                 if (p.fin_out) {                       // handed to the launch's last workgroup: write-through
                     mi_st_sc1(st + n0 + tid, s1);
                     mi_st_sc1(st + p.N + n0 + tid, s2);
@@ -386,11 +367,11 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
                 // (double): the same bits as the separate launch.  The loads of a channel are spread over the L = 256 / BN threads that share it (a few
                 // independent loads each, no register arrays that would cost the main loop its occupancy) and meet in LDS, one statistic at a time
                 // ([64][BN] floats: 16 KB at BN = 64); one thread per channel adds them.
-                if (mi_last_arriver(p.fin_ticket + blockIdx.y, gridDim.x, reinterpret_cast<int*>(smem))) {
+                if (mi_last_arriver(p.fin_ticket + nt, m_tiles, reinterpret_cast<int*>(smem))) {
                     mi_acquire_partials();
                     constexpr int L = 256 / BN;
                     float* lanes = reinterpret_cast<float*>(smem + 16);                       // [MI_INLAUNCH_MAX_PARTS][BN]
-                    const int ch = tid % BN, j = tid / BN, tiles = gridDim.x;
+                    const int ch = tid % BN, j = tid / BN, tiles = m_tiles;
                     const int cc = n0 + ch;
                     double tot[2] = {0.0, 0.0};
 #pragma unroll
@@ -439,6 +420,10 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
 template <int BN, int KC, int AVEC, int OVEC, bool OUTF32>
 void glaunch(const GConvP& p, hipStream_t s) {
     dim3 grid((p.M + GBM - 1) / GBM, (p.N + BN - 1) / BN);
+    if (p.mode != MI_GATHER_FWD && (p.sh != 1 || p.sw != 1)) {                     // data gradient of a strided conv: the general source map
+        hipLaunchKernelGGL((gconv_kernel<BN, KC, AVEC, OVEC, OUTF32, true>), grid, dim3(256), 0, s, p);
+        return;
+    }
     hipLaunchKernelGGL((gconv_kernel<BN, KC, AVEC, OVEC, OUTF32>), grid, dim3(256), 0, s, p);
 }
 
@@ -498,7 +483,7 @@ struct GWgP {
     int S, rows_per_split, o_tiles, i_tiles;
     unsigned* ticket;      // in-launch reduction (S <= GW_INLAUNCH_S): one zeroed word per (tap, output tile); else null
     float* dwout;
-    int accumulate;
+    int accumulate, remap;
 };
 constexpr int GW_INLAUNCH_S = 16;      // K splits the last workgroup of a tile adds itself (64 KB of slabs at most); more: the reducer launch
 
@@ -528,7 +513,7 @@ __global__ __launch_bounds__(256, 4) void gwgrad_kernel(GWgP p) {       // four 
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * WKP * WRS];      // [buf][dy | x][64 pixels][144 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles = p.o_tiles * p.i_tiles;
-    int id = blockIdx.x;
+    int id = p.remap ? mi_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;      // the (tile, tap) workgroups of a pixel split share its dy / x rows: keep them on one XCD's L2
     const int tile = id % tiles;
     id /= tiles;
     const int t = id % p.T, split = id / p.T;
@@ -553,7 +538,10 @@ __global__ __launch_bounds__(256, 4) void gwgrad_kernel(GWgP p) {       // four 
         coh[h] = rem / p.Wo;
         cow[h] = rem - coh[h] * p.Wo;
     }
-    const int step_rows = WKP / p.Wo, step_cols = WKP - step_rows * p.Wo;
+    // (selects only - the main loop stays one basic block, see gconv_kernel: a 64-pixel step is step_imgs images + step_rows rows + step_cols columns
+    //  with step_rows < Ho, so every coordinate wraps at most once per step)
+    const int step_imgs = WKP / hw, step_rem = WKP - step_imgs * hw;
+    const int step_rows = step_rem / p.Wo, step_cols = step_rem - step_rows * p.Wo;
     auto load = [&](int kt, bf16x8 (&ry)[2], bf16x8 (&rx)[2]) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -561,14 +549,19 @@ __global__ __launch_bounds__(256, 4) void gwgrad_kernel(GWgP p) {       // four 
             const bool ok = m < m_end;                 // (a step past the last one has every row >= m_end: zero-page reads)
             ry[h] = gload8<YVEC>(p.dY + (long)(ok ? m : 0) * p.ldy, o0 + lch * 8, p.O, ok);
             const int b = cb[h], oh = coh[h], ow = cow[h];
-            cow[h] += step_cols;
-            coh[h] += step_rows;
-            if (cow[h] >= p.Wo) cow[h] -= p.Wo, ++coh[h];
-            while (coh[h] >= p.Ho) coh[h] -= p.Ho, ++cb[h];
+            {
+                const int w1 = cow[h] + step_cols;
+                const bool cw = w1 >= p.Wo;
+                cow[h] = cw ? w1 - p.Wo : w1;
+                const int h1 = coh[h] + step_rows + (cw ? 1 : 0);
+                const bool ch = h1 >= p.Ho;
+                coh[h] = ch ? h1 - p.Ho : h1;
+                cb[h] += step_imgs + (ch ? 1 : 0);
+            }
             const int ih = oh * p.sh + ky * p.dh - p.ph, iw = ow * p.sw + kx * p.dw - p.pw;
-            const bool xok = ok && (unsigned)ih < (unsigned)p.Ha && (unsigned)iw < (unsigned)p.Wa;
-            const long pix = xok ? ((long)b * p.Ha + ih) * p.Wa + iw : 0;
-            rx[h] = gload8<XVEC>(p.X + pix * p.ldx, i0 + lch * 8, p.I, xok);
+            const bool xok = ok & ((unsigned)ih < (unsigned)p.Ha) & ((unsigned)iw < (unsigned)p.Wa);
+            const long pix = ((long)b * p.Ha + min(max(ih, 0), p.Ha - 1)) * p.Wa + min(max(iw, 0), p.Wa - 1);        // always a real pixel; !xok lanes read the zero page
+            rx[h] = gload8<XVEC>(p.X + (ok ? pix : 0) * p.ldx, i0 + lch * 8, p.I, xok);
         }
     };
     auto stash = [&](int buf, const bf16x8 (&ry)[2], const bf16x8 (&rx)[2]) {
@@ -617,18 +610,23 @@ __global__ __launch_bounds__(256, 4) void gwgrad_kernel(GWgP p) {       // four 
         }
     };
     if (nk > 0) {
+        // (steps rounded up to two: a step past the split's last one multiplies zero-page operands - cheaper than a second loop exit; sched_barrier:
+        //  left alone hipcc sinks a step's loads below its MFMAs, right in front of the wait for them)
         load(0, ry0, rx0);
         load(1, ry1, rx1);
         stash(0, ry0, rx0);
         __syncthreads();
         for (int kt = 0; kt < nk; kt += 2) {
             load(kt + 2, ry0, rx0);
+            __builtin_amdgcn_sched_barrier(0);
             compute(0);
+            __builtin_amdgcn_sched_barrier(0);
             stash(1, ry1, rx1);
             __syncthreads();
-            if (kt + 1 >= nk) break;
             load(kt + 3, ry1, rx1);
+            __builtin_amdgcn_sched_barrier(0);
             compute(1);
+            __builtin_amdgcn_sched_barrier(0);
             stash(0, ry0, rx0);
             __syncthreads();
         }
@@ -711,14 +709,16 @@ __global__ __launch_bounds__(256, 4) void gwgrad_kernel(GWgP p) {       // four 
 // pmc_pranet.json): the per-tap kernel moved 32.6 / 13.3 GB of HBM per step (GALD / PraNet), its L2 hit rate 0.57 / 0.42 - nine re-reads of dy and x.
 constexpr int W3_MAXD = 8;                                  // largest column dilation the window holds
 constexpr int W3_XROWS = WKP + 2 * W3_MAXD;                 // 80 pixel rows of x per stage
-constexpr int W3_STAGE = (W3_XROWS + WKP) * WRS + 64;       // x window | dy tile | 64 flag bytes
+constexpr int W3_STAGE = (W3_XROWS + WKP) * WRS + 64 + 2 * WRS;      // x window | dy tile | 64 flag bytes | dummy area (target of the loader's out-of-window writes)
+constexpr int W3_DUMMY_ROW = ((W3_XROWS + WKP) * WRS + 64 + WRS - 1) / WRS;      // the whole row that lies inside the dummy area, counted from the stage start
+static_assert((W3_DUMMY_ROW + 1) * WRS <= W3_STAGE && W3_DUMMY_ROW * WRS >= (W3_XROWS + WKP) * WRS + 64 && W3_STAGE % 16 == 0, "dummy row inside the stage");
 template <int YVEC, int XVEC>
 __global__ __launch_bounds__(256, 2) void gwgrad3_kernel(GWgP p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * W3_STAGE + WRS];      // two stages + one zero row
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles = p.o_tiles * p.i_tiles;
     const int kh = p.T / 3;
-    int id = blockIdx.x;
+    int id = p.remap ? mi_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;      // the (tile, tap) workgroups of a pixel split share its dy / x rows: keep them on one XCD's L2
     const int tile = id % tiles;
     id /= tiles;
     const int ky = id % kh, split = id / kh;
@@ -751,12 +751,16 @@ __global__ __launch_bounds__(256, 2) void gwgrad3_kernel(GWgP p) {
         xh[h] = rem / p.Wa;
         xw[h] = rem - xh[h] * p.Wa;
     }
-    const int step_rows = WKP / p.Wa, step_cols = WKP - step_rows * p.Wa;
+    // (selects only - the main loop stays one basic block, see gconv_kernel; only the row within the image matters here, so a step is
+    //  (64 mod Ha*Wa) pixels = step_rows < Ha rows + step_cols columns and every coordinate wraps at most once)
+    const int step_rem = WKP % hw;
+    const int step_rows = step_rem / p.Wa, step_cols = step_rem - step_rows * p.Wa;
     auto advance = [&](int& hh, int& ww) {
-        ww += step_cols;
-        hh += step_rows;
-        if (ww >= p.Wa) ww -= p.Wa, ++hh;
-        while (hh >= p.Ha) hh -= p.Ha;
+        const int w1 = ww + step_cols;
+        const bool cw = w1 >= p.Wa;
+        ww = cw ? w1 - p.Wa : w1;
+        const int h1 = hh + step_rows + (cw ? 1 : 0);
+        hh = h1 >= p.Ha ? h1 - p.Ha : h1;
     };
     bf16x8 ry0[2], rx0[3], ry1[2], rx1[3];
     uint32_t rf0 = 0, rf1 = 0;                               // validity bits of the two dy rows (byte h)
@@ -774,7 +778,7 @@ __global__ __launch_bounds__(256, 2) void gwgrad3_kernel(GWgP p) {
 #pragma unroll
         for (int h = 0; h < 3; ++h) {
             const bool in_window = lpx + 32 * h < xrows;
-            const bool ok = in_window && xq[h] >= 0 && xq[h] < (long)p.M && (unsigned)(xh[h] - dyoff) < (unsigned)p.Ha && kt < nk;
+            const bool ok = in_window & (xq[h] >= 0) & (xq[h] < (long)p.M) & ((unsigned)(xh[h] - dyoff) < (unsigned)p.Ha) & (kt < nk);
             rx[h] = gload8<XVEC>(p.X + (ok ? xq[h] : 0L) * p.ldx, i0 + lch * 8, p.I, ok);
             xq[h] += WKP;
             advance(xh[h], xw[h]);
@@ -784,12 +788,14 @@ __global__ __launch_bounds__(256, 2) void gwgrad3_kernel(GWgP p) {
         char* sx = smem + buf * W3_STAGE;
         char* sy = sx + W3_XROWS * WRS;
 #pragma unroll
-        for (int h = 0; h < 3; ++h)
-            if (lpx + 32 * h < W3_XROWS) *reinterpret_cast<bf16x8*>(sx + (lpx + 32 * h) * WRS + lch * 16) = rx[h];
+        for (int h = 0; h < 3; ++h) {                        // (rows past the window go to the stage's dummy row: an unconditional write, no branch)
+            const int row = lpx + 32 * h < W3_XROWS ? lpx + 32 * h : W3_DUMMY_ROW;
+            *reinterpret_cast<bf16x8*>(sx + row * WRS + lch * 16) = rx[h];
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             *reinterpret_cast<bf16x8*>(sy + (lpx + 32 * h) * WRS + lch * 16) = ry[h];
-            if (lch == 0) sy[WKP * WRS + lpx + 32 * h] = (char)((rf >> (8 * h)) & 0xff);
+            sy[WKP * WRS + lpx + 32 * h] = (char)((rf >> (8 * h)) & 0xff);            // (the eight threads of a pixel row write the same byte)
         }
     };
 
@@ -843,14 +849,17 @@ __global__ __launch_bounds__(256, 2) void gwgrad3_kernel(GWgP p) {
         load(1, ry1, rx1, rf1);
         stash(0, ry0, rx0, rf0);
         __syncthreads();
-        for (int kt = 0; kt < nk; kt += 2) {
+        for (int kt = 0; kt < nk; kt += 2) {                 // (steps rounded up to two, sched_barrier: see gwgrad_kernel)
             load(kt + 2, ry0, rx0, rf0);
+            __builtin_amdgcn_sched_barrier(0);
             compute(0);
+            __builtin_amdgcn_sched_barrier(0);
             stash(1, ry1, rx1, rf1);
             __syncthreads();
-            if (kt + 1 >= nk) break;
             load(kt + 3, ry1, rx1, rf1);
+            __builtin_amdgcn_sched_barrier(0);
             compute(1);
+            __builtin_amdgcn_sched_barrier(0);
             stash(0, ry0, rx0, rf0);
             __syncthreads();
         }
@@ -1036,6 +1045,7 @@ static int gconv_impl(const void* a, long lda, const void* wp, void* out, long l
     p.kw = kw; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.dh = dh; p.dw = dw;
     p.mode = mode;
     p.nchunks = p.Cpad / 32;
+    p.remap = mi_sw().gconv_remap;
     p.fin_ticket = fin ? fin->ticket : nullptr;
     p.fin_out = fin ? fin->out : nullptr;
     p.gamma = fin ? fin->gamma : nullptr;
@@ -1087,6 +1097,7 @@ int mi_gconv_wgrad(const void* dy, long ldy, const void* x, long ldx, float* dw,
                "mi_gconv_wgrad: output %dx%d does not follow from input %dx%d", Ho, Wo, Ha, Wa);
     MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "mi_gconv_wgrad: workspace must be 16-byte aligned");
     GWgP p;
+    p.remap = mi_sw().gconv_remap;
     p.dY = (const __bf16*)dy;
     p.X = (const __bf16*)x;
     p.slab = (float*)workspace;

@@ -36,6 +36,7 @@ struct MiSwitches {
     int wgrad_s4;          // MI_WGRAD_S4         1: deep-stream 1x1 weight gradient
     int gconv_bn128;       // MI_GCONV_BN128      0: general conv keeps 64-wide tiles (1: 128-wide where they fit)
     int gconv_kc;          // MI_GCONV_KC         0: K chunk of the general conv by rule (32 | 64: forced)
+    int gconv_remap;       // MI_GCONV_REMAP      1: general conv / weight gradient walk their tiles XCD-contiguous (0: plain grid order)
     int gwgrad3;           // MI_GWGRAD3          1: general weight gradient of three-column kernels as one fused kernel row per workgroup from 65 536 pixels up (0: per tap, 2: always)
     int p3_dbg;            // MI_P3_DBG           0 (-DMI_EXPERIMENTS builds only)
     int pp_trace_wg;       // MI_PP_TRACE_WG      0 (-DMI_PP_TRACE builds only)
