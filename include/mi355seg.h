@@ -336,6 +336,19 @@ size_t mi_gconv_wgrad_workspace(int B, int Ho, int Wo, int O, int I, int kh, int
 int mi_gconv_wgrad(const void* dy, long ldy, const void* x, long ldx, float* dw, int B, int Ha, int Wa, int I, int Ho, int Wo, int O,
                    int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw_, int accumulate, void* workspace, size_t workspace_bytes, unsigned* tickets, int n_tickets,
                    void* stream);      /* tickets: NULL, or n_tickets zeroed words (left zero): with few K splits the slabs are then added inside the first launch (same bits) */
+/* The weight gradients of many convs in one go (the tape of host/pranet.py queues them and flushes once per backward: nothing reads a weight gradient
+ * before the optimizer; reference: the autograd of nn.Conv2d.weight, PraNet_Res2Net.py:7-20, hardnet_68.py:56-80).  Each job is mi_gconv_wgrad's argument
+ * list; two jobs must not name the same dw.  table_dev: device scratch of mi_gconv_wgrad_multi_table_bytes(n) bytes; workspace: device scratch of
+ * mi_gconv_wgrad_multi_workspace(jobs, n) bytes (fp32 split-K slabs of all jobs).  Launches: the table writers (descriptors travel as kernel arguments),
+ * one main kernel per operand-alignment class, one reducer.  The K split per job is ~24 steps of 64 pixels (MI_GWM_STEPS) - not mi_gconv_wgrad's split, so the
+ * fp32 summation order (not the result beyond rounding) differs from the one-conv call. */
+typedef struct MiWgradJob {
+    const void* dy; long ldy; const void* x; long ldx; float* dw;
+    int B, Ha, Wa, I, Ho, Wo, O, kh, kw, sh, sw, ph, pw, dh, dw_, accumulate;
+} MiWgradJob;
+size_t mi_gconv_wgrad_multi_table_bytes(int n);
+size_t mi_gconv_wgrad_multi_workspace(const MiWgradJob* jobs, int n);
+int mi_gconv_wgrad_multi(const MiWgradJob* jobs, int n, void* table_dev, size_t table_bytes, void* workspace, size_t workspace_bytes, void* stream);
 /* nn.BatchNorm2d in train() from the conv's tile statistics: mean, invstd = rsqrt(biased var + eps), scale = gamma * invstd,
  * shift = beta - mean * scale, and the running-statistics update (momentum; unbiased variance), all per channel.  count = pixels. */
 int mi_gbn_finalize(const float* partials, int tiles, int C, long count, const float* gamma, const float* beta, float* running_mean, float* running_var,

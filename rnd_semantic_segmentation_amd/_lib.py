@@ -81,6 +81,9 @@ SIGNATURES = {
     "mi_gconv": (I, [P, L, P, P, L] + [I] * 16 + [P, P, I, P]),
     "mi_gconv_wgrad_workspace": (Z, [I] * 7),
     "mi_gconv_wgrad": (I, [P, L, P, L, P] + [I] * 16 + [P, Z, P, I, P]),
+    "mi_gconv_wgrad_multi_table_bytes": (Z, [I]),
+    "mi_gconv_wgrad_multi_workspace": (Z, [P, I]),
+    "mi_gconv_wgrad_multi": (I, [P, I, P, Z, P, Z, P]),
     "mi_gbn_finalize": (I, [P, I, I, L, P, P, P, P, F, F, P, P, P, P, P]),
     "mi_gbn_fold": (I, [P, P, P, P, F, P, P, I, P]),
     "mi_gbn_apply": (I, [P, L, P, P, P, L, P, L, I, L, I, I, P]),

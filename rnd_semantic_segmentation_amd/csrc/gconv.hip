@@ -19,6 +19,9 @@
 // outputs - the first level of the BatchNorm batch statistics (nn.BatchNorm2d in train(), PraNet_Res2Net.py:13,17-19) - so
 // that no separate pass over the conv output is needed for them.
 #include "mi_common.h"
+#include <type_traits>
+#include <vector>
+#include <string.h>
 #include <stdlib.h>
 
 namespace {
@@ -483,7 +486,7 @@ struct GWgP {
     int S, rows_per_split, o_tiles, i_tiles;
     unsigned* ticket;      // in-launch reduction (S <= GW_INLAUNCH_S): one zeroed word per (tap, output tile); else null
     float* dwout;
-    int accumulate, remap;
+    int accumulate, remap, dbg;
 };
 constexpr int GW_INLAUNCH_S = 16;      // K splits the last workgroup of a tile adds itself (64 KB of slabs at most); more: the reducer launch
 
@@ -508,12 +511,14 @@ __device__ __forceinline__ s16x4 tr_read(const char* lds_generic) {
 
 // One workgroup = one (K split, tap, o tile, i tile).  Both operands have the contraction index (pixel) as their memory row, so the
 // tiles are staged pixel-major and the MFMA fragments come from ds_read_b64_tr_b16 (hardware transpose), as in igemm_tn.hip.
+// (the body is shared by the one-conv launch and by the table-driven launch that runs the weight gradients of many convs at once: `bid` of `nblk`
+//  workgroups of THIS conv)
+constexpr int GW_SMEM = 2 * 2 * WKP * WRS;                                 // [buf][dy | x][64 pixels][144 B]
 template <int YVEC, int XVEC>
-__global__ __launch_bounds__(256, 4) void gwgrad_kernel(GWgP p) {       // four workgroups per CU (<= 128 VGPRs): the large launches are bandwidth-bound, 136 VGPRs cost them 25 %
-    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * WKP * WRS];      // [buf][dy | x][64 pixels][144 B]
+__device__ __forceinline__ void gwgrad_body(const GWgP& p, int bid, int nblk, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles = p.o_tiles * p.i_tiles;
-    int id = p.remap ? mi_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;      // the (tile, tap) workgroups of a pixel split share its dy / x rows: keep them on one XCD's L2
+    int id = p.remap ? mi_xcd_remap(bid, nblk) : bid;      // the (tile, tap) workgroups of a pixel split share its dy / x rows: keep them on one XCD's L2
     const int tile = id % tiles;
     id /= tiles;
     const int t = id % p.T, split = id / p.T;
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(256, 4) void gwgrad_kernel(GWgP p) {       // four 
     const int ky = t / p.kw, kx = t - ky * p.kw;
     const int m_begin = split * p.rows_per_split;
     const int m_end = min(p.M, m_begin + p.rows_per_split);
-    const int nk = m_end > m_begin ? (m_end - m_begin + WKP - 1) / WKP : 0;
+    const int nk = (p.dbg & 1) ? 0 : (m_end > m_begin ? (m_end - m_begin + WKP - 1) / WKP : 0);
     const int lpx = tid >> 3, lch = tid & 7;          // loader: pixel rows lpx and lpx + 32 of the step, 8-channel chunk
     const int hw = p.Ho * p.Wo;
 
@@ -657,43 +662,57 @@ __global__ __launch_bounds__(256, 4) void gwgrad_kernel(GWgP p) {       // four 
         // splits l, l + 8, ... ascending, the eight sums are combined as the butterfly does: ((0+1)+(2+3))+((4+5)+(6+7))) - the same bits, one launch
         if (mi_last_arriver(p.ticket + (long)t * tiles + tile, p.S, reinterpret_cast<int*>(smem))) {
             mi_acquire_partials();
+            // A thread owns eight float2 elements of the tile (rows tid / 32 + 8 k, columns 2 (tid % 32)), S <= 16 slabs each: 128 loads that all miss the L2
+            // (the slabs were written by other XCDs).  They are issued in groups that fill ~64 registers - two elements at S > 8, four at S > 4, all eight
+            // below - and only then added and stored: the first version went element by element, and since a store to dw may alias a slab as far as the
+            // compiler knows, each element's two load batches waited for the previous element's store - sixteen dependent round trips, 24 of the 33 us of a
+            // 3x3 104 -> 104 gradient at 16 x 22 x 22 (tools/gkshape.py, MI_GW_DBG=1).
             const long sstride = (long)p.T * p.O * Ip;
-            const float* base = p.slab + (long)t * p.O * Ip;
-            for (int e = tid; e < WTO * (WTI / 2); e += 256) {
-                const int ol = e / (WTI / 2), ip = (e - ol * (WTI / 2)) * 2;
-                const int o = o0 + ol, i = i0 + ip;
-                if (o >= p.O || i >= Ip) continue;
-                float v0[8], v1[8];                                                          // two batches of eight independent loads
+            const float* __restrict__ base = p.slab + (long)t * p.O * Ip;
+            float* __restrict__ dwo = p.dwout;
+            const int S = p.S, accumulate = p.accumulate;
+            const int ip = (tid & 31) * 2, i = i0 + ip;
+            auto group = [&](auto EGc, int k0) {
+                constexpr int EG = decltype(EGc)::value, SL = 32 / EG;        // elements per group, slab loads per element (>= S)
+                float2 v[EG][SL];
+                float old0[EG], old1[EG];
 #pragma unroll
-                for (int l = 0; l < 8; ++l) {
-                    const int ss = l < p.S ? l : p.S - 1;
-                    const float2 v = *reinterpret_cast<const float2*>(base + ss * sstride + (long)o * Ip + i);
-                    v0[l] = l < p.S ? v.x : 0.f;
-                    v1[l] = l < p.S ? v.y : 0.f;
+                for (int k = 0; k < EG; ++k) {
+                    const int o = o0 + (tid >> 5) + 8 * (k0 + k);
+                    const bool live = o < p.O && i < Ip;
+                    const long off = live ? (long)o * Ip + i : 0;
+#pragma unroll
+                    for (int l = 0; l < SL; ++l) v[k][l] = *reinterpret_cast<const float2*>(base + (l < S ? l : S - 1) * sstride + off);
+                    old0[k] = (accumulate && live && i < p.I) ? dwo[((long)o * p.I + i) * p.T + t] : 0.f;
+                    old1[k] = (accumulate && live && i + 1 < p.I) ? dwo[((long)o * p.I + i + 1) * p.T + t] : 0.f;
                 }
-                if (p.S > 8) {
-                    float w0[8], w1[8];
+#pragma unroll
+                for (int k = 0; k < EG; ++k) {
+                    const int o = o0 + (tid >> 5) + 8 * (k0 + k);
+                    // gwgrad_reduce_kernel's arithmetic in its order: lane l of 8 adds the splits l, l + 8 ascending, the eight sums meet as the butterfly does
+                    float a0[8], a1[8];
 #pragma unroll
                     for (int l = 0; l < 8; ++l) {
-                        const int ss = l + 8 < p.S ? l + 8 : p.S - 1;
-                        const float2 v = *reinterpret_cast<const float2*>(base + ss * sstride + (long)o * Ip + i);
-                        w0[l] = v.x;
-                        w1[l] = v.y;
+                        a0[l] = (l < SL && l < S) ? v[k][l < SL ? l : 0].x : 0.f;
+                        a1[l] = (l < SL && l < S) ? v[k][l < SL ? l : 0].y : 0.f;
+                        if constexpr (SL > 8) {
+                            if (l + 8 < S) a0[l] += v[k][l + 8].x, a1[l] += v[k][l + 8].y;
+                        }
                     }
-#pragma unroll
-                    for (int l = 0; l < 8; ++l)
-                        if (l + 8 < p.S) v0[l] += w0[l], v1[l] += w1[l];
+                    const float r0 = ((a0[0] + a0[1]) + (a0[2] + a0[3])) + ((a0[4] + a0[5]) + (a0[6] + a0[7]));
+                    const float r1 = ((a1[0] + a1[1]) + (a1[2] + a1[3])) + ((a1[4] + a1[5]) + (a1[6] + a1[7]));
+                    if (o < p.O && i < p.I) dwo[((long)o * p.I + i) * p.T + t] = accumulate ? old0[k] + r0 : r0;
+                    if (o < p.O && i + 1 < p.I) dwo[((long)o * p.I + i + 1) * p.T + t] = accumulate ? old1[k] + r1 : r1;
                 }
-                const float r0 = ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v0[4] + v0[5]) + (v0[6] + v0[7]));
-                const float r1 = ((v1[0] + v1[1]) + (v1[2] + v1[3])) + ((v1[4] + v1[5]) + (v1[6] + v1[7]));
-                if (i < p.I) {
-                    float* d = p.dwout + ((long)o * p.I + i) * p.T + t;
-                    *d = p.accumulate ? *d + r0 : r0;
-                }
-                if (i + 1 < p.I) {
-                    float* d = p.dwout + ((long)o * p.I + i + 1) * p.T + t;
-                    *d = p.accumulate ? *d + r1 : r1;
-                }
+            };
+            if (S > 8) {
+#pragma unroll 1
+                for (int k0 = 0; k0 < 8; k0 += 2) group(std::integral_constant<int, 2>{}, k0);
+            } else if (S > 4) {
+#pragma unroll 1
+                for (int k0 = 0; k0 < 8; k0 += 4) group(std::integral_constant<int, 4>{}, k0);
+            } else {
+                group(std::integral_constant<int, 8>{}, 0);
             }
         }
     }
@@ -712,13 +731,13 @@ constexpr int W3_XROWS = WKP + 2 * W3_MAXD;                 // 80 pixel rows of 
 constexpr int W3_STAGE = (W3_XROWS + WKP) * WRS + 64 + 2 * WRS;      // x window | dy tile | 64 flag bytes | dummy area (target of the loader's out-of-window writes)
 constexpr int W3_DUMMY_ROW = ((W3_XROWS + WKP) * WRS + 64 + WRS - 1) / WRS;      // the whole row that lies inside the dummy area, counted from the stage start
 static_assert((W3_DUMMY_ROW + 1) * WRS <= W3_STAGE && W3_DUMMY_ROW * WRS >= (W3_XROWS + WKP) * WRS + 64 && W3_STAGE % 16 == 0, "dummy row inside the stage");
+constexpr int GW3_SMEM = 2 * W3_STAGE + WRS;                               // two stages + one zero row
 template <int YVEC, int XVEC>
-__global__ __launch_bounds__(256, 2) void gwgrad3_kernel(GWgP p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * W3_STAGE + WRS];      // two stages + one zero row
+__device__ __forceinline__ void gwgrad3_body(const GWgP& p, int bid, int nblk, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles = p.o_tiles * p.i_tiles;
     const int kh = p.T / 3;
-    int id = p.remap ? mi_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;      // the (tile, tap) workgroups of a pixel split share its dy / x rows: keep them on one XCD's L2
+    int id = p.remap ? mi_xcd_remap(bid, nblk) : bid;      // the (tile, tap) workgroups of a pixel split share its dy / x rows: keep them on one XCD's L2
     const int tile = id % tiles;
     id /= tiles;
     const int ky = id % kh, split = id / kh;
@@ -726,7 +745,7 @@ __global__ __launch_bounds__(256, 2) void gwgrad3_kernel(GWgP p) {
     const int o0 = ot * WTO, i0 = itile * WTI;
     const int m_begin = split * p.rows_per_split;
     const int m_end = min(p.M, m_begin + p.rows_per_split);
-    const int nk = m_end > m_begin ? (m_end - m_begin + WKP - 1) / WKP : 0;
+    const int nk = (p.dbg & 1) ? 0 : (m_end > m_begin ? (m_end - m_begin + WKP - 1) / WKP : 0);
     const int lpx = tid >> 3, lch = tid & 7;
     const int hw = p.Ha * p.Wa;
     const int dyoff = ky * p.dh - p.ph;                      // source row - output row
@@ -884,12 +903,12 @@ __global__ __launch_bounds__(256, 2) void gwgrad3_kernel(GWgP p) {
 
 // dw[o][i][t] (+)= sum over the K splits (bitwise reproducible); 8 lanes per output element (t, o, i: i fastest): lane l adds the splits
 // l, l + 8, ... in ascending order, the eight partial sums are combined by a fixed butterfly
-__global__ __launch_bounds__(256) void gwgrad_reduce_kernel(const float* slab, float* dw, int O, int I, int T, int S, int accumulate) {
+__device__ __forceinline__ void gwgrad_reduce_body(const float* __restrict__ slab, float* __restrict__ dw, int O, int I, int T, int S, int accumulate, long bid, long nblk) {
     const int Ip = (I + 3) & ~3;
     const long n = (long)T * O * I;
     const long sstride = (long)T * O * Ip;
     const int l = threadIdx.x & 7;
-    for (long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 3; e < n; e += ((long)gridDim.x * blockDim.x) >> 3) {      // the 8 lanes of a group share e
+    for (long e = (bid * blockDim.x + threadIdx.x) >> 3; e < n; e += (nblk * blockDim.x) >> 3) {      // the 8 lanes of a group share e
         const int i = (int)(e % I);
         const long r = e / I;
         const int o = (int)(r % O), t = (int)(r / O);
@@ -904,6 +923,80 @@ __global__ __launch_bounds__(256) void gwgrad_reduce_kernel(const float* slab, f
             *d = accumulate ? *d + v : v;
         }
     }
+}
+__global__ __launch_bounds__(256) void gwgrad_reduce_kernel(const float* slab, float* dw, int O, int I, int T, int S, int accumulate) {
+    gwgrad_reduce_body(slab, dw, O, I, T, S, accumulate, blockIdx.x, gridDim.x);
+}
+
+// ---- launches: one conv per launch (parameters as kernel arguments) ...
+template <int YVEC, int XVEC>
+__global__ __launch_bounds__(256, 4) void gwgrad_kernel(GWgP p) {       // four workgroups per CU (<= 128 VGPRs): the large launches are bandwidth-bound, 136 VGPRs cost them 25 %
+    __shared__ __attribute__((aligned(16))) char smem[GW_SMEM];
+    gwgrad_body<YVEC, XVEC>(p, blockIdx.x, gridDim.x, smem);
+}
+template <int YVEC, int XVEC>
+__global__ __launch_bounds__(256, 2) void gwgrad3_kernel(GWgP p) {
+    __shared__ __attribute__((aligned(16))) char smem[GW3_SMEM];
+    gwgrad3_body<YVEC, XVEC>(p, blockIdx.x, gridDim.x, smem);
+}
+
+// ---- ... or the weight gradients of MANY convs in one launch (mi_gconv_wgrad_multi).  A training step of PraNet / GALD issues 140 - 200 weight
+// gradients of 1 - 10 GFLOP; alone, each is a latency chain (launch, a handful of K steps of ~0.9 us, slab round trip, second-level sum: 15 - 25 us
+// of its 25 - 60 us are fixed, tools/gkshape.py with MI_GW_DBG=1), and nothing reads a weight gradient before the optimizer.  The tape therefore
+// queues them and flushes the queue once per backward: a descriptor table in device memory (written by gw_table_kernel from kernel arguments - no host
+// buffer that a HIP graph would have to keep alive), one main launch per operand-alignment class in which every workgroup finds its conv by binary
+// search over the table's first-block column, and ONE reducer launch for all slabs.  With the whole backward's gradients in flight together a conv needs
+// no split count that fills the chip by itself: the K range per workgroup is ~24 steps (MI_GWM_STEPS) and the slabs shrink accordingly.
+struct alignas(16) GWgD {
+    GWgP p;
+    int first_block, nblk;        // main launch of the conv's class: its workgroups are [first_block, first_block + nblk), first_block a multiple of 8 (XCD phase)
+    int first_rblock, n_rblk;     // reducer launch
+    int pad_[4];
+};
+static_assert(sizeof(GWgD) % 16 == 0, "descriptor rows are copied as 16-byte words");
+constexpr int GW_CHUNK = 8;
+struct GWgChunk { GWgD d[GW_CHUNK]; };
+
+__global__ __launch_bounds__(256) void gw_table_kernel(GWgD* table, int first, int count, GWgChunk c) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&c);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(table + first);
+    const int words = count * (int)(sizeof(GWgD) / 4);
+    for (int i = threadIdx.x; i < words; i += 256) dst[i] = src[i];
+}
+
+__device__ __forceinline__ int gw_find(const GWgD* __restrict__ table, int first, int n, int bid, bool reducer) {
+    int lo = first, hi = first + n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((reducer ? table[mid].first_rblock : table[mid].first_block) <= bid) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
+template <int YVEC, int XVEC>
+__global__ __launch_bounds__(256, 4) void gwgrad_multi_kernel(const GWgD* __restrict__ table, int first, int n) {
+    __shared__ __attribute__((aligned(16))) char smem[GW_SMEM];
+    const int at = gw_find(table, first, n, blockIdx.x, false);
+    const GWgP p = table[at].p;                          // (by value: scalar loads once, not re-read after the kernel's own stores)
+    const int b = blockIdx.x - table[at].first_block;
+    if (b >= table[at].nblk) return;                     // (padding up to the next multiple of 8)
+    gwgrad_body<YVEC, XVEC>(p, b, table[at].nblk, smem);
+}
+template <int YVEC, int XVEC>
+__global__ __launch_bounds__(256, 2) void gwgrad3_multi_kernel(const GWgD* __restrict__ table, int first, int n) {
+    __shared__ __attribute__((aligned(16))) char smem[GW3_SMEM];
+    const int at = gw_find(table, first, n, blockIdx.x, false);
+    const GWgP p = table[at].p;
+    const int b = blockIdx.x - table[at].first_block;
+    if (b >= table[at].nblk) return;
+    gwgrad3_body<YVEC, XVEC>(p, b, table[at].nblk, smem);
+}
+
+__global__ __launch_bounds__(256) void gwgrad_reduce_multi_kernel(const GWgD* __restrict__ table, int n) {
+    const int at = gw_find(table, 0, n, blockIdx.x, true);
+    const GWgP p = table[at].p;
+    gwgrad_reduce_body(p.slab, p.dwout, p.O, p.I, p.T, p.S, p.accumulate, blockIdx.x - table[at].first_rblock, table[at].n_rblk);
 }
 
 void gwgrad_plan(int M, int O, int I, int T, int* S, int* rows, int* ot, int* it) {
@@ -1098,6 +1191,7 @@ int mi_gconv_wgrad(const void* dy, long ldy, const void* x, long ldx, float* dw,
     MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "mi_gconv_wgrad: workspace must be 16-byte aligned");
     GWgP p;
     p.remap = mi_sw().gconv_remap;
+    { static const int dbg = getenv("MI_GW_DBG") ? atoi(getenv("MI_GW_DBG")) : 0; p.dbg = dbg; }
     p.dY = (const __bf16*)dy;
     p.X = (const __bf16*)x;
     p.slab = (float*)workspace;
@@ -1163,6 +1257,143 @@ int mi_gconv_wgrad(const void* dy, long ldy, const void* x, long ldx, float* dw,
     const int blocks = (int)((n + 31) / 32 < 4096 ? (n + 31) / 32 : 4096);          // 32 output elements (8 lanes each) per block
     hipLaunchKernelGGL(gwgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slab, dw, O, I, p.T, p.S, accumulate);
     MI_CHECK_LAUNCH("gwgrad_reduce_kernel");
+    return MI_OK;
+}
+
+
+// ---- the weight gradients of many convs in one go (see GWgD above).  jobs: host array; table_dev: device buffer of mi_gconv_wgrad_multi_table_bytes(n)
+// bytes; workspace: device buffer of mi_gconv_wgrad_multi_workspace(jobs, n) bytes.  Two jobs must not share a dw (the caller flushes between them).
+static bool gwm_fused(const MiWgradJob& j, long M) {
+    const int mode = mi_sw().gwgrad3;                    // 0: never fused; otherwise fused whenever the geometry allows (MI_GWM_FUSED3=0: the one-conv rule, from 65 536 pixels)
+    static const int always = getenv("MI_GWM_FUSED3") ? atoi(getenv("MI_GWM_FUSED3")) : 1;
+    const bool can = j.kw == 3 && j.sh == 1 && j.sw == 1 && j.pw == j.dw_ && j.Ho == j.Ha && j.Wo == j.Wa && j.dw_ <= W3_MAXD;
+    return can && mode != 0 && (always || mode == 2 || M >= 65536);
+}
+static void gwm_plan(const MiWgradJob& j, GWgD& d) {
+    static const int steps = getenv("MI_GWM_STEPS") ? atoi(getenv("MI_GWM_STEPS")) : 24;
+    GWgP& p = d.p;
+    p.remap = mi_sw().gconv_remap;
+    p.dbg = 0;
+    p.dY = (const __bf16*)j.dy;
+    p.X = (const __bf16*)j.x;
+    p.ldy = j.ldy;
+    p.ldx = j.ldx;
+    p.M = j.B * j.Ho * j.Wo;
+    p.O = j.O; p.I = j.I; p.T = j.kh * j.kw;
+    p.Ho = j.Ho; p.Wo = j.Wo; p.Ha = j.Ha; p.Wa = j.Wa;
+    p.kw = j.kw; p.sh = j.sh; p.sw = j.sw; p.ph = j.ph; p.pw = j.pw; p.dh = j.dh; p.dw = j.dw_;
+    p.o_tiles = (j.O + WTO - 1) / WTO;
+    p.i_tiles = (j.I + WTI - 1) / WTI;
+    int S = (p.M + WKP * (steps > 0 ? steps : 24) - 1) / (WKP * (steps > 0 ? steps : 24));
+    if (S < 1) S = 1;
+    int r = rup((p.M + S - 1) / S, WKP);
+    p.rows_per_split = r;
+    p.S = (p.M + r - 1) / r;
+    p.ticket = nullptr;
+    p.dwout = j.dw;
+    p.accumulate = j.accumulate;
+    const bool fused = gwm_fused(j, p.M);
+    d.nblk = p.o_tiles * p.i_tiles * (fused ? j.kh : p.T) * p.S;
+    const long n = (long)j.O * j.I * p.T;
+    d.n_rblk = (int)((n + 31) / 32 < 1024 ? (n + 31) / 32 : 1024);
+}
+static inline size_t gwm_slab_bytes(const GWgD& d) { return ((size_t)d.p.S * d.p.T * d.p.O * ((d.p.I + 3) & ~3) * sizeof(float) + 255) & ~(size_t)255; }
+
+size_t mi_gconv_wgrad_multi_table_bytes(int n) { return (size_t)(n > 0 ? n : 0) * sizeof(GWgD); }
+
+size_t mi_gconv_wgrad_multi_workspace(const MiWgradJob* jobs, int n) {
+    size_t total = 0;
+    for (int k = 0; k < n; ++k) {
+        const MiWgradJob& j = jobs[k];
+        if ((long)j.B * j.Ho * j.Wo <= 0 || (long)j.B * j.Ho * j.Wo >= (1L << 31) || j.O <= 0 || j.I <= 0 || j.kh <= 0 || j.kw <= 0) return 0;
+        GWgD d;
+        gwm_plan(j, d);
+        total += gwm_slab_bytes(d);
+    }
+    return total;
+}
+
+int mi_gconv_wgrad_multi(const MiWgradJob* jobs, int n, void* table_dev, size_t table_bytes, void* workspace, size_t workspace_bytes, void* stream) {
+    if (n == 0) return MI_OK;
+    MI_REQUIRE(jobs && n > 0 && table_dev && workspace, "mi_gconv_wgrad_multi: null operand");
+    MI_REQUIRE(table_bytes >= mi_gconv_wgrad_multi_table_bytes(n), "mi_gconv_wgrad_multi: table buffer %zu < %zu bytes", table_bytes, mi_gconv_wgrad_multi_table_bytes(n));
+    MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && (reinterpret_cast<uintptr_t>(table_dev) & 15) == 0, "mi_gconv_wgrad_multi: buffers must be 16-byte aligned");
+    std::vector<GWgD> table((size_t)n);
+    std::vector<int> cls((size_t)n);                        // 0 .. 8: per-tap kernel by (yv, xv); 9 .. 17: fused-row kernel
+    auto vidx = [](int v) { return v == 8 ? 0 : (v == 4 ? 1 : 2); };
+    std::vector<int> order;
+    size_t need = 0;
+    for (int k = 0; k < n; ++k) {
+        const MiWgradJob& j = jobs[k];
+        MI_REQUIRE(j.dy && j.x && j.dw, "mi_gconv_wgrad_multi: job %d: null operand", k);
+        MI_REQUIRE(j.B > 0 && j.Ha > 0 && j.Wa > 0 && j.Ho > 0 && j.Wo > 0 && j.I > 0 && j.O > 0, "mi_gconv_wgrad_multi: job %d: empty shape", k);
+        MI_REQUIRE(j.ldy >= j.O && j.ldx >= j.I, "mi_gconv_wgrad_multi: job %d: a view's row stride is smaller than its channel count", k);
+        MI_REQUIRE(j.kh > 0 && j.kw > 0 && j.sh > 0 && j.sw > 0 && j.dh > 0 && j.dw_ > 0 && j.ph >= 0 && j.pw >= 0, "mi_gconv_wgrad_multi: job %d: bad conv geometry", k);
+        MI_REQUIRE((long)j.B * j.Ho * j.Wo < (1L << 31) && (long)j.B * j.Ha * j.Wa < (1L << 31), "mi_gconv_wgrad_multi: job %d: more than 2^31 pixels", k);
+        MI_REQUIRE((j.Ha + 2 * j.ph - j.dh * (j.kh - 1) - 1) / j.sh + 1 == j.Ho && (j.Wa + 2 * j.pw - j.dw_ * (j.kw - 1) - 1) / j.sw + 1 == j.Wo,
+                   "mi_gconv_wgrad_multi: job %d: output %dx%d does not follow from input %dx%d", k, j.Ho, j.Wo, j.Ha, j.Wa);
+        for (int q = 0; q < k; ++q) MI_REQUIRE(jobs[q].dw != j.dw, "mi_gconv_wgrad_multi: jobs %d and %d write the same gradient", q, k);
+        gwm_plan(j, table[k]);
+        cls[k] = vidx(view_vec(j.dy, j.ldy, j.O)) * 3 + vidx(view_vec(j.x, j.ldx, j.I)) + (gwm_fused(j, table[k].p.M) ? 9 : 0);
+        need += gwm_slab_bytes(table[k]);
+    }
+    if (workspace_bytes < need) return mi_set_error(MI_ENOMEM, "mi_gconv_wgrad_multi: workspace %zu < %zu bytes", workspace_bytes, need);
+    // table order: by class; inside a class the job order
+    std::vector<GWgD> sorted;
+    sorted.reserve((size_t)n);
+    int cls_first[18], cls_n[18], cls_blocks[18];
+    size_t off = 0;
+    int rblocks = 0;
+    for (int c = 0; c < 18; ++c) {
+        cls_first[c] = (int)sorted.size();
+        int blocks = 0;
+        for (int k = 0; k < n; ++k) {
+            if (cls[k] != c) continue;
+            GWgD d = table[k];
+            d.p.slab = reinterpret_cast<float*>(static_cast<char*>(workspace) + off);
+            off += gwm_slab_bytes(d);
+            d.first_block = blocks;
+            blocks += (d.nblk + 7) & ~7;
+            d.first_rblock = rblocks;
+            rblocks += d.n_rblk;
+            sorted.push_back(d);
+        }
+        cls_n[c] = (int)sorted.size() - cls_first[c];
+        cls_blocks[c] = blocks;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    GWgD* tdev = static_cast<GWgD*>(table_dev);
+    for (int first = 0; first < n; first += GW_CHUNK) {
+        GWgChunk c;
+        const int count = n - first < GW_CHUNK ? n - first : GW_CHUNK;
+        memset(&c, 0, sizeof(c));
+        for (int k = 0; k < count; ++k) c.d[k] = sorted[(size_t)first + k];
+        hipLaunchKernelGGL(gw_table_kernel, dim3(1), dim3(256), 0, s, tdev, first, count, c);
+    }
+    MI_CHECK_LAUNCH("gw_table_kernel");
+    static const int vv[3] = {8, 4, 1};
+    for (int c = 0; c < 18; ++c) {
+        if (!cls_n[c]) continue;
+        const int yv = vv[(c % 9) / 3], xv = vv[c % 3];
+        const dim3 grid((unsigned)cls_blocks[c]);
+#define GWM(K, YV, XV) hipLaunchKernelGGL((K<YV, XV>), grid, dim3(256), 0, s, (const GWgD*)tdev, cls_first[c], cls_n[c])
+#define GWM_ALL(K)                                   \
+        if (yv == 8 && xv == 8) GWM(K, 8, 8);        \
+        else if (yv == 8 && xv == 4) GWM(K, 8, 4);   \
+        else if (yv == 8) GWM(K, 8, 1);              \
+        else if (yv == 4 && xv == 8) GWM(K, 4, 8);   \
+        else if (yv == 4 && xv == 4) GWM(K, 4, 4);   \
+        else if (yv == 4) GWM(K, 4, 1);              \
+        else if (xv == 8) GWM(K, 1, 8);              \
+        else if (xv == 4) GWM(K, 1, 4);              \
+        else GWM(K, 1, 1);
+        if (c < 9) { GWM_ALL(gwgrad_multi_kernel) } else { GWM_ALL(gwgrad3_multi_kernel) }
+#undef GWM_ALL
+#undef GWM
+    }
+    MI_CHECK_LAUNCH("gwgrad_multi_kernel");
+    hipLaunchKernelGGL(gwgrad_reduce_multi_kernel, dim3((unsigned)rblocks), dim3(256), 0, s, (const GWgD*)tdev, n);
+    MI_CHECK_LAUNCH("gwgrad_reduce_multi_kernel");
     return MI_OK;
 }
 

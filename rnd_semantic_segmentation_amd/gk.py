@@ -18,7 +18,7 @@ class _TimedLib:
 
     def __getattr__(self, name):
         fn = getattr(_lib.lib(), name)
-        if name.endswith(("_workspace", "_elems")):
+        if name.endswith(("_workspace", "_elems", "_bytes")):
             return fn
 
         def call(*args):
@@ -151,6 +151,44 @@ def gconv_wgrad(dy, x, dw, geom, accumulate=False):
     check(L.mi_gconv_wgrad(py, ldy, px, ldx, _p(dw), B, Ha, Wa, I, Ho, Wo, O, kh, kw, sh, sw, ph, pw, dh, dw_, int(accumulate), _p(ws), ws.numel(), _p(tk),
                            tk.numel() if tk is not None else 0, _stream()), "mi_gconv_wgrad")
     return dw
+
+
+class _WgradJob(ctypes.Structure):
+    """include/mi355seg.h: MiWgradJob"""
+    _fields_ = ([("dy", ctypes.c_void_p), ("ldy", ctypes.c_long), ("x", ctypes.c_void_p), ("ldx", ctypes.c_long), ("dw", ctypes.c_void_p)] +
+                [(_k, ctypes.c_int) for _k in ("B", "Ha", "Wa", "I", "Ho", "Wo", "O", "kh", "kw", "sh", "sw", "ph", "pw", "dh", "dw_", "accumulate")])
+
+
+def gconv_wgrad_multi(jobs):
+    """The weight gradients of many convs in one go: jobs = [(dy, x, dw, geom, accumulate), ...] with gconv_wgrad's operands; no two jobs may share a dw."""
+    if not jobs:
+        return
+    n = len(jobs)
+    arr = (_WgradJob * n)()
+    flops = 0.0
+    for j, (dy, x, dw, geom, accumulate) in zip(arr, jobs):
+        kh, kw, sh, sw, ph, pw, dh, dw_ = geom
+        B, Ho, Wo, O = dy.shape
+        _, Ha, Wa, I = x.shape
+        if not (dw.is_contiguous() and dw.dtype == torch.float32 and dw.numel() == O * I * kh * kw):
+            raise _lib.MiError("gconv_wgrad_multi: dw must be contiguous fp32 [O,I,kh,kw]")
+        py, ldy = view(dy, torch.bfloat16)
+        px, ldx = view(x, torch.bfloat16)
+        j.dy, j.ldy, j.x, j.ldx, j.dw = py.value if hasattr(py, "value") else py, ldy, px.value if hasattr(px, "value") else px, ldx, dw.data_ptr()
+        j.B, j.Ha, j.Wa, j.I, j.Ho, j.Wo, j.O = B, Ha, Wa, I, Ho, Wo, O
+        j.kh, j.kw, j.sh, j.sw, j.ph, j.pw, j.dh, j.dw_, j.accumulate = kh, kw, sh, sw, ph, pw, dh, dw_, int(accumulate)
+        flops += 2.0 * B * Ho * Wo * O * I * kh * kw
+    dev = jobs[0][0].device
+    L = _L()
+    pj = ctypes.cast(arr, ctypes.c_void_p)
+    need = L.mi_gconv_wgrad_multi_workspace(pj, n)
+    if not need:
+        raise _lib.MiError("gconv_wgrad_multi: a job has an empty or oversized shape")
+    ws = _workspace(need, dev, "gwgrad_multi")
+    table = _workspace(L.mi_gconv_wgrad_multi_table_bytes(n), dev, "gwgrad_table")
+    if _K.PROFILE is not None:
+        _work[0], _work[1] = flops, ("gwgrad_multi", n, 0, 0, 0, 0, 0)
+    check(L.mi_gconv_wgrad_multi(pj, n, _p(table), table.numel(), _p(ws), ws.numel(), _stream()), "mi_gconv_wgrad_multi")
 
 
 def gconv_pack_multi(wflat, wp, wpt, table_dev, n_desc, total_blocks):

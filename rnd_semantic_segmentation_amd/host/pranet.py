@@ -177,6 +177,7 @@ class _Run:
 
     def __init__(self, net, train, rec):
         self.net, self.train, self.rec, self.tape, self.side = net, train, rec, [], None
+        self.wq, self.wq_slots = None, None            # weight gradients queued during backward (see _conv_backward)
         # fp32: the evaluation forward in the reference's precision (csrc/gf32.hip; _Engine.set_precision): every activation fp32, every conv with
         # its eval()-BatchNorm affine, residual and activation in one launch
         self.f32 = (not train) and getattr(net, "precision", "bf16") == "fp32"
@@ -293,7 +294,16 @@ class _Run:
                                  out=tgt if (tgt is not None and tgt.is_contiguous()) else None)
                 _acc(x, dx, True)
             return
-        _off_path(side, lambda: gk.gconv_wgrad(dy, x.t, slot, u.geom, accumulate=acc), dy, x.t)
+        if self.wq is not None and side is None:
+            # queued: the whole backward's weight gradients run as one table-driven launch at the end of the tape (gk.gconv_wgrad_multi) - alone each
+            # is a 25 - 60 us latency chain of which 15 - 25 us are fixed.  The queue keeps dy and x alive until then; a slot that is already in the
+            # queue (a module applied twice) flushes first, so that the accumulation order stays the tape's.
+            if slot.data_ptr() in self.wq_slots:
+                self.flush_wgrads()
+            self.wq.append((dy, x.t, slot, u.geom, acc))
+            self.wq_slots.add(slot.data_ptr())
+        else:
+            _off_path(side, lambda: gk.gconv_wgrad(dy, x.t, slot, u.geom, accumulate=acc), dy, x.t)
         if x.needs:
             dx, _ = gk.gconv(dy, u.wpt, u.cin, u.geom, out=_grad_target(x), mode=gk.GATHER_DGRAD, out_hw=(x.t.shape[1], x.t.shape[2]))
             _acc(x, dx, True)
@@ -456,11 +466,20 @@ class _Run:
         self.record(gather)
         return parts, slots
 
+    def flush_wgrads(self):
+        if self.wq:
+            gk.gconv_wgrad_multi(self.wq)
+        if self.wq is not None:
+            self.wq, self.wq_slots = [], set()
+
     def backward(self):
         self.side = _SideStream.get(self.net._store.data.device) if os.environ.get("MI_TAPE_WGRAD_STREAM", "0") == "1" else None
+        self.wq, self.wq_slots = ([], set()) if os.environ.get("MI_WGRAD_BATCH", "1") != "0" else (None, None)
         for fn in reversed(self.tape):
             fn()
         self.tape = []
+        self.flush_wgrads()
+        self.wq = None
         if self.side is not None:
             self.side.join()          # the caller (optimizer, gradient exchange) sees complete weight gradients on its own stream
 

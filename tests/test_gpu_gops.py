@@ -178,6 +178,41 @@ def test_fused_row_weight_gradient_on_a_large_map(gk):
         assert torch.equal(dw, dw2)
 
 
+def test_weight_gradients_of_many_convs_in_one_launch(gk):
+    """gk.gconv_wgrad_multi (the tape's end-of-backward flush): every conv case of this file - all operand alignment classes, strides, dilations, 1 x 7 /
+    7 x 1 / 5 x 5 kernels, the fused kernel row where the geometry allows it - plus a 16 x 44 x 44 map with several K splits, queued together; each gradient
+    against torch in float64, accumulate on half of them, and the whole call twice: the same bits."""
+    jobs, refs, keep = [], [], []
+    cases = list(CONV_CASES) + [(52, 52, (3, 3), (1, 1), (1, 1), (1, 1), 16, 44, 44, (208, 52), (52, 0)), (104, 104, (3, 3), (1, 1), (1, 1), (1, 1), 4, 22, 22, (104, 0), (104, 0))]
+    for n, case in enumerate(cases):
+        Cin, Cout, k, s, p, d, B, H, W, (ldi, offi), (ldo, offo) = case
+        x, w, geom = _conv_setup(case, 900 + n)
+        wd = w.to(torch.bfloat16).double().requires_grad_(True)
+        y = F.conv2d(x.double(), wd, None, s, p, d)
+        dy = _rand(tuple(y.shape), 40 + n)
+        y.backward(dy.double())
+        _, dyv = _embed(_nhwc(dy).cuda(), ldo, offo)
+        _, xv = _embed(_nhwc(x).cuda(), ldi, offi)
+        acc = n % 2 == 1
+        dw = torch.full(tuple(w.shape), 0.25 if acc else float("nan"), device="cuda")
+        jobs.append((dyv, xv, dw, geom, acc))
+        refs.append(wd.grad + (0.25 if acc else 0.0))
+        keep.append((dyv, xv))
+    gk.gconv_wgrad_multi(jobs)
+    torch.cuda.synchronize()
+    first = [j[2].clone() for j in jobs]
+    for case, j, ref in zip(cases, jobs, refs):
+        err = float((j[2].double().cpu() - ref).abs().max()) / float(ref.abs().max())
+        assert err < 2e-5, "multi wgrad %s: %.3e" % (case, err)
+    for j in jobs:
+        j[2].fill_(0.25 if j[4] else float("nan"))
+    gk.gconv_wgrad_multi(jobs)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, j[2]) for a, j in zip(first, jobs))
+    with pytest.raises(Exception, match="same gradient"):
+        gk.gconv_wgrad_multi([jobs[0], jobs[0]])
+
+
 def test_gconv_weight_gradient_is_bit_reproducible_and_splits_k(gk):
     """M = 16 x 44 x 44 pixels: several K splits; two runs give the same bits (fixed-order slab reduction)."""
     x = _rand((16, 52, 44, 44), 1)
