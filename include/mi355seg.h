@@ -340,7 +340,7 @@ int mi_gconv_wgrad(const void* dy, long ldy, const void* x, long ldx, float* dw,
  * before the optimizer; reference: the autograd of nn.Conv2d.weight, PraNet_Res2Net.py:7-20, hardnet_68.py:56-80).  Each job is mi_gconv_wgrad's argument
  * list; two jobs must not name the same dw.  table_dev: device scratch of mi_gconv_wgrad_multi_table_bytes(n) bytes; workspace: device scratch of
  * mi_gconv_wgrad_multi_workspace(jobs, n) bytes (fp32 split-K slabs of all jobs).  Launches: the table writers (descriptors travel as kernel arguments),
- * one main kernel per operand-alignment class, one reducer.  The K split per job is ~24 steps of 64 pixels (MI_GWM_STEPS) - not mi_gconv_wgrad's split, so the
+ * one main kernel per operand-alignment class, one reducer.  The K split per job is ~48 steps of 64 pixels (MI_GWM_STEPS) - not mi_gconv_wgrad's split, so the
  * fp32 summation order (not the result beyond rounding) differs from the one-conv call. */
 typedef struct MiWgradJob {
     const void* dy; long ldy; const void* x; long ldx; float* dw;

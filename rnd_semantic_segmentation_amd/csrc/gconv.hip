@@ -946,7 +946,7 @@ __global__ __launch_bounds__(256, 2) void gwgrad3_kernel(GWgP p) {
 // queues them and flushes the queue once per backward: a descriptor table in device memory (written by gw_table_kernel from kernel arguments - no host
 // buffer that a HIP graph would have to keep alive), one main launch per operand-alignment class in which every workgroup finds its conv by binary
 // search over the table's first-block column, and ONE reducer launch for all slabs.  With the whole backward's gradients in flight together a conv needs
-// no split count that fills the chip by itself: the K range per workgroup is ~24 steps (MI_GWM_STEPS) and the slabs shrink accordingly.
+// no split count that fills the chip by itself: the K range per workgroup is ~48 steps (MI_GWM_STEPS; 8: 894, 16: 915, 24: 911, 48: 917 images/s on PraNet, GALD 44.0 / 42.7 / 42.5 / 42.2 ms) and the slabs shrink accordingly.
 struct alignas(16) GWgD {
     GWgP p;
     int first_block, nblk;        // main launch of the conv's class: its workgroups are [first_block, first_block + nblk), first_block a multiple of 8 (XCD phase)
@@ -993,10 +993,48 @@ __global__ __launch_bounds__(256, 2) void gwgrad3_multi_kernel(const GWgD* __res
     gwgrad3_body<YVEC, XVEC>(p, b, table[at].nblk, smem);
 }
 
+// The reducer of the table-driven launch: a thread owns four consecutive i of one (t, o) - the lanes of a wave read 1 KiB runs of a slab - and adds the
+// splits in ascending order, eight loads in flight (the one-conv reducer spreads an element's splits over 8 lanes: with the 2 - 80 splits of this path most
+// of those lanes idle, and the wave's reads are 32-byte pieces: 0.66 ms per PraNet step for ~300 MB).
 __global__ __launch_bounds__(256) void gwgrad_reduce_multi_kernel(const GWgD* __restrict__ table, int n) {
     const int at = gw_find(table, 0, n, blockIdx.x, true);
     const GWgP p = table[at].p;
-    gwgrad_reduce_body(p.slab, p.dwout, p.O, p.I, p.T, p.S, p.accumulate, blockIdx.x - table[at].first_rblock, table[at].n_rblk);
+    const int bid = blockIdx.x - table[at].first_rblock, nblk = table[at].n_rblk;
+    const int Ip = (p.I + 3) & ~3, I4 = Ip >> 2;
+    const long n4 = (long)p.T * p.O * I4;
+    const long sstride = (long)p.T * p.O * Ip;
+    const float* __restrict__ slab = p.slab;
+    float* __restrict__ dw = p.dwout;
+    for (long e = (long)bid * 256 + threadIdx.x; e < n4; e += (long)nblk * 256) {
+        const int i = (int)(e % I4) * 4;
+        const long r = e / I4;
+        const int o = (int)(r % p.O), t = (int)(r / p.O);
+        const float* src = slab + e * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        int s0 = 0;
+        for (; s0 + 8 <= p.S; s0 += 8) {
+            f32x4 b[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) b[k] = *reinterpret_cast<const f32x4*>(src + (s0 + k) * sstride);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v += b[k];
+        }
+        {
+            f32x4 b[8];                                   // the tail: clamped loads, masked adds (same order)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) b[k] = *reinterpret_cast<const f32x4*>(src + (s0 + k < p.S ? s0 + k : p.S - 1) * sstride);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (s0 + k < p.S) v += b[k];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (i + c < p.I) {
+                float* d = dw + ((long)o * p.I + i + c) * p.T + t;
+                *d = p.accumulate ? *d + v[c] : v[c];
+            }
+        }
+    }
 }
 
 void gwgrad_plan(int M, int O, int I, int T, int* S, int* rows, int* ot, int* it) {
@@ -1270,7 +1308,7 @@ static bool gwm_fused(const MiWgradJob& j, long M) {
     return can && mode != 0 && (always || mode == 2 || M >= 65536);
 }
 static void gwm_plan(const MiWgradJob& j, GWgD& d) {
-    static const int steps = getenv("MI_GWM_STEPS") ? atoi(getenv("MI_GWM_STEPS")) : 24;
+    static const int steps = getenv("MI_GWM_STEPS") ? atoi(getenv("MI_GWM_STEPS")) : 48;
     GWgP& p = d.p;
     p.remap = mi_sw().gconv_remap;
     p.dbg = 0;
@@ -1284,7 +1322,7 @@ static void gwm_plan(const MiWgradJob& j, GWgD& d) {
     p.kw = j.kw; p.sh = j.sh; p.sw = j.sw; p.ph = j.ph; p.pw = j.pw; p.dh = j.dh; p.dw = j.dw_;
     p.o_tiles = (j.O + WTO - 1) / WTO;
     p.i_tiles = (j.I + WTI - 1) / WTI;
-    int S = (p.M + WKP * (steps > 0 ? steps : 24) - 1) / (WKP * (steps > 0 ? steps : 24));
+    int S = (p.M + WKP * (steps > 0 ? steps : 48) - 1) / (WKP * (steps > 0 ? steps : 48));
     if (S < 1) S = 1;
     int r = rup((p.M + S - 1) / S, WKP);
     p.rows_per_split = r;
@@ -1294,8 +1332,8 @@ static void gwm_plan(const MiWgradJob& j, GWgD& d) {
     p.accumulate = j.accumulate;
     const bool fused = gwm_fused(j, p.M);
     d.nblk = p.o_tiles * p.i_tiles * (fused ? j.kh : p.T) * p.S;
-    const long n = (long)j.O * j.I * p.T;
-    d.n_rblk = (int)((n + 31) / 32 < 1024 ? (n + 31) / 32 : 1024);
+    const long n4 = (long)j.O * ((j.I + 3) / 4) * p.T;                  // the reducer's threads: four consecutive i each
+    d.n_rblk = (int)((n4 + 255) / 256 < 512 ? (n4 + 255) / 256 : 512);
 }
 static inline size_t gwm_slab_bytes(const GWgD& d) { return ((size_t)d.p.S * d.p.T * d.p.O * ((d.p.I + 3) & ~3) * sizeof(float) + 255) & ~(size_t)255; }
 
