@@ -266,19 +266,24 @@ __global__ __launch_bounds__(256) void gcolsum_partial_kernel(const TG* g, long 
         red[1][threadIdx.x][j] = s2[j];
     }
     __syncthreads();
-    if (ty == 0) {
-        if (c0 < C) {
+    // the row lanes meet in a fixed tree (lane ty takes lane ty + stride, stride = ty_n / 2 ... 1): log2(ty_n) parallel steps.  The first version had the
+    // tx_n threads of row lane 0 add all ty_n lanes one after the other - with 32 channels that is 4 threads x 1024 LDS reads, 4 of the launch's 13 us.
+    for (int stride = ty_n >> 1; stride > 0; stride >>= 1) {
+        if (ty < stride) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                float a = 0.f, b = 0.f;
-                for (int k = 0; k < ty_n; ++k) {
-                    a += red[0][k * tx_n + tx][j];
-                    b += red[1][k * tx_n + tx][j];
-                }
-                if (c0 + j < C) {
-                    partial[((long)blockIdx.x * 2 + 0) * C + c0 + j] = a;
-                    partial[((long)blockIdx.x * 2 + 1) * C + c0 + j] = b;
-                }
+                red[0][threadIdx.x][j] += red[0][threadIdx.x + stride * tx_n][j];
+                red[1][threadIdx.x][j] += red[1][threadIdx.x + stride * tx_n][j];
+            }
+        }
+        __syncthreads();
+    }
+    if (ty == 0 && c0 < C) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            if (c0 + j < C) {
+                partial[((long)blockIdx.x * 2 + 0) * C + c0 + j] = red[0][tx][j];
+                partial[((long)blockIdx.x * 2 + 1) * C + c0 + j] = red[1][tx][j];
             }
         }
     }
