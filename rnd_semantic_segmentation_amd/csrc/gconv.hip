@@ -44,7 +44,7 @@ struct GConvP {
     long lda, ldo;
     int M, N, Ca, Cpad, Npad, T;
     int Ha, Wa, Ho, Wo;
-    int kw, sh, sw, ph, pw, dh, dw, mode, nchunks, remap;
+    int kw, sh, sw, ph, pw, dh, dw, mode, nchunks, remap, dbg;
     // in-launch BatchNorm finalize (fin_out != null; the launch has at most MI_INLAUNCH_MAX_PARTS row tiles): the arguments of mi_gbn_finalize
     unsigned* fin_ticket;      // one zeroed word per column tile
     float* fin_out;            // [4][N]: mean, invstd, scale, shift
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
 
     // two register sets: the chunk after next is in flight while the next one waits in registers and the current one is in LDS
     bf16x8 ra0[2 * AQ], rb0[BROWS], ra1[2 * AQ], rb1[BROWS];
-    const int total = p.T * p.nchunks;
+    const int total = (p.dbg & 1) ? 0 : p.T * p.nchunks;
     // load() is called for it = 0, 1, 2, ... in order: (tap, chunk, ky, kx) advance with it instead of being divided out of it on every call
     // (counters of one launch: 113 VALU + 143 SALU instructions per wave and K step beside 16 MFMAs - the waves were issuing index arithmetic half
     // of their time)
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);      // D rows = channels, D columns = pixels: a lane ends up with FOUR CONSECUTIVE CHANNELS of one pixel
         }
     };
     // every load and every LDS write below is issued unconditionally (past the last chunk the lanes read the zero page into a buffer nobody reads): with a
@@ -281,12 +281,15 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
         constexpr int CSW = BN + 4;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const int n = n0 + j * 16 + frow;
-            const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+            float bv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + j * 16 + fq * 4 + r;
+                bv[r] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Cs[(wave * 32 + i * 16 + fq * 4 + r) * CSW + j * 16 + frow] = acc[i][j][r] + bv;
+                *reinterpret_cast<f32x4*>(Cs + (wave * 32 + i * 16 + frow) * CSW + j * 16 + fq * 4) = f32x4{acc[i][j][0] + bv[0], acc[i][j][1] + bv[1], acc[i][j][2] + bv[2], acc[i][j][3] + bv[3]};
         }
         __syncthreads();
         float* out = reinterpret_cast<float*>(p.out);
@@ -299,22 +302,47 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
         __bf16* Cs = reinterpret_cast<__bf16*>(smem);
         constexpr int CSW = BN + 8;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int n = n0 + j * 16 + frow;
-            const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+        for (int j = 0; j < NT; ++j) {                       // (one 8-byte LDS write per 16 x 16 block and lane: its four consecutive channels of pixel row frow)
+            float bv[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + j * 16 + fq * 4 + r;
+                bv[r] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+            }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Cs[(wave * 32 + i * 16 + fq * 4 + r) * CSW + j * 16 + frow] = (__bf16)(acc[i][j][r] + bv);
+            for (int i = 0; i < 2; ++i) {
+                union { __bf16 h[4]; uint64_t u; } pk;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pk.h[r] = (__bf16)(acc[i][j][r] + bv[r]);
+                *reinterpret_cast<uint64_t*>(Cs + (wave * 32 + i * 16 + frow) * CSW + j * 16 + fq * 4) = pk.u;
+            }
         }
         __syncthreads();
         __bf16* out = reinterpret_cast<__bf16*>(p.out);
         constexpr int OW = OVEC == 4 ? 8 : OVEC;     // channels per store slot
         constexpr int G = BN / OW;                   // store slots per row
+        if constexpr (OVEC == 8) {
+            // (the tile's LDS reads are issued together, then the stores: a read inside the bounds branch waits for itself before every store)
+            constexpr int TRIPS = GBM * G / 256;
+            bf16x8 v[TRIPS];
+#pragma unroll
+            for (int k = 0; k < TRIPS; ++k) {
+                const int idx = tid + k * 256;
+                const int row = idx / G, cg = idx - row * G;
+                v[k] = *reinterpret_cast<const bf16x8*>(Cs + row * CSW + cg * OW);
+            }
+#pragma unroll
+            for (int k = 0; k < TRIPS; ++k) {
+                const int idx = tid + k * 256;
+                const int row = idx / G, cg = idx - row * G;
+                const int m = m0 + row, n = n0 + cg * OW;
+                if (m < p.M && n < p.N && !(p.dbg & 4)) *reinterpret_cast<bf16x8*>(out + (long)m * p.ldo + n) = v[k];
+            }
+        } else
         for (int idx = tid; idx < GBM * G; idx += 256) {
             const int row = idx / G, cg = idx - row * G;
             const int m = m0 + row, n = n0 + cg * OW;
-            if (m < p.M && n < p.N) {
+            if (m < p.M && n < p.N && !(p.dbg & 4)) {
                 __bf16* dst = out + (long)m * p.ldo + n;
                 const __bf16* src = Cs + row * CSW + cg * OW;
                 if constexpr (OVEC == 8) *reinterpret_cast<bf16x8*>(dst) = *reinterpret_cast<const bf16x8*>(src);
@@ -327,7 +355,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
                 } else *dst = *src;
             }
         }
-        if (p.stats) {
+        if (p.stats && !(p.dbg & 2)) {
             // thread -> (column, row group): fixed-order sums over the group's rows, then over the groups
             constexpr int RG = 256 / BN > 0 ? 256 / BN : 1;      // 8 | 4 | 2 row groups
             constexpr int RPG = GBM / RG;
@@ -335,13 +363,15 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
             const int col = tid % BN, rg = tid / BN;
             if (rg < RG) {
                 float s1 = 0.f, s2 = 0.f;
+                // (unconditional LDS reads + a select: with the read inside the row-bound branch every one of the 16 - 64 rows was its own LDS round trip -
+                //  15 of the 63 us of a 104 -> 256 conv at 16 x 88 x 88; adding 0 for a row past M leaves the sums' bits as they were)
+#pragma unroll 8
                 for (int r = 0; r < RPG; ++r) {
                     const int row = rg * RPG + r;
-                    if (m0 + row < p.M) {
-                        const float v = (float)Cs[row * CSW + col];
-                        s1 += v;
-                        s2 += v * v;
-                    }
+                    const float raw = (float)Cs[row * CSW + col];
+                    const float v = m0 + row < p.M ? raw : 0.f;
+                    s1 += v;
+                    s2 += v * v;
                 }
                 red[(rg * 2 + 0) * BN + col] = s1;
                 red[(rg * 2 + 1) * BN + col] = s2;
@@ -452,7 +482,12 @@ void glaunch_a(const GConvP& p, int avec, int ovec, bool f32, hipStream_t s) {
 template <int BN>
 void glaunch_k(GConvP& p, int avec, int ovec, bool f32, hipStream_t s) {
     if constexpr (BN <= 64) {
-        if (p.Cpad >= 64 && p.T * ((p.Cpad + 63) / 64) >= 2 && mi_sw().gconv_kc != 32) {
+        // 64-channel chunks halve the K steps; a 1x1 conv on a large map (thousands of workgroups with 2 - 4 steps each) gains more from the occupancy of
+        // the 32-channel tile (30 KB of LDS instead of 55: 104 -> 256 at 16 x 88 x 88 54.7 vs 63.7 us, 208 -> 512 at 44 x 44 33.5 vs 41.0)
+        static const int kc32_wgs = getenv("MI_GCONV_KC32_WGS") ? atoi(getenv("MI_GCONV_KC32_WGS")) : 1536;
+        const long wgs = (long)((p.M + GBM - 1) / GBM) * ((p.N + BN - 1) / BN);
+        const bool small_k_big_m = p.T == 1 && wgs >= kc32_wgs && mi_sw().gconv_kc != 64;
+        if (p.Cpad >= 64 && p.T * ((p.Cpad + 63) / 64) >= 2 && mi_sw().gconv_kc != 32 && !small_k_big_m) {
             p.nchunks = (p.Cpad + 63) / 64;
             glaunch_a<BN, 64>(p, avec, ovec, f32, s);
             return;
@@ -1177,6 +1212,7 @@ static int gconv_impl(const void* a, long lda, const void* wp, void* out, long l
     p.mode = mode;
     p.nchunks = p.Cpad / 32;
     p.remap = mi_sw().gconv_remap;
+    { static const int dbg = getenv("MI_GC_DBG") ? atoi(getenv("MI_GC_DBG")) : 0; p.dbg = dbg; }
     p.fin_ticket = fin ? fin->ticket : nullptr;
     p.fin_out = fin ? fin->out : nullptr;
     p.gamma = fin ? fin->gamma : nullptr;
