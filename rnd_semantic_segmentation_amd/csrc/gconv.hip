@@ -1228,11 +1228,12 @@ static int gconv_impl(const void* a, long lda, const void* wp, void* out, long l
     else MI_REQUIRE((reinterpret_cast<uintptr_t>(out) & 3) == 0, "mi_gconv: fp32 output must be 4-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const long mt = (p.M + GBM - 1) / GBM;
+    static const int bn32_wgs = getenv("MI_GCONV_BN32_WGS") ? atoi(getenv("MI_GCONV_BN32_WGS")) : 256;
     if (out_f32) {
         MI_REQUIRE(N <= 32, "mi_gconv: fp32 outputs are the one-channel side maps (N <= 32), got N = %d", N);
         glaunch_k<32>(p, avec, 1, true, s);
     } else if (N <= 32) glaunch_k<32>(p, avec, ovec, false, s);
-    else if (mt * ((N + 63) / 64) < 256) glaunch_k<32>(p, avec, ovec, false, s);          // few pixels (1/32 resolution): narrower tiles, more workgroups
+    else if (mt * ((N + 63) / 64) < bn32_wgs) glaunch_k<32>(p, avec, ovec, false, s);     // few pixels (1/16, 1/32 resolution): narrower tiles, more workgroups
     else if (N <= 64 || N % 128 == 64 || mt * ((N + 127) / 128) < 512 || !mi_sw().gconv_bn128 || fin) glaunch_k<64>(p, avec, ovec, false, s);      // (the in-launch finalize lives in the 32- / 64-wide instances)
     else glaunch_k<128>(p, avec, ovec, false, s);
     MI_CHECK_LAUNCH("gconv_kernel");
