@@ -202,7 +202,7 @@ def aux_workload(args, device):
         tsec, fl, n = by[dom]
         # counters of the dominant kernel class from the separate rocprofv3 --pmc passes of tools/profile_aux.sh (profiles/pmc_<workload>.json,
         # written by profiles/make_pmc_any.py: FETCH_SIZE x 2 x 1024, WRITE_SIZE x 1024): they say which resource the class is nearer to
-        pmc_class = {"gconv": "gconv_kernel", "gconv_wgrad": "gwgrad_kernel", "gbn_bwd_sums": "gcolsum_partial_kernel", "gbn_bwd_apply": "gbn_bwd_apply_kernel",
+        pmc_class = {"gconv": "gconv_kernel", "gconv_wgrad": "gwgrad_kernel", "gconv_wgrad_multi": "gwgrad_multi_kernel", "gbn_bwd_sums": "gcolsum_partial_kernel", "gbn_bwd_apply": "gbn_bwd_apply_kernel",
                      "gbn_apply": "gbn_apply_kernel", "gbinary": "gbinary_kernel", "gbn_finalize": "gbn_finalize_kernel"}.get(dom, dom)
         traffic = hbm_frac = busy = src = whole = None
         try:

@@ -30,29 +30,44 @@ __global__ __launch_bounds__(256) void gdw_fwd_kernel(const __bf16* x, const flo
 #pragma unroll
         for (int t = 0; t < 9; ++t) wt[t] = w[c * 9 + t];
         const float bv = bias ? bias[c] : 0.f;
-        for (int r = ry; r < DW_TILE; r += 4) {
-            const long m = (long)blockIdx.x * DW_TILE + r;
-            if (m >= M) break;
-            const int ow = (int)(m % q.Wo);
-            const long tt = m / q.Wo;
-            const int oh = (int)(tt % q.Ho), b = (int)(tt / q.Ho);
-            float acc = bv;
+        // Two pixels per trip, their 18 taps loaded UNCONDITIONALLY at clamped coordinates and selected afterwards: with the loads inside the padding
+        // branches every tap was its own memory round trip - 288 dependent loads per thread, 90 us for the 8 - 36 workgroups of a local-attention
+        // module (the taps are added in the same order, so the sums keep their bits).
+        for (int r0 = ry; r0 < DW_TILE; r0 += 8) {
+            float xv[2][9];
+            bool ok[2][9];
+            long ms[2];
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int ih = oh * q.stride - q.pad + ky;
-                if ((unsigned)ih >= (unsigned)q.H) continue;
+            for (int u = 0; u < 2; ++u) {
+                const long m = (long)blockIdx.x * DW_TILE + r0 + 4 * u;
+                ms[u] = m;
+                const long mm = m < M ? m : M - 1;
+                const int ow = (int)(mm % q.Wo);
+                const long tt = mm / q.Wo;
+                const int oh = (int)(tt % q.Ho), b = (int)(tt / q.Ho);
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int iw = ow * q.stride - q.pad + kx;
-                    if ((unsigned)iw >= (unsigned)q.W) continue;
-                    acc += (float)x[(((long)b * q.H + ih) * q.W + iw) * q.ldx + c] * wt[ky * 3 + kx];
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int ih = oh * q.stride - q.pad + ky;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int iw = ow * q.stride - q.pad + kx;
+                        ok[u][ky * 3 + kx] = ((unsigned)ih < (unsigned)q.H) & ((unsigned)iw < (unsigned)q.W);
+                        xv[u][ky * 3 + kx] = (float)x[(((long)b * q.H + min(max(ih, 0), q.H - 1)) * q.W + min(max(iw, 0), q.W - 1)) * q.ldx + c];
+                    }
                 }
             }
-            const __bf16 o = (__bf16)acc;
-            out[m * q.ldo + c] = o;
-            const float v = (float)o;                  // statistics of the ROUNDED output, as gconv.hip
-            s1 += v;
-            s2 += v * v;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (r0 + 4 * u >= DW_TILE || ms[u] >= M) break;
+                float acc = bv;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc = ok[u][t] ? __builtin_fmaf(xv[u][t], wt[t], acc) : acc;
+                const __bf16 o = (__bf16)acc;
+                out[ms[u] * q.ldo + c] = o;
+                const float v = (float)o;                  // statistics of the ROUNDED output, as gconv.hip
+                s1 += v;
+                s2 += v * v;
+            }
         }
     }
     if (stats) {

@@ -798,14 +798,25 @@ __global__ __launch_bounds__(256) void gresize_bwd_pix_kernel(const T* dout, T* 
             if (wh == 0.f) continue;
             float rsum = 0.f;
             const T* drow = dout + (((long)b * q.Ho + oh) * q.Wo) * q.ldo + c;
-            for (int ow = wlo; ow <= whi; ++ow) {
-                int w0, wp;
-                float wl;
-                rs_src(ow, q.sw, q.align, q.W, w0, wp, wl);
-                float ww = 0.f;
-                if (w0 == iw) ww += 1.f - wl;
-                if (w0 + wp == iw) ww += wl;
-                if (ww != 0.f) rsum += ww * ldf(drow + (long)ow * q.ldo);
+            // eight candidates per trip: weights first, then eight UNCONDITIONAL loads (a candidate past the range re-reads the last one with weight 0),
+            // then the adds in ascending order - with the load inside `if (ww != 0)` every contributing pixel was its own memory round trip (a 1/32 -> 1/4
+            // gradient of 256 channels: 1 024 dependent loads per wave, 650 us)
+            for (int ow = wlo; ow <= whi; ow += 8) {
+                float ww[8], v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int oc = min(ow + u, whi);
+                    int w0, wp;
+                    float wl;
+                    rs_src(oc, q.sw, q.align, q.W, w0, wp, wl);
+                    float w_ = 0.f;
+                    w_ += w0 == iw ? 1.f - wl : 0.f;
+                    w_ += w0 + wp == iw ? wl : 0.f;
+                    ww[u] = ow + u <= whi ? w_ : 0.f;
+                    v[u] = ldf(drow + (long)oc * q.ldo);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) rsum = ww[u] != 0.f ? __builtin_fmaf(ww[u], v[u], rsum) : rsum;
             }
             s += wh * rsum;
         }
@@ -881,18 +892,25 @@ __global__ __launch_bounds__(256) void gresize_bwd8_kernel(const __bf16* dout, _
 #pragma unroll
         for (int k = 0; k < 8; ++k) rsum[k] = 0.f;
         const __bf16* drow = dout + (((long)b * q.Ho + oh) * q.Wo) * q.ldo + c;
-        for (int ow = wlo; ow <= whi; ++ow) {
-            int w0, wp;
-            float wl;
-            rs_src(ow, q.sw, q.align, q.W, w0, wp, wl);
-            float ww = 0.f;
-            if (w0 == iw) ww += 1.f - wl;
-            if (w0 + wp == iw) ww += wl;
-            if (ww != 0.f) {
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(drow + (long)ow * q.ldo);
+        for (int ow = wlo; ow <= whi; ow += 4) {                 // (four candidates per trip, loads unconditional: see gresize_bwd_pix_kernel)
+            float ww[4];
+            bf16x8 v[4];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) rsum[k] += ww * (float)v[k];
+            for (int u = 0; u < 4; ++u) {
+                const int oc = min(ow + u, whi);
+                int w0, wp;
+                float wl;
+                rs_src(oc, q.sw, q.align, q.W, w0, wp, wl);
+                float w_ = 0.f;
+                w_ += w0 == iw ? 1.f - wl : 0.f;
+                w_ += w0 + wp == iw ? wl : 0.f;
+                ww[u] = ow + u <= whi ? w_ : 0.f;
+                v[u] = *reinterpret_cast<const bf16x8*>(drow + (long)oc * q.ldo);
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) rsum[k] = ww[u] != 0.f ? __builtin_fmaf(ww[u], (float)v[u][k], rsum[k]) : rsum[k];
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) s[k] += wh * rsum[k];
@@ -1150,7 +1168,7 @@ int mi_gresize(const void* x, long ldx, void* out, long ldo, int f32, int B, int
     } else {       // x = dx (written), out = dout (read)
         const long nsrc = (long)B * H * W * C;
         const float mag = (scale_h > 0.f ? 1.f / scale_h : (float)Ho) * (scale_w > 0.f ? 1.f / scale_w : (float)Wo);
-        if (vec8 && mag < 64.f) {                        // bf16 feature maps with 16-byte views: thread per (source pixel, 8 channels)
+        if (vec8 && mag <= 256.f) {                      // bf16 feature maps with 16-byte views: thread per (source pixel, 8 channels)
             const long items = (long)B * H * W * (C / 8);
             hipLaunchKernelGGL(gresize_bwd8_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, (const __bf16*)out, (__bf16*)const_cast<void*>(x), q);
         } else if (C >= 8 && mag >= 4.f) {               // feature maps / class logits: one wave per source pixel, lanes over the channels

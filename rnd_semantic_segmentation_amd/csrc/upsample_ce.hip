@@ -194,14 +194,14 @@ __global__ void ce_bwd_kernel(const float* __restrict__ logits, const int64_t* _
 // pass 1: one workgroup per (b, y, tile of JT low-res columns).  Threads compute, ONCE per high-res pixel, the
 // interpolated logits, the loss term and d = softmax - onehot into LDS; then (j,k) items gather the pixels of
 // their column support in ascending x:  tmp[b][y][j][k] = sum_x wx(x,j) d[x][k].
-constexpr int JT = 32;
+constexpr int JT = 32;              // the largest tile; the launcher narrows it for large upsample factors (pick_jt)
 
 // KT > 0: the class count is a compile-time constant (19 for Cityscapes: exact-length register loops instead of 32 predicated
 // iterations); KT == 0: K is read from the arguments.
 template <int KT>
 __global__ __launch_bounds__(256) void upce_pass1_kernel(const float* __restrict__ low, const int64_t* __restrict__ labels,
                                                          float* __restrict__ partial, float* __restrict__ tmp, int B, int Krt, Axis ay,
-                                                         Axis ax, int ignore_index, int npx_max, unsigned* __restrict__ bad) {
+                                                         Axis ax, int ignore_index, int npx_max, unsigned* __restrict__ bad, int jt_cols) {
     const int K = KT > 0 ? KT : Krt;
     constexpr int KR = KT > 0 ? KT : KMAX;          // register array length
     extern __shared__ __attribute__((aligned(16))) float sh[];
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void upce_pass1_kernel(const float* __restrict
     float* vrow = red + 512 + JT + 4;                // [JT+2][K] low-res row already interpolated along y
     const int H = ay.n_out, W = ax.n_out, h = ay.n_in, w = ax.n_in;
     const int jt = blockIdx.x, y = blockIdx.y, b = blockIdx.z;
-    const int j0 = jt * JT, j1 = min(w, j0 + JT);
+    const int j0 = jt * jt_cols, j1 = min(w, j0 + jt_cols);
     const int xa = ax.first_with_i0_ge(j0 - 1), xb = ax.first_with_i0_ge(j1);   // pixels with x0 in [j0-1, j1-1]
     const int npx = xb - xa;
     int y0, y1;
@@ -364,11 +364,20 @@ __global__ void upsample_softmax_kernel(const float* __restrict__ low, float* __
 
 inline unsigned nblk(long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
-inline int pass1_npx_max(const Axis& ax) {
-    // upper bound of pixels whose x0 falls in JT+1 consecutive source columns
+inline int pass1_npx_max(const Axis& ax, int jt_cols) {
+    // upper bound of pixels whose x0 falls in jt_cols+1 consecutive source columns
     if (ax.scale <= 0.f) return ax.n_out;
-    const long n = (long)((float)(JT + 1) / ax.scale) + 4;
+    const long n = (long)((float)(jt_cols + 1) / ax.scale) + 4;
     return (int)(n < ax.n_out ? n : ax.n_out);
+}
+
+// Low-res columns per workgroup: 32 up to an 8x upsample, fewer above (a tile of 32 columns at 32x is 1 056 pixels x 19 classes = 80 KB of LDS: one
+// workgroup per CU - the 1/32 head of GALD took 788 us against 204 us for the 1/4 head with the same 5.5 M pixels); about 256 pixels per tile.
+inline int pick_jt(int w, int W) {
+    const int f = w > 0 ? (W + w - 1) / w : 1;
+    int jt = JT;
+    while (jt > 4 && jt * f > 256) jt >>= 1;
+    return jt;
 }
 
 }  // namespace
@@ -415,7 +424,8 @@ extern "C" int mi_softmax_ce_bwd(const float* logits, const int64_t* labels, con
 }
 
 extern "C" size_t mi_upsample_ce_workspace(int B, int h, int w, int K, int H, int W) {
-    const size_t tiles = (size_t)((w + JT - 1) / JT);
+    const int jt_cols = pick_jt(w, W);
+    const size_t tiles = (size_t)((w + jt_cols - 1) / jt_cols);
     const size_t partial = (size_t)B * H * tiles * 2 * sizeof(float);
     const size_t tmp = (size_t)B * H * w * K * sizeof(float);
     return ((partial + 255) & ~(size_t)255) + tmp;
@@ -437,11 +447,12 @@ extern "C" int mi_upsample_ce_ex(const float* low, const int64_t* labels, float*
     MI_REQUIRE(H <= 65535 && B <= 65535, "mi_upsample_ce: grid dimension overflow");
     if (workspace_bytes < mi_upsample_ce_workspace(B, h, w, K, H, W)) return mi_set_error(MI_ENOMEM, "mi_upsample_ce: workspace too small");
     const Axis ay = make_axis(h, H, align_corners), ax = make_axis(w, W, align_corners);
-    const int tiles = (w + JT - 1) / JT;
+    const int jt_cols = pick_jt(w, W);
+    const int tiles = (w + jt_cols - 1) / jt_cols;
     float* partial = (float*)workspace;
     const size_t poff = (((size_t)B * H * tiles * 2 * sizeof(float)) + 255) & ~(size_t)255;
     float* tmp = dlow ? (float*)((char*)workspace + poff) : nullptr;
-    const int npx_max = pass1_npx_max(ax);
+    const int npx_max = pass1_npx_max(ax, jt_cols);
     const size_t lds = (size_t)npx_max * K * 4 + (size_t)npx_max * 8 + 512 * 4 + (JT + 4) * 4 + (size_t)(JT + 2) * K * 4;
     MI_REQUIRE(lds <= 160 * 1024, "mi_upsample_ce: upsample factor too large for one LDS tile (%zu B)", lds);
     static std::atomic<uint64_t> lds_set[2];           // the launch size varies with the upsample factor: allow the maximum once per device
@@ -451,10 +462,10 @@ extern "C" int mi_upsample_ce_ex(const float* low, const int64_t* labels, float*
     if (hipMemsetAsync(bad, 0, sizeof(unsigned), (hipStream_t)stream) != hipSuccess) return mi_set_error(MI_EHIP, "mi_upsample_ce: memset");
     if (K == 19)
         hipLaunchKernelGGL(upce_pass1_kernel<19>, dim3(tiles, H, B), dim3(256), lds, (hipStream_t)stream, low, labels, partial, tmp, B, K, ay,
-                           ax, ignore_index, npx_max, bad);
+                           ax, ignore_index, npx_max, bad, jt_cols);
     else
         hipLaunchKernelGGL(upce_pass1_kernel<0>, dim3(tiles, H, B), dim3(256), lds, (hipStream_t)stream, low, labels, partial, tmp, B, K, ay,
-                           ax, ignore_index, npx_max, bad);
+                           ax, ignore_index, npx_max, bad, jt_cols);
     MI_CHECK_LAUNCH("mi_upsample_ce pass1");
     hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partial, B * H * tiles, loss_out);
     MI_CHECK_LAUNCH("mi_upsample_ce finalize");
