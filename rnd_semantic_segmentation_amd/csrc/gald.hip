@@ -243,11 +243,33 @@ __global__ __launch_bounds__(256) void gcca_bwd_a_kernel(const __bf16* kv, const
     const int h = (int)(tt % p.H), b = (int)(tt / p.H);
     const int J = p.H + p.W;
     const __bf16* gp = dagg + pix * lddagg;
-    for (int j = tid; j < J; j += 256) {
-        const __bf16* vp = vv + cca_cand(p, b, h, w, j) * p.ldv;
-        float s = 0.f;
-        for (int c = 0; c < p.C; ++c) s += (float)gp[c] * (float)vp[c];
-        d[j] = s;
+    // datt: four lanes per candidate, each a quarter of the channels in 8-channel pieces (16-byte loads where the views allow), the four partial sums
+    // added in lane order.  (The first version gave a candidate to ONE thread - 62 of 256 busy, 2 x 256 dependent 2-byte loads each: 306 us per launch.)
+    {
+        const bool vec = (p.C & 7) == 0 && (p.ldv & 7) == 0 && (lddagg & 7) == 0 && ((reinterpret_cast<uintptr_t>(vv) | reinterpret_cast<uintptr_t>(dagg)) & 15) == 0;
+        const int sub = tid & 3;
+        const int cq = ((p.C + 3) / 4 + 7) & ~7;                    // channels per lane, a multiple of 8
+        const int c_lo = sub * cq, c_hi = min(p.C, c_lo + cq);
+        for (int j0 = 0; j0 < J; j0 += 64) {
+            const int j = j0 + (tid >> 2);
+            float s = 0.f;
+            if (j < J) {
+                const __bf16* vp = vv + cca_cand(p, b, h, w, j) * p.ldv;
+                if (vec) {
+                    for (int c = c_lo; c < c_hi; c += 8) {
+                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(gp + c), bb = *reinterpret_cast<const bf16x8*>(vp + c);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) s += (float)a[k] * (float)bb[k];
+                    }
+                } else {
+                    for (int c = c_lo; c < c_hi; ++c) s += (float)gp[c] * (float)vp[c];
+                }
+            }
+            const float s1 = __shfl_xor(s, 1, 64);
+            const float pair = (sub & 1) ? s1 + s : s + s1;         // (lane 0 + lane 1), (lane 2 + lane 3): the same operand order on both lanes
+            const float other = __shfl_xor(pair, 2, 64);
+            if (sub == 0 && j < J) d[j] = pair + other;
+        }
     }
     __syncthreads();
     float dot = 0.f;
@@ -266,11 +288,30 @@ __global__ __launch_bounds__(256) void gcca_bwd_a_kernel(const __bf16* kv, const
         de[pix * J + j] = v;
     }
     __syncthreads();
-    for (int c = tid; c < p.Cq; c += 256) {
-        float acc = 0.f;
-        for (int j = 0; j < J; ++j)
-            if (j != h) acc += d[j] * (float)kv[cca_cand(p, b, h, w, j) * p.ldk + c];
-        dq[pix * lddq + c] = (__bf16)acc;
+    // dq: the candidates are dealt to 256 / Cq' thread groups (Cq' = Cq rounded up to a power of two <= 256), each thread adds its group's candidates in
+    // ascending order with unconditional loads, the groups meet in LDS in group order (Cq = 32: 8 groups instead of 32 busy threads and 62 serial loads)
+    {
+        int cw = 1;
+        while (cw < p.Cq && cw < 256) cw <<= 1;
+        const int groups = 256 / cw, g = tid / cw, c = tid % cw;
+        for (int c0 = 0; c0 < p.Cq; c0 += cw) {
+            float acc = 0.f;
+            const int cc = c0 + c;
+            if (cc < p.Cq) {
+                for (int j = g; j < J; j += groups) {
+                    const float kvv = (float)kv[cca_cand(p, b, h, w, j) * p.ldk + cc];
+                    acc += j != h ? d[j] * kvv : 0.f;
+                }
+            }
+            __syncthreads();
+            redv[tid] = acc;
+            __syncthreads();
+            if (g == 0 && cc < p.Cq) {
+                float tot = 0.f;
+                for (int gg = 0; gg < groups; ++gg) tot += redv[gg * cw + c];
+                dq[pix * lddq + cc] = (__bf16)tot;
+            }
+        }
     }
 }
 // part B (per pixel, gather form): this pixel (b, h', w') is candidate h' of every pixel of its column and candidate H + w' of every pixel of

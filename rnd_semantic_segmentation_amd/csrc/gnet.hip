@@ -786,6 +786,16 @@ __global__ __launch_bounds__(256) void gresize_bwd_pix_kernel(const T* dout, T* 
     int hlo, hhi, wlo, whi;
     range(ih, q.sh, q.Ho, hlo, hhi);
     range(iw, q.sw, q.Wo, wlo, whi);
+    {   // the range is padded by two on both sides: trim the columns that do not touch iw, so that the unconditional loads below fetch contributors only
+        auto touches = [&](int ow) {
+            int w0, wp;
+            float wl;
+            rs_src(ow, q.sw, q.align, q.W, w0, wp, wl);
+            return w0 == iw || w0 + wp == iw;
+        };
+        while (wlo < whi && !touches(wlo)) ++wlo;
+        while (whi > wlo && !touches(whi)) --whi;
+    }
     for (int c = lane; c < q.C; c += 64) {
         float s = 0.f;
         for (int oh = hlo; oh <= hhi; ++oh) {
@@ -877,6 +887,16 @@ __global__ __launch_bounds__(256) void gresize_bwd8_kernel(const __bf16* dout, _
     int hlo, hhi, wlo, whi;
     range(ih, q.sh, q.Ho, hlo, hhi);
     range(iw, q.sw, q.Wo, wlo, whi);
+    {   // the range is padded by two on both sides: trim the columns that do not touch iw, so that the unconditional loads below fetch contributors only
+        auto touches = [&](int ow) {
+            int w0, wp;
+            float wl;
+            rs_src(ow, q.sw, q.align, q.W, w0, wp, wl);
+            return w0 == iw || w0 + wp == iw;
+        };
+        while (wlo < whi && !touches(wlo)) ++wlo;
+        while (whi > wlo && !touches(whi)) --whi;
+    }
     float s[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) s[k] = 0.f;
