@@ -10,6 +10,8 @@
 
 namespace {
 
+__device__ __attribute__((aligned(256))) uint32_t g_nzero[64];          // what an absent optional operand (mask, y) is read from: loads stay unconditional
+
 __device__ __forceinline__ float ldf(const __bf16* p) { return (float)*p; }
 __device__ __forceinline__ float ldf(const float* p) { return *p; }
 __device__ __forceinline__ void stf(__bf16* p, float v) { *p = (__bf16)v; }
@@ -160,8 +162,8 @@ __global__ __launch_bounds__(256) void gbn_apply_kernel(const __bf16* y, long ld
         ldp<VEC>(shift + c0, sh);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) v[j] = v[j] * sc[j] + sh[j];
+        ldv<VEC>(add ? add + m * ldadd + c0 : reinterpret_cast<const __bf16*>(g_nzero), a);       // (unconditional: an absent residual reads zeros)
         if (add) {
-            ldv<VEC>(add + m * ldadd + c0, a);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) v[j] += a[j];
         }
@@ -221,19 +223,19 @@ __global__ __launch_bounds__(256) void gcolsum_partial_kernel(const TG* g, long 
         for (; m + 3L * ty_n < rend; m += 4L * ty_n) {
             float gv[4][VEC], yv[4][VEC], mv[4][VEC];
 #pragma unroll
+            // (the twelve loads of a trip are issued back to back: an absent mask / y is read from a zero page instead of being branched around - with
+            //  `if (mask) load` the compiler waited for every optional load inside its own block, eight dependent round trips per trip)
             for (int u = 0; u < 4; ++u) {
                 const long mm = m + (long)u * ty_n;
                 ldv<VEC>(g + mm * ldg + c0, gv[u]);
-                if (mask) ldv<VEC>(mask + mm * ldm + c0, mv[u]);
-                if (y) ldv<VEC>(y + mm * ldy + c0, yv[u]);
+                ldv<VEC>(mask ? mask + mm * ldm + c0 : reinterpret_cast<const TM*>(g_nzero), mv[u]);
+                ldv<VEC>(y ? y + mm * ldy + c0 : reinterpret_cast<const __bf16*>(g_nzero), yv[u]);
             }
+            const bool has_mask = mask != nullptr;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (mask) {
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j)
-                        if (!(mv[u][j] > 0.f && mv[u][j] < hi)) gv[u][j] = 0.f;
-                }
+                for (int j = 0; j < VEC; ++j) gv[u][j] = (has_mask && !(mv[u][j] > 0.f && mv[u][j] < hi)) ? 0.f : gv[u][j];
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) s1[j] += gv[u][j];
                 if (y) {
@@ -245,16 +247,14 @@ __global__ __launch_bounds__(256) void gcolsum_partial_kernel(const TG* g, long 
         for (; m < rend; m += ty_n) {
             float gv[VEC], yv[VEC], mv[VEC];
             ldv<VEC>(g + m * ldg + c0, gv);
-            if (mask) {
-                ldv<VEC>(mask + m * ldm + c0, mv);
+            ldv<VEC>(mask ? mask + m * ldm + c0 : reinterpret_cast<const TM*>(g_nzero), mv);
+            ldv<VEC>(y ? y + m * ldy + c0 : reinterpret_cast<const __bf16*>(g_nzero), yv);
+            const bool has_mask = mask != nullptr;
 #pragma unroll
-                for (int j = 0; j < VEC; ++j)
-                    if (!(mv[j] > 0.f && mv[j] < hi)) gv[j] = 0.f;
-            }
+            for (int j = 0; j < VEC; ++j) gv[j] = (has_mask && !(mv[j] > 0.f && mv[j] < hi)) ? 0.f : gv[j];
 #pragma unroll
             for (int j = 0; j < VEC; ++j) s1[j] += gv[j];
             if (y) {
-                ldv<VEC>(y + m * ldy + c0, yv);
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) s2[j] += gv[j] * ((yv[j] - mu[j]) * is[j]);
             }
@@ -329,18 +329,18 @@ __global__ __launch_bounds__(256) void gbn_bwd_apply_kernel(const TG* g, long ld
         float gv[VEC], yv[VEC], mv[VEC], o[VEC];
         ldv<VEC>(g + m * ldg + c0, gv);
         ldv<VEC>(y + m * ldy + c0, yv);
-        if (mask) {
-            ldv<VEC>(mask + m * ldm + c0, mv);
+        ldv<VEC>(mask ? mask + m * ldm + c0 : reinterpret_cast<const TM*>(g_nzero), mv);       // (unconditional: see gcolsum_partial_kernel)
+        {
+            const bool has_mask = mask != nullptr;
 #pragma unroll
-            for (int j = 0; j < VEC; ++j)
-                if (!(mv[j] > 0.f && mv[j] < hi)) gv[j] = 0.f;
+            for (int j = 0; j < VEC; ++j) gv[j] = (has_mask && !(mv[j] > 0.f && mv[j] < hi)) ? 0.f : gv[j];
         }
         float is[VEC], mu[VEC], ga[VEC], db[VEC], dg[VEC];
         ldp<VEC>(invstd + c0, is);
         ldp<VEC>(mean + c0, mu);
         ldp<VEC>(dbeta + c0, db);
         ldp<VEC>(dgamma + c0, dg);
-        if (gamma) ldp<VEC>(gamma + c0, ga);
+        ldp<VEC>(gamma ? gamma + c0 : reinterpret_cast<const float*>(g_nzero), ga);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const float xhat = (yv[j] - mu[j]) * is[j];
