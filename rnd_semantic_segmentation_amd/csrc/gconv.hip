@@ -482,11 +482,11 @@ void glaunch_a(const GConvP& p, int avec, int ovec, bool f32, hipStream_t s) {
 template <int BN>
 void glaunch_k(GConvP& p, int avec, int ovec, bool f32, hipStream_t s) {
     if constexpr (BN <= 64) {
-        // 64-channel chunks halve the K steps; a 1x1 conv on a large map (thousands of workgroups with 2 - 4 steps each) gains more from the occupancy of
+        // 64-channel chunks halve the K steps; a conv on a large map (thousands of workgroups) gains more from the occupancy of
         // the 32-channel tile (30 KB of LDS instead of 55: 104 -> 256 at 16 x 88 x 88 54.7 vs 63.7 us, 208 -> 512 at 44 x 44 33.5 vs 41.0)
         static const int kc32_wgs = getenv("MI_GCONV_KC32_WGS") ? atoi(getenv("MI_GCONV_KC32_WGS")) : 1536;
         const long wgs = (long)((p.M + GBM - 1) / GBM) * ((p.N + BN - 1) / BN);
-        const bool small_k_big_m = p.T == 1 && wgs >= kc32_wgs && mi_sw().gconv_kc != 64;
+        const bool small_k_big_m = wgs >= kc32_wgs && mi_sw().gconv_kc != 64;          // (3x3 convs on large maps too: GALD 38.4 -> 37.6 ms with 32-channel chunks)
         if (p.Cpad >= 64 && p.T * ((p.Cpad + 63) / 64) >= 2 && mi_sw().gconv_kc != 32 && !small_k_big_m) {
             p.nchunks = (p.Cpad + 63) / 64;
             glaunch_a<BN, 64>(p, avec, ovec, f32, s);
