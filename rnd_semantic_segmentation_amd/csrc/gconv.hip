@@ -12,7 +12,7 @@
 // the 3-channel stem conv and the one-channel side outputs.  Channel counts that are not multiples of the 32-channel K chunk
 // are padded in LDS (zero fill on load), never in HBM.
 //
-// Tile: 128 pixels x BN channels (BN = 32 | 64 | 128), 4 waves, each 32 rows x BN columns of v_mfma_f32_16x16x32_bf16;
+// Tile: 128 pixels x BN channels (BN = 16 | 32 | 64 | 80 | 112 | 128, chosen per launch by a cost model: see mi_gconv), 4 waves, each 32 rows x BN columns of v_mfma_f32_16x16x32_bf16;
 // operands are register-staged (global -> VGPR -> LDS, double buffered): the sources are arbitrary-alignment slices, which the
 // LDS-DMA path of igemm_nt.hip (16-byte granules) cannot fetch.  The epilogue stages the tile in LDS, stores rows with
 // the widest access the view's alignment allows, and (optionally) emits per-tile column sums / sums of squares of the ROUNDED
@@ -111,7 +111,8 @@ template <int BN, int KC, bool OUTF32>
 struct GSmem {
     static constexpr int AB = 2 * (GBM + BN) * (KC + 8) * 2;                          // double-buffered operand tiles
     static constexpr int CS = OUTF32 ? GBM * (BN + 4) * 4 : GBM * (BN + 8) * 2;       // staged output tile
-    static constexpr int RED = 2 * (256 / BN > 0 ? 256 / BN : 1) * BN * 4;            // stats partials of the row groups
+    static constexpr int RG = BN <= 32 ? 8 : (BN <= 64 ? 4 : 2);                      // row groups of the statistics pass (a power of two, RG * BN <= 256)
+    static constexpr int RED = 2 * RG * BN * 4;                                       // stats partials of the row groups
     static constexpr int BYTES = (AB > CS + RED ? AB : CS + RED);
 };
 
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
         }
         if (p.stats && !(p.dbg & 2)) {
             // thread -> (column, row group): fixed-order sums over the group's rows, then over the groups
-            constexpr int RG = 256 / BN > 0 ? 256 / BN : 1;      // 8 | 4 | 2 row groups
+            constexpr int RG = GSmem<BN, KC, false>::RG;         // 8 | 4 | 2 row groups
             constexpr int RPG = GBM / RG;
             float* red = reinterpret_cast<float*>(smem + GSmem<BN, KC, false>::CS);
             const int col = tid % BN, rg = tid / BN;
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
                     st[p.N + n0 + tid] = s2;
                 }
             }
-            if constexpr (BN <= 64) {
+            if constexpr (BN == 32 || BN == 64) {
             if (p.fin_out) {
                 // The column tile's last workgroup turns the row tiles' sums into mean / invstd / folded affine and updates the running statistics with
                 // mi_gbn_finalize's arithmetic in its order - for at most 128 row tiles every tile is its own lane and the lanes are added in ascending order
@@ -481,7 +482,7 @@ void glaunch_a(const GConvP& p, int avec, int ovec, bool f32, hipStream_t s) {
 // BN = 128 keeps 32-channel chunks (its LDS image with 64 would pass the 64 KiB of static LDS)
 template <int BN>
 void glaunch_k(GConvP& p, int avec, int ovec, bool f32, hipStream_t s) {
-    if constexpr (BN <= 64) {
+    if constexpr (2 * (GBM + BN) * (64 + 8) * 2 <= 64 * 1024) {          // (BN <= 80: the 64-channel image fits the 64 KiB of static LDS)
         // 64-channel chunks halve the K steps; a conv on a large map (thousands of workgroups) gains more from the occupancy of
         // the 32-channel tile (30 KB of LDS instead of 55: 104 -> 256 at 16 x 88 x 88 54.7 vs 63.7 us, 208 -> 512 at 44 x 44 33.5 vs 41.0)
         static const int kc32_wgs = getenv("MI_GCONV_KC32_WGS") ? atoi(getenv("MI_GCONV_KC32_WGS")) : 1536;
@@ -1229,13 +1230,39 @@ static int gconv_impl(const void* a, long lda, const void* wp, void* out, long l
     hipStream_t s = (hipStream_t)stream;
     const long mt = (p.M + GBM - 1) / GBM;
     static const int bn32_wgs = getenv("MI_GCONV_BN32_WGS") ? atoi(getenv("MI_GCONV_BN32_WGS")) : 256;
+    static const bool bn_any = !(getenv("MI_GCONV_BN_ANY") && atoi(getenv("MI_GCONV_BN_ANY")) == 0);      // MI_GCONV_BN_ANY=0: tile widths 32 / 64 (/ 128) only
     if (out_f32) {
         MI_REQUIRE(N <= 32, "mi_gconv: fp32 outputs are the one-channel side maps (N <= 32), got N = %d", N);
         glaunch_k<32>(p, avec, 1, true, s);
-    } else if (N <= 32) glaunch_k<32>(p, avec, ovec, false, s);
-    else if (mt * ((N + 63) / 64) < bn32_wgs) glaunch_k<32>(p, avec, ovec, false, s);     // few pixels (1/16, 1/32 resolution): narrower tiles, more workgroups
-    else if (N <= 64 || N % 128 == 64 || mt * ((N + 127) / 128) < 512 || !mi_sw().gconv_bn128 || fin) glaunch_k<64>(p, avec, ovec, false, s);      // (the in-launch finalize lives in the 32- / 64-wide instances)
-    else glaunch_k<128>(p, avec, ovec, false, s);
+    } else if (fin || !bn_any) {                            // (the in-launch finalize lives in the 32- / 64-wide instances)
+        if (N <= 32) glaunch_k<32>(p, avec, ovec, false, s);
+        else if (mt * ((N + 63) / 64) < bn32_wgs) glaunch_k<32>(p, avec, ovec, false, s);      // few pixels (1/16, 1/32 resolution): narrower tiles, more workgroups
+        else if (N <= 64 || N % 128 == 64 || mt * ((N + 127) / 128) < 512 || !mi_sw().gconv_bn128 || fin) glaunch_k<64>(p, avec, ovec, false, s);
+        else glaunch_k<128>(p, avec, ovec, false, s);
+    } else if (N > 32 && mt * ((N + 63) / 64) < bn32_wgs) glaunch_k<32>(p, avec, ovec, false, s);
+    else {
+        // Tile width by a cost model fitted on HarDNet's shapes (tools/dbg/bn_width.sh: every width forced on every shape): a column tile costs its width
+        // plus ~64 columns' worth of fixed work (the A rows it re-reads, prologue, epilogue), so cost = ceil(N / w) * (w + 64).  N = 68 -> one 80-wide tile
+        // (248 vs 347 us for two 64-wide), 334 -> three 112-wide (221 vs 318), 256 -> four 64-wide; the least-padding rule tried first chose 16-wide tiles
+        // for N = 168 (1 270 us against 393).  MI_GCONV_BN_FORCE: one width for everything (measurement).
+        static const int widths[] = {64, 80, 112, 32, 16};
+        static const int force = getenv("MI_GCONV_BN_FORCE") ? atoi(getenv("MI_GCONV_BN_FORCE")) : 0;
+        static const int fixed = getenv("MI_GCONV_BN_C") ? atoi(getenv("MI_GCONV_BN_C")) : 64;
+        int best = 64;
+        long best_cost = 1L << 60;
+        for (int wdt : widths) {
+            const long cost = (long)((N + wdt - 1) / wdt) * (wdt + fixed);
+            if (cost < best_cost) best = wdt, best_cost = cost;
+        }
+        if (force) best = force;
+        switch (best) {
+            case 16: glaunch_k<16>(p, avec, ovec, false, s); break;
+            case 32: glaunch_k<32>(p, avec, ovec, false, s); break;
+            case 80: glaunch_k<80>(p, avec, ovec, false, s); break;
+            case 112: glaunch_k<112>(p, avec, ovec, false, s); break;
+            default: glaunch_k<64>(p, avec, ovec, false, s); break;
+        }
+    }
     MI_CHECK_LAUNCH("gconv_kernel");
     return MI_OK;
 }

@@ -56,6 +56,8 @@ CONV_CASES = [
     (104, 256, (1, 1), (1, 1), (0, 0), (1, 1), 3, 17, 9, (104, 0), (256, 0)),        # conv3
     (96, 96, (3, 3), (1, 1), (1, 1), (1, 1), 2, 12, 12, (96, 0), (96, 0)),           # partial decoder
     (64, 1, (3, 3), (1, 1), (1, 1), (1, 1), 2, 12, 12, (64, 0), (1, 0)),             # one-channel side output
+    (142, 68, (3, 3), (1, 1), (1, 1), (1, 1), 2, 12, 14, (142, 0), (262, 64)),       # HarDNet: 80-wide tile forward, 48-wide data gradient, 4-byte aligned views
+    (40, 14, (3, 3), (1, 1), (1, 1), (1, 1), 2, 12, 14, (64, 24), (78, 64)),         # HarDNet: 16-wide tile forward, 48-wide data gradient
 ]
 
 

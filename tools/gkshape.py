@@ -19,10 +19,11 @@ PRANET = [  # name, B, H, W, Cin, Cout, (kh, kw), dil, count per step
     ("rfb2 cat 3x3 128->32", 16, 44, 44, 128, 32, (3, 3), 1, 1), ("rfb4 1x1 2048->32", 16, 11, 11, 2048, 32, (1, 1), 1, 5),
     ("ra 5x5 256->256", 16, 11, 11, 256, 256, (5, 5), 1, 3), ("ra 3x3 64->64", 16, 22, 22, 64, 64, (3, 3), 1, 4),
 ]
-GALD = [
-    ("hd 3x3 466->168", 6, 90, 160, 466, 168, (3, 3), 1, 1), ("hd 3x3 124->48", 6, 180, 320, 124, 48, (3, 3), 1, 1), ("hd 3x3 64->14", 6, 180, 320, 64, 14, (3, 3), 1, 1),
-    ("hd 3x3 142->58", 6, 90, 160, 142, 58, (3, 3), 1, 1), ("hd 1x1 262->256", 6, 90, 160, 262, 256, (1, 1), 1, 1), ("hd 3x3 68->34", 6, 90, 160, 68, 34, (3, 3), 1, 1),
-    ("hd 3x3 328->70", 6, 45, 80, 328, 70, (3, 3), 1, 1), ("hd 3x3 1024? 640->1024 1x1", 6, 45, 80, 640, 1024, (1, 1), 1, 1),
+GALD = [  # HarDNet-68 trunk at 6 x 720 x 1280 (bench.py --workload gald with MI_BENCH_SHAPES=1 lists them)
+    ("hd 3x3 142->68 /4", 6, 180, 320, 142, 68, (3, 3), 1, 1), ("hd 3x3 102->40 /4", 6, 180, 320, 102, 40, (3, 3), 1, 1), ("hd 3x3 64->32 /2", 6, 360, 640, 64, 32, (3, 3), 1, 1),
+    ("hd 3x3 466->168 /8", 6, 90, 160, 466, 168, (3, 3), 1, 1), ("hd 3x3 134->296 /8", 6, 90, 160, 296, 134, (3, 3), 1, 1), ("hd 3x3 368->98 /8", 6, 90, 160, 368, 98, (3, 3), 1, 1),
+    ("hd 3x3 218->78 /8", 6, 90, 160, 218, 78, (3, 3), 1, 1), ("hd 3x3 740->334 /16", 6, 45, 80, 740, 334, (3, 3), 1, 1), ("hd 3x3 462->1072 /32", 6, 22, 40, 462, 1072, (3, 3), 1, 1),
+    ("hd 1x1 262->256 /8", 6, 90, 160, 262, 256, (1, 1), 1, 1), ("hd 3x3 124->48 /4", 6, 180, 320, 124, 48, (3, 3), 1, 1), ("hd 3x3 24->14 /4", 6, 180, 320, 24, 14, (3, 3), 1, 1),
 ]
 
 
