@@ -19,6 +19,10 @@ PRANET = [  # name, B, H, W, Cin, Cout, (kh, kw), dil, count per step
     ("rfb2 cat 3x3 128->32", 16, 44, 44, 128, 32, (3, 3), 1, 1), ("rfb4 1x1 2048->32", 16, 11, 11, 2048, 32, (1, 1), 1, 5),
     ("ra 5x5 256->256", 16, 11, 11, 256, 256, (5, 5), 1, 3), ("ra 3x3 64->64", 16, 22, 22, 64, 64, (3, 3), 1, 4),
 ]
+ALIGN = [  # the same conv with 16-byte aligned channel counts and with HarDNet's 4-byte aligned ones: what the unaligned 16-byte operand loads cost
+    ("3x3 144->72 aligned", 6, 180, 320, 144, 72, (3, 3), 1, 1), ("3x3 142->68", 6, 180, 320, 142, 68, (3, 3), 1, 1),
+    ("3x3 464->168 aligned", 6, 90, 160, 464, 168, (3, 3), 1, 1), ("3x3 466->168", 6, 90, 160, 466, 168, (3, 3), 1, 1),
+]
 GALD = [  # HarDNet-68 trunk at 6 x 720 x 1280 (bench.py --workload gald with MI_BENCH_SHAPES=1 lists them)
     ("hd 3x3 142->68 /4", 6, 180, 320, 142, 68, (3, 3), 1, 1), ("hd 3x3 102->40 /4", 6, 180, 320, 102, 40, (3, 3), 1, 1), ("hd 3x3 64->32 /2", 6, 360, 640, 64, 32, (3, 3), 1, 1),
     ("hd 3x3 466->168 /8", 6, 90, 160, 466, 168, (3, 3), 1, 1), ("hd 3x3 134->296 /8", 6, 90, 160, 296, 134, (3, 3), 1, 1), ("hd 3x3 368->98 /8", 6, 90, 160, 368, 98, (3, 3), 1, 1),
@@ -54,7 +58,7 @@ def main():
     kinds = (sys.argv[2] if len(sys.argv) > 2 else "fwd,dgrad,wgrad").split(",")
     tot = {k: 0.0 for k in kinds}
     print("%-28s %6s %5s | %s" % ("shape", "M", "steps", " | ".join("%-16s" % (k + " us (ns/step)") for k in kinds)))
-    for name, B, H, W, ci, co, (kh, kw), d, cnt in (PRANET if which == "pranet" else GALD):
+    for name, B, H, W, ci, co, (kh, kw), d, cnt in {"pranet": PRANET, "gald": GALD, "align": ALIGN}[which]:
         geom = (kh, kw, 1, 1, d * (kh // 2), d * (kw // 2), d, d)
         R = 4
         xs = [torch.randn((B, H, W, ci), device="cuda").to(torch.bfloat16) for _ in range(R)]
