@@ -20,6 +20,7 @@
 // that no separate pass over the conv output is needed for them.
 #include "mi_common.h"
 #include <type_traits>
+#include <atomic>
 #include <vector>
 #include <string.h>
 #include <stdlib.h>
@@ -116,13 +117,24 @@ struct GSmem {
     static constexpr int BYTES = (AB > CS + RED ? AB : CS + RED);
 };
 
-template <int BN, int KC, int AVEC, int OVEC, bool OUTF32, bool GEN = false>
-__global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
+// KS = 2 (launches that put at most ~one workgroup on a CU: the 22 x 22 / 11 x 11 maps): 512 threads, two wave groups that each run this main loop
+// over every other K chunk of the SAME tile through their own LDS stages - half as many serial K steps with nobody to share the CU with anyway - and meet
+// once at the end: group 1 hands its accumulators over through LDS (group 0's sum + group 1's sum, a fixed order), leaves, and group 0 runs the epilogue.
+template <int BN, int KC, int AVEC, int OVEC, bool OUTF32, bool GEN = false, int KS = 1>
+__global__ __launch_bounds__(256 * KS) void gconv_kernel(GConvP p) {
     constexpr int NT = BN / 16, GRS = KC + 8, AQ = KC / 32;
-    __shared__ __attribute__((aligned(16))) char smem[GSmem<BN, KC, OUTF32>::BYTES];
-    __bf16* As = reinterpret_cast<__bf16*>(smem);                         // [2][GBM][GRS]
+    char* smem;
+    if constexpr (KS == 1) {
+        __shared__ __attribute__((aligned(16))) char smem_static[GSmem<BN, KC, OUTF32>::BYTES];
+        smem = smem_static;
+    } else {
+        extern __shared__ __attribute__((aligned(16))) char smem_dynamic[];          // KS * AB bytes (the launcher asks for them)
+        smem = smem_dynamic;
+    }
+    const int grp = KS > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;      // wave group (wave-uniform)
+    __bf16* As = reinterpret_cast<__bf16*>(smem + grp * GSmem<BN, KC, OUTF32>::AB);        // [2][GBM][GRS]
     __bf16* Bs = As + 2 * GBM * GRS;                                      // [2][BN][GRS]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;                   // (position inside the wave group)
     // Tile order: the hardware dispatches workgroups x-fastest and round-robin over the 8 XCDs (each with its own L2).  Remapped so that one XCD
     // owns a CONTIGUOUS run of row tiles and walks the column tiles of a row tile back to back: the column tiles' re-reads of the A rows and the
     // halo rows that neighbouring row tiles of a 3x3 share are served by that XCD's L2 instead of being fetched once per XCD (MI_GCONV_REMAP=0:
@@ -155,7 +167,8 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
 
     // two register sets: the chunk after next is in flight while the next one waits in registers and the current one is in LDS
     bf16x8 ra0[2 * AQ], rb0[BROWS], ra1[2 * AQ], rb1[BROWS];
-    const int total = (p.dbg & 1) ? 0 : p.T * p.nchunks;
+    const int total_all = (p.dbg & 1) ? 0 : p.T * p.nchunks;
+    const int total = (total_all + KS - 1) / KS;          // K steps of this wave group: it takes the chunks grp, grp + KS, ...
     // load() is called for it = 0, 1, 2, ... in order: (tap, chunk, ky, kx) advance with it instead of being divided out of it on every call
     // (counters of one launch: 113 VALU + 143 SALU instructions per wave and K step beside 16 MFMAs - the waves were issuing index arithmetic half
     // of their time)
@@ -170,6 +183,15 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
     const int th = fwd ? p.dh : -p.dh, tw = fwd ? p.dw : -p.dw;
     const int base_h = fwd ? aoh * p.sh - p.ph : aoh + p.ph, base_w = fwd ? aow * p.sw - p.pw : aow + p.pw;
     const __bf16* arow0 = p.A + (((long)ab * p.Ha + base_h) * p.Wa + base_w) * p.lda;      // this thread's source row for tap (0, 0) (an address only: used where the tap lies inside the image)
+    auto advance = [&]() {                                 // (tap, chunk, ky, kx) one chunk further
+        const bool wrap = l_kc + 1 == p.nchunks;
+        const bool roww = wrap && l_kx + 1 == p.kw;
+        l_kc = wrap ? 0 : l_kc + 1;
+        l_tap += wrap ? 1 : 0;
+        l_kx = roww ? 0 : (wrap ? l_kx + 1 : l_kx);
+        l_ky += roww ? 1 : 0;
+    };
+    if (KS > 1 && grp) advance();                          // group 1 starts at chunk 1
     long boff[BROWS];                                      // this thread's weight rows: offset inside a tap's [Npad][Cpad] plane, channel offset, row in range
     int bch8[BROWS];
     bool brow_ok[BROWS];
@@ -182,16 +204,10 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
         boff[j] = (long)(n0 + nr) * p.Cpad + ch * 8;
     }
     auto load = [&](int it, bf16x8 (&ra)[2 * AQ], bf16x8 (&rb)[BROWS]) {
-        const bool live = it < total;                  // past the end: every lane reads the zero page (cheap, and keeps the issue unconditional)
+        const bool live = it * KS + grp < total_all;   // past the end: every lane reads the zero page (cheap, and keeps the issue unconditional)
         const int tap = l_tap, kc = l_kc, ky = l_ky, kx = l_kx;
-        {
-            const bool wrap = l_kc + 1 == p.nchunks;
-            const bool roww = wrap && l_kx + 1 == p.kw;
-            l_kc = wrap ? 0 : l_kc + 1;
-            l_tap += wrap ? 1 : 0;
-            l_kx = roww ? 0 : (wrap ? l_kx + 1 : l_kx);
-            l_ky += roww ? 1 : 0;
-        }
+#pragma unroll
+        for (int a = 0; a < KS; ++a) advance();
         bool ok = am_ok & live;                        // (& not &&: a short-circuit chain becomes branches)
         const __bf16* arow;
         if constexpr (GEN) {
@@ -279,6 +295,29 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConvP p) {
             stash(0, ra0, rb0);
             __syncthreads();
         }
+    }
+
+    if constexpr (KS > 1) {
+        // the two wave groups' partial sums meet: group 1 writes its accumulators (element-major: conflict-free), leaves; group 0 adds them to its own.
+        // The barriers after this point wait for the surviving waves only (s_barrier does not count terminated waves).
+        float* rbuf = reinterpret_cast<float*>(smem);          // [2 * NT * 4][256] floats (<= 32 KB; the operand stages are dead after the loop's last barrier)
+        if (grp) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) rbuf[((i * NT + j) * 4 + r) * 256 + tid] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (grp) return;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += rbuf[((i * NT + j) * 4 + r) * 256 + tid];
+        __syncthreads();
     }
 
     // ---- epilogue: (+ bias) -> LDS image of the tile -> row stores (+ column statistics of the rounded values)
@@ -463,6 +502,17 @@ void glaunch(const GConvP& p, hipStream_t s) {
     if (p.mode != MI_GATHER_FWD && (p.sh != 1 || p.sw != 1)) {                     // data gradient of a strided conv: the general source map
         hipLaunchKernelGGL((gconv_kernel<BN, KC, AVEC, OVEC, OUTF32, true>), grid, dim3(256), 0, s, p);
         return;
+    }
+    if constexpr (!OUTF32 && (BN == 32 || BN == 64) && KC == 64 && AVEC >= 4 && OVEC >= 4) {       // two wave groups over the K chunks (see KS above)
+        static const int ks2_wgs = getenv("MI_GCONV_KS2_WGS") ? atoi(getenv("MI_GCONV_KS2_WGS")) : 320;
+        if ((int)(grid.x * grid.y) <= ks2_wgs && p.T * p.nchunks >= 8) {
+            constexpr int bytes = 2 * GSmem<BN, KC, false>::AB;
+            static_assert(bytes >= GSmem<BN, KC, false>::CS + GSmem<BN, KC, false>::RED && bytes >= 2 * (BN / 16) * 4 * 256 * 4, "LDS of the two-group launch");
+            static std::atomic<uint64_t> attr;
+            mi_allow_dynamic_lds((const void*)gconv_kernel<BN, KC, AVEC, OVEC, false, false, 2>, bytes, attr);
+            hipLaunchKernelGGL((gconv_kernel<BN, KC, AVEC, OVEC, false, false, 2>), grid, dim3(512), bytes, s, p);
+            return;
+        }
     }
     hipLaunchKernelGGL((gconv_kernel<BN, KC, AVEC, OVEC, OUTF32>), grid, dim3(256), 0, s, p);
 }
@@ -1260,6 +1310,9 @@ static int gconv_impl(const void* a, long lda, const void* wp, void* out, long l
             const long cost = (long)((N + wdt - 1) / wdt) * (wdt + fixed);
             if (cost < best_cost) best = wdt, best_cost = cost;
         }
+        // (only where the wider tiles still leave the chip full: on the 11 x 11 / 22 x 22 maps a 2048-channel data gradient took 26 us as 304 112-wide
+        //  workgroups against 20 us as 512 64-wide ones)
+        if (best > 64 && mt * ((N + best - 1) / best) < 384) best = 64;
         if (force) best = force;
         switch (best) {
             case 16: glaunch_k<16>(p, avec, ovec, false, s); break;
