@@ -117,6 +117,183 @@ struct GSmem {
     static constexpr int BYTES = (AB > CS + RED ? AB : CS + RED);
 };
 
+// The conv epilogue (shared by gconv_kernel and gconv3_kernel): accumulators (+ bias) -> LDS image of the tile -> row stores, the column statistics of the
+// rounded values, and (small launches) the in-launch BatchNorm finalize.  acc[i][j]: rows wave * 32 + i * 16 + (lane & 15) hold FOUR CONSECUTIVE CHANNELS
+// j * 16 + (lane >> 4) * 4 .. + 3 per lane (MFMA with the weights as the first operand).
+template <int BN, int OVEC, bool OUTF32>
+__device__ __forceinline__ void gconv_epilogue(const GConvP& p, char* smem, f32x4 (&acc)[2][BN / 16], int tid, int m0, int n0, int mt, int nt, int m_tiles) {
+    constexpr int NT = BN / 16;
+    const int lane = tid & 63, wave = tid >> 6, frow = lane & 15;
+    // ---- epilogue: (+ bias) -> LDS image of the tile -> row stores (+ column statistics of the rounded values)
+    const int fq = lane >> 4;
+    if constexpr (OUTF32) {
+        float* Cs = reinterpret_cast<float*>(smem);
+        constexpr int CSW = BN + 4;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float bv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + j * 16 + fq * 4 + r;
+                bv[r] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                *reinterpret_cast<f32x4*>(Cs + (wave * 32 + i * 16 + frow) * CSW + j * 16 + fq * 4) = f32x4{acc[i][j][0] + bv[0], acc[i][j][1] + bv[1], acc[i][j][2] + bv[2], acc[i][j][3] + bv[3]};
+        }
+        __syncthreads();
+        float* out = reinterpret_cast<float*>(p.out);
+        for (int idx = tid; idx < GBM * BN; idx += 256) {
+            const int row = idx / BN, col = idx - row * BN;
+            const int m = m0 + row, n = n0 + col;
+            if (m < p.M && n < p.N) out[(long)m * p.ldo + n] = Cs[row * CSW + col];
+        }
+    } else {
+        __bf16* Cs = reinterpret_cast<__bf16*>(smem);
+        constexpr int CSW = BN + 8;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {                       // (one 8-byte LDS write per 16 x 16 block and lane: its four consecutive channels of pixel row frow)
+            float bv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + j * 16 + fq * 4 + r;
+                bv[r] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                union { __bf16 h[4]; uint64_t u; } pk;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pk.h[r] = (__bf16)(acc[i][j][r] + bv[r]);
+                *reinterpret_cast<uint64_t*>(Cs + (wave * 32 + i * 16 + frow) * CSW + j * 16 + fq * 4) = pk.u;
+            }
+        }
+        __syncthreads();
+        __bf16* out = reinterpret_cast<__bf16*>(p.out);
+        constexpr int OW = OVEC == 4 ? 8 : OVEC;     // channels per store slot
+        constexpr int G = BN / OW;                   // store slots per row
+        if constexpr (OVEC == 8) {
+            // (the tile's LDS reads are issued together, then the stores: a read inside the bounds branch waits for itself before every store)
+            constexpr int TRIPS = GBM * G / 256;
+            bf16x8 v[TRIPS];
+#pragma unroll
+            for (int k = 0; k < TRIPS; ++k) {
+                const int idx = tid + k * 256;
+                const int row = idx / G, cg = idx - row * G;
+                v[k] = *reinterpret_cast<const bf16x8*>(Cs + row * CSW + cg * OW);
+            }
+#pragma unroll
+            for (int k = 0; k < TRIPS; ++k) {
+                const int idx = tid + k * 256;
+                const int row = idx / G, cg = idx - row * G;
+                const int m = m0 + row, n = n0 + cg * OW;
+                if (m < p.M && n < p.N && !(p.dbg & 4)) *reinterpret_cast<bf16x8*>(out + (long)m * p.ldo + n) = v[k];
+            }
+        } else
+        for (int idx = tid; idx < GBM * G; idx += 256) {
+            const int row = idx / G, cg = idx - row * G;
+            const int m = m0 + row, n = n0 + cg * OW;
+            if (m < p.M && n < p.N && !(p.dbg & 4)) {
+                __bf16* dst = out + (long)m * p.ldo + n;
+                const __bf16* src = Cs + row * CSW + cg * OW;
+                if constexpr (OVEC == 8) *reinterpret_cast<bf16x8*>(dst) = *reinterpret_cast<const bf16x8*>(src);
+                else if constexpr (OVEC == 4) {       // 4-byte aligned rows, even N: one 16-byte store per full chunk, dword stores for the row's tail
+                    if (n + 8 <= p.N) {
+                        *reinterpret_cast<u32x4_a4*>(dst) = *reinterpret_cast<const u32x4*>(src);
+                    } else {
+                        for (int e = 0; n + e < p.N; e += 2) *reinterpret_cast<uint32_t*>(dst + e) = *reinterpret_cast<const uint32_t*>(src + e);
+                    }
+                } else *dst = *src;
+            }
+        }
+        if (p.stats && !(p.dbg & 2)) {
+            // thread -> (column, row group): fixed-order sums over the group's rows, then over the groups
+            constexpr int RG = GSmem<BN, 32, false>::RG;         // 8 | 4 | 2 row groups
+            constexpr int RPG = GBM / RG;
+            float* red = reinterpret_cast<float*>(smem + GSmem<BN, 32, false>::CS);
+            const int col = tid % BN, rg = tid / BN;
+            if (rg < RG) {
+                float s1 = 0.f, s2 = 0.f;
+                // (unconditional LDS reads + a select: with the read inside the row-bound branch every one of the 16 - 64 rows was its own LDS round trip -
+                //  15 of the 63 us of a 104 -> 256 conv at 16 x 88 x 88; adding 0 for a row past M leaves the sums' bits as they were)
+#pragma unroll 8
+                for (int r = 0; r < RPG; ++r) {
+                    const int row = rg * RPG + r;
+                    const float raw = (float)Cs[row * CSW + col];
+                    const float v = m0 + row < p.M ? raw : 0.f;
+                    s1 += v;
+                    s2 += v * v;
+                }
+                red[(rg * 2 + 0) * BN + col] = s1;
+                red[(rg * 2 + 1) * BN + col] = s2;
+            }
+            __syncthreads();
+            if (tid < BN && n0 + tid < p.N) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int g = 0; g < RG; ++g) {
+                    s1 += red[(g * 2 + 0) * BN + tid];
+                    s2 += red[(g * 2 + 1) * BN + tid];
+                }
+                float* st = p.stats + (long)mt * 2 * p.N;
+                if (p.fin_out) {                       // handed to the launch's last workgroup: write-through
+                    mi_st_sc1(st + n0 + tid, s1);
+                    mi_st_sc1(st + p.N + n0 + tid, s2);
+                } else {
+                    st[n0 + tid] = s1;
+                    st[p.N + n0 + tid] = s2;
+                }
+            }
+            if constexpr (BN == 32 || BN == 64) {
+            if (p.fin_out) {
+                // The column tile's last workgroup turns the row tiles' sums into mean / invstd / folded affine and updates the running statistics with
+                // mi_gbn_finalize's arithmetic in its order - for at most 128 row tiles every tile is its own lane and the lanes are added in ascending order
+                // (double): the same bits as the separate launch.  The loads of a channel are spread over the L = 256 / BN threads that share it (a few
+                // independent loads each, no register arrays that would cost the main loop its occupancy) and meet in LDS, one statistic at a time
+                // ([64][BN] floats: 16 KB at BN = 64); one thread per channel adds them.
+                if (mi_last_arriver(p.fin_ticket + nt, m_tiles, reinterpret_cast<int*>(smem))) {
+                    mi_acquire_partials();
+                    constexpr int L = 256 / BN;
+                    float* lanes = reinterpret_cast<float*>(smem + 16);                       // [MI_INLAUNCH_MAX_PARTS][BN]
+                    const int ch = tid % BN, j = tid / BN, tiles = m_tiles;
+                    const int cc = n0 + ch;
+                    double tot[2] = {0.0, 0.0};
+#pragma unroll
+                    for (int which = 0; which < 2; ++which) {
+                        if (cc < p.N) {
+#pragma unroll
+                            for (int q = 0; q < MI_INLAUNCH_MAX_PARTS / L; ++q) {
+                                const int t = j + q * L;
+                                lanes[t * BN + ch] = p.stats[(long)(t < tiles ? t : tiles - 1) * 2 * p.N + which * p.N + cc];
+                            }
+                        }
+                        __syncthreads();
+                        if (tid < BN && n0 + tid < p.N) {
+                            double sum = 0.0;
+                            for (int t = 0; t < tiles; ++t) sum += (double)lanes[t * BN + tid];
+                            tot[which] = sum;
+                        }
+                        __syncthreads();
+                    }
+                    const int c = n0 + tid;
+                    if (tid < BN && c < p.N) {
+                        const double s1 = tot[0], s2 = tot[1];
+                        const MiBnFin f = mi_bn_finalize_channel(s1, s2, p.count, p.eps, p.gamma ? p.gamma[c] : 1.f, p.beta ? p.beta[c] : 0.f);
+                        p.fin_out[c] = f.mean;
+                        p.fin_out[p.N + c] = f.invstd;
+                        p.fin_out[2 * p.N + c] = f.scale;
+                        p.fin_out[3 * p.N + c] = f.shift;
+                        if (p.running_mean) {
+                            p.running_mean[c] = mi_bn_running(p.running_mean[c], p.momentum, f.mean);
+                            p.running_var[c] = mi_bn_running(p.running_var[c], p.momentum, mi_bn_unbiased(f.var, p.count));
+                        }
+                    }
+                }
+            }
+            }
+        }
+    }
+}
+
 // KS = 2 (launches that put at most ~one workgroup on a CU: the 22 x 22 / 11 x 11 maps): 512 threads, two wave groups that each run this main loop
 // over every other K chunk of the SAME tile through their own LDS stages - half as many serial K steps with nobody to share the CU with anyway - and meet
 // once at the end: group 1 hands its accumulators over through LDS (group 0's sum + group 1's sum, a fixed order), leaves, and group 0 runs the epilogue.
@@ -320,180 +497,188 @@ __global__ __launch_bounds__(256 * KS) void gconv_kernel(GConvP p) {
         __syncthreads();
     }
 
-    // ---- epilogue: (+ bias) -> LDS image of the tile -> row stores (+ column statistics of the rounded values)
-    const int fq = lane >> 4;
-    if constexpr (OUTF32) {
-        float* Cs = reinterpret_cast<float*>(smem);
-        constexpr int CSW = BN + 4;
+    gconv_epilogue<BN, OVEC, OUTF32>(p, smem, acc, tid, m0, n0, mt, nt, m_tiles);
+}
+
+// ---- kernel-row window variant (round 4): stride-1 convs with three kernel columns whose output has the input's size (pad = dilation: the 3x3 / 1x3 convs of
+// HarDNet, Res2Net, RFB, the decoders) at large M.  Counters of gconv_kernel on such a launch (profiles/r04_gconv_144x72_counters.txt): 1.83 GB of L1 -> L2 reads
+// for 150 MB of tensors, 54 % of them the A rows that each of the nine taps fetches again.  The sources of 128 consecutive output pixels for the three taps of a
+// kernel row are ONE window of 128 + 2 d consecutive input pixels: a K step here is (kernel row, 32-channel chunk) - the window staged once, the three taps'
+// weight tiles beside it, 3 x 2 x NT MFMAs per wave from it (tap kx reads the window kx d rows further down).  A pixel whose tap leaves the image row reads a zero
+// row instead (two validity bits per pixel, as gwgrad3_kernel does on its dy side); a window row whose source lies outside the image / the tensor is staged as
+// zeros.  A third of the A loads, a third of the barriers; same epilogue, same accumulation order over (ky, chunk, kx) as ... no: gconv_kernel runs (tap, chunk),
+// this kernel (ky, chunk, kx) - results agree to fp32 rounding.
+constexpr int G3_MAXD = 8;                                   // largest column dilation the window holds
+constexpr int G3_ROWS = GBM + 2 * G3_MAXD;                   // 144 window rows (+ a zero row + a dummy row for the loader's out-of-window writes)
+constexpr int G3_GRS = 32 + 8;                               // LDS row stride (elements): 32-channel chunks
+template <int BN>
+struct G3Smem {
+    static constexpr int A = (G3_ROWS + 2) * G3_GRS * 2;
+    static constexpr int B = 3 * BN * G3_GRS * 2;
+    static constexpr int STAGE = A + B;
+    static constexpr int EPI = GSmem<BN, 32, false>::CS + GSmem<BN, 32, false>::RED;
+    static constexpr int BYTES = 2 * STAGE > EPI ? 2 * STAGE : EPI;
+};
+
+template <int BN, int AVEC, int OVEC>
+__global__ __launch_bounds__(256) void gconv3_kernel(GConvP p) {
+    constexpr int NT = BN / 16, GRS = G3_GRS, KC = 32;
+    __shared__ __attribute__((aligned(16))) char smem[G3Smem<BN>::BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int mt = blockIdx.x, nt = blockIdx.y;
+    const int m_tiles = gridDim.x;
+    if (p.remap) {
+        const int n_tiles = gridDim.y;
+        const int logical = mi_xcd_remap(blockIdx.y * m_tiles + blockIdx.x, m_tiles * n_tiles);
+        mt = logical / n_tiles;
+        nt = logical - mt * n_tiles;
+    }
+    const int m0 = mt * GBM, n0 = nt * BN;
+    const bool fwd = p.mode == MI_GATHER_FWD;
+    const int sgn = fwd ? 1 : -1, dwc = p.dw, hw = p.Ha * p.Wa;
+    const int wrows = GBM + 2 * dwc;                          // window rows in use
+
+    // ---- A loader: thread -> (window row, 16-channel half); rows 0 .. 127 by all threads, rows 128 .. 127 + 2 d by the first 4 d thread slots
+    const int ahalf = tid & 1;
+    int wr[2];                                               // this thread's two window rows (the second: a real row or the dummy row)
+    wr[0] = tid >> 1;
+    wr[1] = GBM + (tid >> 1);
+    const __bf16* arow0[2];
+    bool aok0[2];
+    int ah[2];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            float bv[4];
+    for (int h = 0; h < 2; ++h) {
+        const long pb = (long)m0 - dwc + wr[h];               // the window row's pixel for the centre kernel row (flat index)
+        const bool in_win = wr[h] < wrows;
+        aok0[h] = in_win && pb >= 0 && pb < (long)p.M;
+        const int pc = aok0[h] ? (int)pb : 0;
+        ah[h] = (pc % hw) / p.Wa;
+        arow0[h] = p.A + (long)pc * p.lda;
+        if (!in_win) wr[h] = G3_ROWS + 1;                    // dummy row: the write stays unconditional
+    }
+    // ---- B loader: three taps x BN rows x 4 chunks of 8 channels
+    constexpr int BCH = KC / 8, BLOADS = BN * BCH, BROWS = (BLOADS + 255) / 256;
+    long boff[BROWS];
+    int bch8[BROWS], bnr[BROWS];
+    bool brow_ok[BROWS];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + j * 16 + fq * 4 + r;
-                bv[r] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                *reinterpret_cast<f32x4*>(Cs + (wave * 32 + i * 16 + frow) * CSW + j * 16 + fq * 4) = f32x4{acc[i][j][0] + bv[0], acc[i][j][1] + bv[1], acc[i][j][2] + bv[2], acc[i][j][3] + bv[3]};
+    for (int j = 0; j < BROWS; ++j) {
+        const int idx = (tid + j * 256) % BLOADS;
+        const int nr = idx / BCH, ch = idx - nr * BCH;
+        bnr[j] = nr;
+        bch8[j] = ch * 8;
+        brow_ok[j] = n0 + nr < p.Npad;
+        boff[j] = (long)(n0 + nr) * p.Cpad + ch * 8;
+    }
+    const int kh = p.T / 3;
+    const int total = (p.dbg & 1) ? 0 : kh * p.nchunks;      // K steps: (kernel row, 32-channel chunk), chunk fastest
+    int l_ky = 0, l_kc = 0;
+    bf16x8 ra0[4], rb0[3 * BROWS], ra1[4], rb1[3 * BROWS];
+    auto load = [&](int it, bf16x8 (&ra)[4], bf16x8 (&rb)[3 * BROWS]) {
+        const bool live = it < total;
+        const int ky = l_ky, kc = l_kc;
+        {
+            const bool wrap = l_kc + 1 == p.nchunks;
+            l_kc = wrap ? 0 : l_kc + 1;
+            l_ky += wrap ? 1 : 0;
         }
-        __syncthreads();
-        float* out = reinterpret_cast<float*>(p.out);
-        for (int idx = tid; idx < GBM * BN; idx += 256) {
-            const int row = idx / BN, col = idx - row * BN;
-            const int m = m0 + row, n = n0 + col;
-            if (m < p.M && n < p.N) out[(long)m * p.ldo + n] = Cs[row * CSW + col];
+        const int off = sgn * (ky * p.dh - p.ph);             // source row - output row (wave-uniform)
+        const long aoff = (long)off * p.Wa * p.lda;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const bool ok = aok0[h] & live & ((unsigned)(ah[h] + off) < (unsigned)p.Ha);
+            bf16x8 two[2];
+            gload16<AVEC>(arow0[h] + aoff, kc * KC + ahalf * 16, p.Ca, ok, two);
+            ra[2 * h] = two[0];
+            ra[2 * h + 1] = two[1];
         }
-    } else {
-        __bf16* Cs = reinterpret_cast<__bf16*>(smem);
-        constexpr int CSW = BN + 8;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {                       // (one 8-byte LDS write per 16 x 16 block and lane: its four consecutive channels of pixel row frow)
-            float bv[4];
+        for (int kx = 0; kx < 3; ++kx) {
+            const __bf16* wt = p.Wp + ((long)(ky * 3 + kx) * p.Npad) * p.Cpad + kc * KC;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + j * 16 + fq * 4 + r;
-                bv[r] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                union { __bf16 h[4]; uint64_t u; } pk;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pk.h[r] = (__bf16)(acc[i][j][r] + bv[r]);
-                *reinterpret_cast<uint64_t*>(Cs + (wave * 32 + i * 16 + frow) * CSW + j * 16 + fq * 4) = pk.u;
+            for (int j = 0; j < BROWS; ++j) {
+                const bool bok = live & brow_ok[j];
+                rb[kx * BROWS + j] = *reinterpret_cast<const bf16x8*>(bok ? wt + boff[j] : reinterpret_cast<const __bf16*>(g_gzero));
             }
         }
-        __syncthreads();
-        __bf16* out = reinterpret_cast<__bf16*>(p.out);
-        constexpr int OW = OVEC == 4 ? 8 : OVEC;     // channels per store slot
-        constexpr int G = BN / OW;                   // store slots per row
-        if constexpr (OVEC == 8) {
-            // (the tile's LDS reads are issued together, then the stores: a read inside the bounds branch waits for itself before every store)
-            constexpr int TRIPS = GBM * G / 256;
-            bf16x8 v[TRIPS];
+    };
+    auto stash = [&](int buf, const bf16x8 (&ra)[4], const bf16x8 (&rb)[3 * BROWS]) {
+        __bf16* aw = reinterpret_cast<__bf16*>(smem + buf * G3Smem<BN>::STAGE);
+        __bf16* bw = reinterpret_cast<__bf16*>(smem + buf * G3Smem<BN>::STAGE + G3Smem<BN>::A);
 #pragma unroll
-            for (int k = 0; k < TRIPS; ++k) {
-                const int idx = tid + k * 256;
-                const int row = idx / G, cg = idx - row * G;
-                v[k] = *reinterpret_cast<const bf16x8*>(Cs + row * CSW + cg * OW);
-            }
-#pragma unroll
-            for (int k = 0; k < TRIPS; ++k) {
-                const int idx = tid + k * 256;
-                const int row = idx / G, cg = idx - row * G;
-                const int m = m0 + row, n = n0 + cg * OW;
-                if (m < p.M && n < p.N && !(p.dbg & 4)) *reinterpret_cast<bf16x8*>(out + (long)m * p.ldo + n) = v[k];
-            }
-        } else
-        for (int idx = tid; idx < GBM * G; idx += 256) {
-            const int row = idx / G, cg = idx - row * G;
-            const int m = m0 + row, n = n0 + cg * OW;
-            if (m < p.M && n < p.N && !(p.dbg & 4)) {
-                __bf16* dst = out + (long)m * p.ldo + n;
-                const __bf16* src = Cs + row * CSW + cg * OW;
-                if constexpr (OVEC == 8) *reinterpret_cast<bf16x8*>(dst) = *reinterpret_cast<const bf16x8*>(src);
-                else if constexpr (OVEC == 4) {       // 4-byte aligned rows, even N: one 16-byte store per full chunk, dword stores for the row's tail
-                    if (n + 8 <= p.N) {
-                        *reinterpret_cast<u32x4_a4*>(dst) = *reinterpret_cast<const u32x4*>(src);
-                    } else {
-                        for (int e = 0; n + e < p.N; e += 2) *reinterpret_cast<uint32_t*>(dst + e) = *reinterpret_cast<const uint32_t*>(src + e);
-                    }
-                } else *dst = *src;
-            }
+        for (int h = 0; h < 2; ++h) {
+            *reinterpret_cast<bf16x8*>(aw + wr[h] * GRS + ahalf * 16) = ra[2 * h];
+            *reinterpret_cast<bf16x8*>(aw + wr[h] * GRS + ahalf * 16 + 8) = ra[2 * h + 1];
         }
-        if (p.stats && !(p.dbg & 2)) {
-            // thread -> (column, row group): fixed-order sums over the group's rows, then over the groups
-            constexpr int RG = GSmem<BN, KC, false>::RG;         // 8 | 4 | 2 row groups
-            constexpr int RPG = GBM / RG;
-            float* red = reinterpret_cast<float*>(smem + GSmem<BN, KC, false>::CS);
-            const int col = tid % BN, rg = tid / BN;
-            if (rg < RG) {
-                float s1 = 0.f, s2 = 0.f;
-                // (unconditional LDS reads + a select: with the read inside the row-bound branch every one of the 16 - 64 rows was its own LDS round trip -
-                //  15 of the 63 us of a 104 -> 256 conv at 16 x 88 x 88; adding 0 for a row past M leaves the sums' bits as they were)
-#pragma unroll 8
-                for (int r = 0; r < RPG; ++r) {
-                    const int row = rg * RPG + r;
-                    const float raw = (float)Cs[row * CSW + col];
-                    const float v = m0 + row < p.M ? raw : 0.f;
-                    s1 += v;
-                    s2 += v * v;
-                }
-                red[(rg * 2 + 0) * BN + col] = s1;
-                red[(rg * 2 + 1) * BN + col] = s2;
-            }
-            __syncthreads();
-            if (tid < BN && n0 + tid < p.N) {
-                float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int g = 0; g < RG; ++g) {
-                    s1 += red[(g * 2 + 0) * BN + tid];
-                    s2 += red[(g * 2 + 1) * BN + tid];
-                }
-                float* st = p.stats + (long)mt * 2 * p.N;
-                if (p.fin_out) {                       // handed to the launch's last workgroup: write-through
-                    mi_st_sc1(st + n0 + tid, s1);
-                    mi_st_sc1(st + p.N + n0 + tid, s2);
-                } else {
-                    st[n0 + tid] = s1;
-                    st[p.N + n0 + tid] = s2;
-                }
-            }
-            if constexpr (BN == 32 || BN == 64) {
-            if (p.fin_out) {
-                // The column tile's last workgroup turns the row tiles' sums into mean / invstd / folded affine and updates the running statistics with
-                // mi_gbn_finalize's arithmetic in its order - for at most 128 row tiles every tile is its own lane and the lanes are added in ascending order
-                // (double): the same bits as the separate launch.  The loads of a channel are spread over the L = 256 / BN threads that share it (a few
-                // independent loads each, no register arrays that would cost the main loop its occupancy) and meet in LDS, one statistic at a time
-                // ([64][BN] floats: 16 KB at BN = 64); one thread per channel adds them.
-                if (mi_last_arriver(p.fin_ticket + nt, m_tiles, reinterpret_cast<int*>(smem))) {
-                    mi_acquire_partials();
-                    constexpr int L = 256 / BN;
-                    float* lanes = reinterpret_cast<float*>(smem + 16);                       // [MI_INLAUNCH_MAX_PARTS][BN]
-                    const int ch = tid % BN, j = tid / BN, tiles = m_tiles;
-                    const int cc = n0 + ch;
-                    double tot[2] = {0.0, 0.0};
+        for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-                    for (int which = 0; which < 2; ++which) {
-                        if (cc < p.N) {
+            for (int j = 0; j < BROWS; ++j) *reinterpret_cast<bf16x8*>(bw + (kx * BN + bnr[j]) * GRS + bch8[j]) = rb[kx * BROWS + j];
+    };
+    // the zero rows of both stages (row G3_ROWS), once
+    if (tid < 2 * (GRS / 2)) {
+        const int b = tid / (GRS / 2), e = tid % (GRS / 2);
+        reinterpret_cast<uint32_t*>(smem + b * G3Smem<BN>::STAGE + G3_ROWS * GRS * 2)[e] = 0u;
+    }
+
+    f32x4 acc[2][NT];
 #pragma unroll
-                            for (int q = 0; q < MI_INLAUNCH_MAX_PARTS / L; ++q) {
-                                const int t = j + q * L;
-                                lanes[t * BN + ch] = p.stats[(long)(t < tiles ? t : tiles - 1) * 2 * p.N + which * p.N + cc];
-                            }
-                        }
-                        __syncthreads();
-                        if (tid < BN && n0 + tid < p.N) {
-                            double sum = 0.0;
-                            for (int t = 0; t < tiles; ++t) sum += (double)lanes[t * BN + tid];
-                            tot[which] = sum;
-                        }
-                        __syncthreads();
-                    }
-                    const int c = n0 + tid;
-                    if (tid < BN && c < p.N) {
-                        const double s1 = tot[0], s2 = tot[1];
-                        const double mean = s1 / p.count;
-                        double var = s2 / p.count - mean * mean;
-                        if (var < 0.0) var = 0.0;
-                        const float invstd = (float)(1.0 / sqrt(var + (double)p.eps));
-                        const float g = p.gamma ? p.gamma[c] : 1.f, b = p.beta ? p.beta[c] : 0.f;
-                        const float sc = g * invstd;
-                        p.fin_out[c] = (float)mean;
-                        p.fin_out[p.N + c] = invstd;
-                        p.fin_out[2 * p.N + c] = sc;
-                        p.fin_out[3 * p.N + c] = b - (float)mean * sc;
-                        if (p.running_mean) {
-                            p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * (float)mean;
-                            const double unbiased = p.count > 1.0 ? var * p.count / (p.count - 1.0) : var;
-                            p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)unbiased;
-                        }
-                    }
-                }
-            }
-            }
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fk = (lane >> 4) * 8;
+    // this lane's two pixels: window rows of the three taps (element offsets) and whether the outer taps stay inside the image row
+    int arow_k[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int local = wave * 32 + i * 16 + frow;
+        const int m = m0 + local;
+        const int ow = (m < p.M ? m : 0) % p.Wa;
+        const bool left = ow - dwc >= 0, right = ow + dwc < p.Wa;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int sft = sgn * (kx - 1) * dwc;             // source column - output column
+            const bool valid = kx == 1 || (sft < 0 ? left : right);
+            arow_k[i][kx] = (valid ? local + dwc + sft : G3_ROWS) * GRS + fk;
         }
     }
+    auto compute = [&](int buf) {
+        const __bf16* aw = reinterpret_cast<const __bf16*>(smem + buf * G3Smem<BN>::STAGE);
+        const __bf16* bw = reinterpret_cast<const __bf16*>(smem + buf * G3Smem<BN>::STAGE + G3Smem<BN>::A) + frow * GRS + fk;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            bf16x8 fa[2], fb[NT];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(aw + arow_k[i][kx]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(bw + (kx * BN + j * 16) * GRS);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+    };
+    {
+        load(0, ra0, rb0);
+        load(1, ra1, rb1);
+        stash(0, ra0, rb0);
+        __syncthreads();
+        for (int it = 0; it < total; it += 2) {
+            load(it + 2, ra0, rb0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(0);
+            __builtin_amdgcn_sched_barrier(0);
+            stash(1, ra1, rb1);
+            __syncthreads();
+            load(it + 3, ra1, rb1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(1);
+            __builtin_amdgcn_sched_barrier(0);
+            stash(0, ra0, rb0);
+            __syncthreads();
+        }
+    }
+    gconv_epilogue<BN, OVEC, false>(p, smem, acc, tid, m0, n0, mt, nt, m_tiles);
 }
 
 template <int BN, int KC, int AVEC, int OVEC, bool OUTF32>
@@ -533,6 +718,22 @@ void glaunch_a(const GConvP& p, int avec, int ovec, bool f32, hipStream_t s) {
     if (avec == 8) glaunch_o<BN, KC, 8>(p, ovec, f32, s);
     else if (avec == 4) glaunch_o<BN, KC, 4>(p, ovec, f32, s);
     else glaunch_o<BN, KC, 1>(p, ovec, f32, s);
+}
+
+template <int BN>
+void glaunch3(const GConvP& p, int avec, int ovec, hipStream_t s) {
+    dim3 grid((p.M + GBM - 1) / GBM, (p.N + BN - 1) / BN);
+#define G3L(AV, OV) hipLaunchKernelGGL((gconv3_kernel<BN, AV, OV>), grid, dim3(256), 0, s, p)
+    if (avec == 8 && ovec == 8) G3L(8, 8);
+    else if (avec == 8 && ovec == 4) G3L(8, 4);
+    else if (avec == 8) G3L(8, 1);
+    else if (avec == 4 && ovec == 8) G3L(4, 8);
+    else if (avec == 4 && ovec == 4) G3L(4, 4);
+    else if (avec == 4) G3L(4, 1);
+    else if (ovec == 8) G3L(1, 8);
+    else if (ovec == 4) G3L(1, 4);
+    else G3L(1, 1);
+#undef G3L
 }
 
 // BN = 128 keeps 32-channel chunks (its LDS image with 64 would pass the 64 KiB of static LDS)
@@ -1287,6 +1488,30 @@ static int gconv_impl(const void* a, long lda, const void* wp, void* out, long l
     const long mt = (p.M + GBM - 1) / GBM;
     static const int bn32_wgs = getenv("MI_GCONV_BN32_WGS") ? atoi(getenv("MI_GCONV_BN32_WGS")) : 256;
     static const bool bn_any = !(getenv("MI_GCONV_BN_ANY") && atoi(getenv("MI_GCONV_BN_ANY")) == 0);      // MI_GCONV_BN_ANY=0: tile widths 32 / 64 (/ 128) only
+    // kernel-row window kernel (gconv3_kernel): three kernel columns, stride 1, output of the input's size, large maps (MI_GCONV3_WGS: from this many 64-wide
+    // workgroups; 0 = never)
+    static const int g3_wgs = getenv("MI_GCONV3_WGS") ? atoi(getenv("MI_GCONV3_WGS")) : 512;       // (GALD 36.56 / 36.27 / 36.16 ms at 1024 / 512 / 256; PraNet indifferent)
+    if (!out_f32 && !fin && g3_wgs > 0 && kw == 3 && sh == 1 && sw == 1 && pw == dw && dw <= G3_MAXD && Wo == Wa && Ho == Ha && 2 * ph == dh * (kh - 1) &&
+        mt * ((N + 63) / 64) >= g3_wgs && (p.Cpad / 32 >= 4 || g3_wgs == 1)) {
+        // measured per shape (tools/gkshape.py gald, MI_GCONV3_WGS = 0 | 1024): the window kernel wins where a kernel row has >= 4 chunks (3x3 142 -> 68 at
+        // 6 x 180 x 320: 206 vs 247 us, 466 -> 168 at 90 x 160: 287 vs 391, 218 -> 78: 78 vs 114) and loses with fewer (data gradient 68 -> 142: 239 vs 222);
+        // it has the widths 32 / 64 / 80 only (LDS), so a launch whose cost model wants 112 or 16 columns stays on gconv_kernel
+        static const int widths3[] = {64, 80, 112, 32, 16};
+        int best = 64;
+        long best_cost = 1L << 60;
+        for (int wdt : widths3) {
+            const long cost = (long)((N + wdt - 1) / wdt) * (wdt + 64);
+            if (cost < best_cost) best = wdt, best_cost = cost;
+        }
+        if (g3_wgs == 1 && best != 80 && best != 32) best = 64;          // (tests: every eligible conv)
+        if (best == 80 || best == 64 || best == 32) {
+            if (best == 80) glaunch3<80>(p, avec, ovec, s);
+            else if (best == 32) glaunch3<32>(p, avec, ovec, s);
+            else glaunch3<64>(p, avec, ovec, s);
+            MI_CHECK_LAUNCH("gconv3_kernel");
+            return MI_OK;
+        }
+    }
     if (out_f32) {
         MI_REQUIRE(N <= 32, "mi_gconv: fp32 outputs are the one-channel side maps (N <= 32), got N = %d", N);
         glaunch_k<32>(p, avec, 1, true, s);

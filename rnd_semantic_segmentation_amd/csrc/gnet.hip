@@ -118,20 +118,14 @@ __global__ __launch_bounds__(256) void gbn_finalize_kernel(const float* partials
             s1 += red[0][cx][k];
             s2 += red[1][cx][k];
         }
-        const double mean = s1 / count;
-        double var = s2 / count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-        mean_out[c] = (float)mean;
-        invstd_out[c] = invstd;
-        const float sc = g * invstd;
-        scale_out[c] = sc;
-        shift_out[c] = b - (float)mean * sc;
+        const MiBnFin f = mi_bn_finalize_channel(s1, s2, count, eps, gamma ? gamma[c] : 1.f, beta ? beta[c] : 0.f);
+        mean_out[c] = f.mean;
+        invstd_out[c] = f.invstd;
+        scale_out[c] = f.scale;
+        shift_out[c] = f.shift;
         if (running_mean) {
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+            running_mean[c] = mi_bn_running(running_mean[c], momentum, f.mean);
+            running_var[c] = mi_bn_running(running_var[c], momentum, mi_bn_unbiased(f.var, count));
         }
     }
 }

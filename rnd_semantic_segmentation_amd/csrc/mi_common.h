@@ -109,6 +109,30 @@ __device__ __forceinline__ int mi_xcd_remap(int bid, int nwg) {
 
 __device__ __forceinline__ float mi_bf16_to_f32(__bf16 v) { return (float)v; }
 
+// ---- BatchNorm finalize arithmetic shared by the separate finalize kernel (gnet.hip) and the conv's in-launch finalize (gconv.hip): every multiply / add an
+// explicitly rounded operation, so that the two give the same bits whatever fused-multiply-add contraction the compiler applies around them (the in-launch
+// version moved into a device function in round 4 and its running_var went one ulp off the kernel's).
+struct MiBnFin {
+    float mean, invstd, scale, shift;
+    double var;
+};
+__device__ __forceinline__ MiBnFin mi_bn_finalize_channel(double s1, double s2, double count, float eps, float gamma, float beta) {
+    MiBnFin r;
+    const double mean = s1 / count;
+    double var = __dsub_rn(s2 / count, __dmul_rn(mean, mean));
+    if (var < 0.0) var = 0.0;
+    r.var = var;
+    r.mean = (float)mean;
+    r.invstd = (float)(1.0 / sqrt(__dadd_rn(var, (double)eps)));
+    r.scale = __fmul_rn(gamma, r.invstd);
+    r.shift = __fsub_rn(beta, __fmul_rn(r.mean, r.scale));
+    return r;
+}
+__device__ __forceinline__ float mi_bn_running(float old, float momentum, float value) {      // (1 - momentum) * old + momentum * value
+    return __fadd_rn(__fmul_rn(1.f - momentum, old), __fmul_rn(momentum, value));
+}
+__device__ __forceinline__ float mi_bn_unbiased(double var, double count) { return (float)(count > 1.0 ? __dmul_rn(var, count) / (count - 1.0) : var); }
+
 // ---- in-launch second-level reductions (the last-arriving workgroup of a launch combines the other workgroups' small partial results) ----
 // The sc1 form of the split-K recipe of cdna_hip_programming.md section 5 / section 6 Guideline 16: the XCDs' L2s are not coherent with each
 // other, so every partial value is stored WRITE-THROUGH (agent-scope relaxed atomic store = global_store ... sc1: no release fence, which would

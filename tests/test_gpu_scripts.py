@@ -128,6 +128,8 @@ def test_opt_in_kernel_variants_and_single_stream_schedule_stay_correct():
                      ({"MI_GWGRAD3": "2"}, ["tests/test_gpu_gops.py", "-k", "weight_gradient"]),                  # general family: fused-row weight gradient forced onto the small shapes
                      ({"MI_GWGRAD3": "0", "MI_INLAUNCH": "0", "MI_BN_INLAUNCH": "0"}, ["tests/test_gpu_gops.py", "-k", "weight_gradient or batch_statistics"]),   # per-tap kernel, two-launch reductions
                      ({"MI_WGRAD_BATCH": "0", "MI_GCONV_REMAP": "0"}, ["tests/test_gpu_pranet.py", "-k", "building_blocks or graph_replay or stale"]),     # tape: every weight gradient its own launch (the queue off), plain tile order
+                     ({"MI_GCONV3_WGS": "1"}, ["tests/test_gpu_gops.py", "-k", "gconv"]),                                          # kernel-row window conv on every eligible (tiny) shape
+                     ({"MI_GCONV_BN_ANY": "0", "MI_GCONV_KS2_WGS": "0", "MI_GCONV3_WGS": "0"}, ["tests/test_gpu_gops.py", "-k", "gconv"]),   # 32 / 64-wide tiles, one wave group, no window kernel
                      ({"MI_GWM_STEPS": "4", "MI_GWM_FUSED3": "0"}, ["tests/test_gpu_gops.py", "-k", "many_convs"]),                # batched weight gradients: many K splits, the one-conv fusing rule
                      ({"MI_WGRAD_STREAM": "0", "MI_BATCH_LANES": "1"}, ["tests/test_gpu_model.py", "-k", "tinynet"])):
         r = run(["-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider"] + sel, env)
