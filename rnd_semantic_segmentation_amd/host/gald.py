@@ -246,6 +246,7 @@ class GCPAEncoder(_Engine):
     bf16, NCHW-shaped views of NHWC memory.  The reference loads 'pretrained/hardnet68.pth', which the image lacks: weights keep the module
     defaults unless a checkpoint is loaded."""
     RUN = _GaldRun
+    PAD_IMAGE = True
 
     def __init__(self):
         super().__init__()

@@ -177,7 +177,7 @@ class _Run:
 
     def __init__(self, net, train, rec):
         self.net, self.train, self.rec, self.tape, self.side = net, train, rec, [], None
-        self.wq, self.wq_slots = None, None            # weight gradients queued during backward (see _conv_backward)
+        self.wq, self.wq_slots, self.wq_fix = None, None, []            # weight gradients queued during backward (see _conv_backward)
         # fp32: the evaluation forward in the reference's precision (csrc/gf32.hip; _Engine.set_precision): every activation fp32, every conv with
         # its eval()-BatchNorm affine, residual and activation in one launch
         self.f32 = (not train) and getattr(net, "precision", "bf16") == "fp32"
@@ -294,7 +294,16 @@ class _Run:
                                  out=tgt if (tgt is not None and tgt.is_contiguous()) else None)
                 _acc(x, dx, True)
             return
-        if self.wq is not None and side is None:
+        if x.t.shape[-1] != u.cin and not u.depthwise:
+            # the zero-padded image (_nhwc_input): the gradient for its eight channels goes to a scratch tensor, the real channels are cut out after the flush
+            wide = torch.empty((u.cout, x.t.shape[-1]) + tuple(u.geom[:2]), dtype=torch.float32, device=dy.device)
+            if self.wq is not None and side is None:
+                self.wq.append((dy, x.t, wide, u.geom, False))
+                self.wq_fix.append((slot, wide, u.cin, acc))
+            else:
+                gk.gconv_wgrad(dy, x.t, wide, u.geom)
+                slot.add_(wide[:, :u.cin]) if acc else slot.copy_(wide[:, :u.cin])
+        elif self.wq is not None and side is None:
             # queued: the whole backward's weight gradients run as one table-driven launch at the end of the tape (gk.gconv_wgrad_multi) - alone each
             # is a 25 - 60 us latency chain of which 15 - 25 us are fixed.  The queue keeps dy and x alive until then; a slot that is already in the
             # queue (a module applied twice) flushes first, so that the accumulation order stays the tape's.
@@ -469,12 +478,15 @@ class _Run:
     def flush_wgrads(self):
         if self.wq:
             gk.gconv_wgrad_multi(self.wq)
+            for slot, wide, cin, acc in self.wq_fix:
+                slot.add_(wide[:, :cin]) if acc else slot.copy_(wide[:, :cin])
         if self.wq is not None:
-            self.wq, self.wq_slots = [], set()
+            self.wq, self.wq_slots, self.wq_fix = [], set(), []
 
     def backward(self):
         self.side = _SideStream.get(self.net._store.data.device) if os.environ.get("MI_TAPE_WGRAD_STREAM", "0") == "1" else None
         self.wq, self.wq_slots = ([], set()) if os.environ.get("MI_WGRAD_BATCH", "1") != "0" else (None, None)
+        self.wq_fix = []
         for fn in reversed(self.tape):
             fn()
         self.tape = []
@@ -747,12 +759,27 @@ class _Engine(nn.Module):
         self._prepare()
         run = self.RUN(self, self.training, rec)
         dt = torch.float32 if run.f32 else torch.bfloat16
-        ins = [run.var(x.detach().permute(0, 2, 3, 1).to(dt).contiguous(), need) for x, need in zip(xs, in_needs)]      # NHWC bf16 (fp32 evaluation: fp32)
+        ins = [run.var(self._nhwc_input(x, dt, (need and rec) or not self.PAD_IMAGE), need) for x, need in zip(xs, in_needs)]      # NHWC bf16 (fp32 evaluation: fp32)
         outs = self._graph(run, *ins)
         if self.training:
             self._nbt.add_(1)
             self._stat_gen += 1                       # the kernels update the running statistics through raw pointers: no tensor version moves
         return run, ins, outs
+
+    PAD_IMAGE = False          # True on the whole nets whose first op is the stem conv on the image (PraNet, GCPAEncoder)
+
+    @staticmethod
+    def _nhwc_input(x, dt, wants_grad):
+        """NCHW module input -> NHWC activation.  A three-channel bf16 image that needs no gradient is stored with EIGHT channels (five zero planes): the stem
+        conv then reads one 16-byte vector per pixel and tap instead of sixteen 2-byte loads (its packed weights are zero beyond channel 3 anyway), and its weight
+        gradient is computed for eight input channels and cut back (see _conv_backward).  GALD's 3 -> 32 stem at 6 x 720 x 1280: 169 -> ~60 us forward, 320 -> ~100
+        us weight gradient."""
+        nhwc = x.detach().permute(0, 2, 3, 1)
+        if dt == torch.bfloat16 and x.shape[1] == 3 and not wants_grad and os.environ.get("MI_STEM_PAD8", "1") != "0":
+            out = torch.zeros((x.shape[0], x.shape[2], x.shape[3], 8), dtype=dt, device=x.device)
+            out[..., :3] = nhwc
+            return out
+        return nhwc.to(dt).contiguous()
 
     def forward(self, *xs):
         self._grad_mode = torch.is_grad_enabled()          # (inside Function.forward grad mode is always off: ask here whether a tape is wanted at all)
@@ -844,6 +871,8 @@ class PraNet(_Engine):
     each [B,1,H,W] fp32 logits.  The reference loads ImageNet weights from a local file the image does not have; weights here are
     initialised like the reference's modules (kaiming_normal fan_out for the trunk's convs, Conv2d defaults elsewhere) or loaded from a
     checkpoint / the formula generator."""
+
+    PAD_IMAGE = True
 
     def __init__(self, channel=32):
         super().__init__()
