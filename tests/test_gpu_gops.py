@@ -180,6 +180,39 @@ def test_fused_row_weight_gradient_on_a_large_map(gk):
         assert torch.equal(dw, dw2)
 
 
+def test_kernel_row_window_conv_on_a_large_map(gk):
+    """From 512 64-wide workgroups up a stride-1 conv with three kernel columns, pad = dilation and >= 4 chunks per kernel row takes gconv3_kernel (one staged
+    window of 128 + 2 d pixels per kernel row and 32-channel chunk, the three taps' MFMAs from it; row wrap by validity bits, image borders by zero window rows):
+    2 x 136 x 200 x 168 -> 136 on channel-slice views (both directions five chunks per kernel row, 80-wide tiles), dilation 1 and 3, forward (+ the column
+    statistics) and data gradient against torch in float64.  The
+    tiny shapes run through it in tests/test_gpu_scripts.py (MI_GCONV3_WGS=1)."""
+    for dil in (1, 3):
+        case = (136, 136, (3, 3), (1, 1), (dil, dil), (dil, dil), 2, 200, 168, (272, 136), (144, 8))
+        Cin, Cout, k, s, p, d, B, H, W, (ldi, offi), (ldo, offo) = case
+        x, w, geom = _conv_setup(case, 800 + dil)
+        xd = x.double().requires_grad_(True)
+        wd = w.to(torch.bfloat16).double()
+        y = F.conv2d(xd, wd, None, s, p, d)
+        dy = _rand(tuple(y.shape), 23)
+        y.backward(dy.double())
+        wp, wpt = gk.gconv_pack(w.cuda())
+        _, xv = _embed(_nhwc(x).cuda(), ldi, offi)
+        obig = torch.zeros((B, H, W, ldo), dtype=torch.bfloat16, device="cuda")
+        out, st = gk.gconv(xv, wp, Cout, geom, out=obig[..., offo:offo + Cout], stats=True)
+        torch.cuda.synchronize()
+        _close_bf16(out.permute(0, 3, 1, 2), y.detach(), "window conv forward d=%d" % dil)
+        assert float(obig[..., :offo].abs().max()) == 0.0                      # nothing outside the slice is written
+        tiles = (B * H * W + 127) // 128
+        sums = st.view(tiles, 2, Cout).double().sum(0).cpu()
+        yb = out.permute(0, 3, 1, 2).double().cpu()
+        assert float((sums[0] - yb.sum((0, 2, 3))).abs().max()) < 1e-3 * float(yb.abs().sum((0, 2, 3)).max())
+        assert float((sums[1] - (yb * yb).sum((0, 2, 3))).abs().max()) < 1e-3 * float((yb * yb).sum((0, 2, 3)).max())
+        _, dyv = _embed(_nhwc(dy).cuda(), ldo, offo)
+        dx, _ = gk.gconv(dyv, wpt, Cin, geom, mode=gk.GATHER_DGRAD, out_hw=(H, W))
+        torch.cuda.synchronize()
+        _close_bf16(dx.permute(0, 3, 1, 2), xd.grad, "window conv data gradient d=%d" % dil)
+
+
 def test_weight_gradients_of_many_convs_in_one_launch(gk):
     """gk.gconv_wgrad_multi (the tape's end-of-backward flush): every conv case of this file - all operand alignment classes, strides, dilations, 1 x 7 /
     7 x 1 / 5 x 5 kernels, the fused kernel row where the geometry allows it - plus a 16 x 44 x 44 map with several K splits, queued together; each gradient
