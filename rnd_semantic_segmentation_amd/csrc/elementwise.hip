@@ -39,6 +39,18 @@ const MiSwitches& mi_sw() {
         sw.gconv_bn128 = env("MI_GCONV_BN128", 0);
         sw.gconv_kc = env("MI_GCONV_KC", 0);
         sw.gconv_remap = env("MI_GCONV_REMAP", 1);
+        sw.gconv_ks2_wgs = env("MI_GCONV_KS2_WGS", 320);
+        sw.gconv_kc32_wgs = env("MI_GCONV_KC32_WGS", 1536);
+        sw.gconv_bn32_wgs = env("MI_GCONV_BN32_WGS", 256);
+        sw.gconv_bn_any = env("MI_GCONV_BN_ANY", 1);
+        sw.gconv_bn_c = env("MI_GCONV_BN_C", 64);
+        sw.gconv_bn_force = env("MI_GCONV_BN_FORCE", 0);
+        sw.gconv3_wgs = env("MI_GCONV3_WGS", 512);
+        sw.gconv_dbg = env("MI_GC_DBG", 0);
+        sw.gw_dbg = env("MI_GW_DBG", 0);
+        sw.gwm_steps = env("MI_GWM_STEPS", 48);
+        if (sw.gwm_steps < 1) sw.gwm_steps = 48;
+        sw.gwm_fused3 = env("MI_GWM_FUSED3", 1);
         sw.gwgrad3 = env("MI_GWGRAD3", 1);
         sw.p3_dbg = env("MI_P3_DBG", 0);
         sw.pp_trace_wg = env("MI_PP_TRACE_WG", 0);

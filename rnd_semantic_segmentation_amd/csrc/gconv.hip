@@ -689,7 +689,7 @@ void glaunch(const GConvP& p, hipStream_t s) {
         return;
     }
     if constexpr (!OUTF32 && (BN == 32 || BN == 64) && KC == 64 && AVEC >= 4 && OVEC >= 4) {       // two wave groups over the K chunks (see KS above)
-        static const int ks2_wgs = getenv("MI_GCONV_KS2_WGS") ? atoi(getenv("MI_GCONV_KS2_WGS")) : 320;
+        const int ks2_wgs = mi_sw().gconv_ks2_wgs;
         if ((int)(grid.x * grid.y) <= ks2_wgs && p.T * p.nchunks >= 8) {
             constexpr int bytes = 2 * GSmem<BN, KC, false>::AB;
             static_assert(bytes >= GSmem<BN, KC, false>::CS + GSmem<BN, KC, false>::RED && bytes >= 2 * (BN / 16) * 4 * 256 * 4, "LDS of the two-group launch");
@@ -742,7 +742,7 @@ void glaunch_k(GConvP& p, int avec, int ovec, bool f32, hipStream_t s) {
     if constexpr (2 * (GBM + BN) * (64 + 8) * 2 <= 64 * 1024) {          // (BN <= 80: the 64-channel image fits the 64 KiB of static LDS)
         // 64-channel chunks halve the K steps; a conv on a large map (thousands of workgroups) gains more from the occupancy of
         // the 32-channel tile (30 KB of LDS instead of 55: 104 -> 256 at 16 x 88 x 88 54.7 vs 63.7 us, 208 -> 512 at 44 x 44 33.5 vs 41.0)
-        static const int kc32_wgs = getenv("MI_GCONV_KC32_WGS") ? atoi(getenv("MI_GCONV_KC32_WGS")) : 1536;
+        const int kc32_wgs = mi_sw().gconv_kc32_wgs;
         const long wgs = (long)((p.M + GBM - 1) / GBM) * ((p.N + BN - 1) / BN);
         const bool small_k_big_m = wgs >= kc32_wgs && mi_sw().gconv_kc != 64;          // (3x3 convs on large maps too: GALD 38.4 -> 37.6 ms with 32-channel chunks)
         if (p.Cpad >= 64 && p.T * ((p.Cpad + 63) / 64) >= 2 && mi_sw().gconv_kc != 32 && !small_k_big_m) {
@@ -1470,7 +1470,7 @@ static int gconv_impl(const void* a, long lda, const void* wp, void* out, long l
     p.mode = mode;
     p.nchunks = p.Cpad / 32;
     p.remap = mi_sw().gconv_remap;
-    { static const int dbg = getenv("MI_GC_DBG") ? atoi(getenv("MI_GC_DBG")) : 0; p.dbg = dbg; }
+    p.dbg = mi_sw().gconv_dbg;
     p.fin_ticket = fin ? fin->ticket : nullptr;
     p.fin_out = fin ? fin->out : nullptr;
     p.gamma = fin ? fin->gamma : nullptr;
@@ -1486,11 +1486,11 @@ static int gconv_impl(const void* a, long lda, const void* wp, void* out, long l
     else MI_REQUIRE((reinterpret_cast<uintptr_t>(out) & 3) == 0, "mi_gconv: fp32 output must be 4-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const long mt = (p.M + GBM - 1) / GBM;
-    static const int bn32_wgs = getenv("MI_GCONV_BN32_WGS") ? atoi(getenv("MI_GCONV_BN32_WGS")) : 256;
-    static const bool bn_any = !(getenv("MI_GCONV_BN_ANY") && atoi(getenv("MI_GCONV_BN_ANY")) == 0);      // MI_GCONV_BN_ANY=0: tile widths 32 / 64 (/ 128) only
+    const int bn32_wgs = mi_sw().gconv_bn32_wgs;
+    const bool bn_any = mi_sw().gconv_bn_any != 0;      // MI_GCONV_BN_ANY=0: tile widths 32 / 64 (/ 128) only
     // kernel-row window kernel (gconv3_kernel): three kernel columns, stride 1, output of the input's size, large maps (MI_GCONV3_WGS: from this many 64-wide
     // workgroups; 0 = never)
-    static const int g3_wgs = getenv("MI_GCONV3_WGS") ? atoi(getenv("MI_GCONV3_WGS")) : 512;       // (GALD 36.56 / 36.27 / 36.16 ms at 1024 / 512 / 256; PraNet indifferent)
+    const int g3_wgs = mi_sw().gconv3_wgs;       // (GALD 36.56 / 36.27 / 36.16 ms at 1024 / 512 / 256; PraNet indifferent)
     if (!out_f32 && !fin && g3_wgs > 0 && kw == 3 && sh == 1 && sw == 1 && pw == dw && dw <= G3_MAXD && Wo == Wa && Ho == Ha && 2 * ph == dh * (kh - 1) &&
         mt * ((N + 63) / 64) >= g3_wgs && (p.Cpad / 32 >= 4 || g3_wgs == 1)) {
         // measured per shape (tools/gkshape.py gald, MI_GCONV3_WGS = 0 | 1024): the window kernel wins where a kernel row has >= 4 chunks (3x3 142 -> 68 at
@@ -1527,8 +1527,8 @@ static int gconv_impl(const void* a, long lda, const void* wp, void* out, long l
         // (248 vs 347 us for two 64-wide), 334 -> three 112-wide (221 vs 318), 256 -> four 64-wide; the least-padding rule tried first chose 16-wide tiles
         // for N = 168 (1 270 us against 393).  MI_GCONV_BN_FORCE: one width for everything (measurement).
         static const int widths[] = {64, 80, 112, 32, 16};
-        static const int force = getenv("MI_GCONV_BN_FORCE") ? atoi(getenv("MI_GCONV_BN_FORCE")) : 0;
-        static const int fixed = getenv("MI_GCONV_BN_C") ? atoi(getenv("MI_GCONV_BN_C")) : 64;
+        const int force = mi_sw().gconv_bn_force;
+        const int fixed = mi_sw().gconv_bn_c;
         int best = 64;
         long best_cost = 1L << 60;
         for (int wdt : widths) {
@@ -1577,7 +1577,7 @@ int mi_gconv_wgrad(const void* dy, long ldy, const void* x, long ldx, float* dw,
     MI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "mi_gconv_wgrad: workspace must be 16-byte aligned");
     GWgP p;
     p.remap = mi_sw().gconv_remap;
-    { static const int dbg = getenv("MI_GW_DBG") ? atoi(getenv("MI_GW_DBG")) : 0; p.dbg = dbg; }
+    p.dbg = mi_sw().gw_dbg;
     p.dY = (const __bf16*)dy;
     p.X = (const __bf16*)x;
     p.slab = (float*)workspace;
@@ -1651,12 +1651,12 @@ int mi_gconv_wgrad(const void* dy, long ldy, const void* x, long ldx, float* dw,
 // bytes; workspace: device buffer of mi_gconv_wgrad_multi_workspace(jobs, n) bytes.  Two jobs must not share a dw (the caller flushes between them).
 static bool gwm_fused(const MiWgradJob& j, long M) {
     const int mode = mi_sw().gwgrad3;                    // 0: never fused; otherwise fused whenever the geometry allows (MI_GWM_FUSED3=0: the one-conv rule, from 65 536 pixels)
-    static const int always = getenv("MI_GWM_FUSED3") ? atoi(getenv("MI_GWM_FUSED3")) : 1;
+    const int always = mi_sw().gwm_fused3;
     const bool can = j.kw == 3 && j.sh == 1 && j.sw == 1 && j.pw == j.dw_ && j.Ho == j.Ha && j.Wo == j.Wa && j.dw_ <= W3_MAXD;
     return can && mode != 0 && (always || mode == 2 || M >= 65536);
 }
 static void gwm_plan(const MiWgradJob& j, GWgD& d) {
-    static const int steps = getenv("MI_GWM_STEPS") ? atoi(getenv("MI_GWM_STEPS")) : 48;
+    const int steps = mi_sw().gwm_steps;
     GWgP& p = d.p;
     p.remap = mi_sw().gconv_remap;
     p.dbg = 0;

@@ -37,6 +37,17 @@ struct MiSwitches {
     int gconv_bn128;       // MI_GCONV_BN128      0: general conv keeps 64-wide tiles (1: 128-wide where they fit)
     int gconv_kc;          // MI_GCONV_KC         0: K chunk of the general conv by rule (32 | 64: forced)
     int gconv_remap;       // MI_GCONV_REMAP      1: general conv / weight gradient walk their tiles XCD-contiguous (0: plain grid order)
+    int gconv_ks2_wgs;     // MI_GCONV_KS2_WGS    320: general-conv launches of at most this many workgroups run two wave groups over the K chunks (0: never)
+    int gconv_kc32_wgs;    // MI_GCONV_KC32_WGS   1536: launches of at least this many workgroups take 32-channel K chunks
+    int gconv_bn32_wgs;    // MI_GCONV_BN32_WGS   256: launches of fewer 64-wide workgroups take 32-wide tiles
+    int gconv_bn_any;      // MI_GCONV_BN_ANY     1: tile width per launch from {16, 32, 64, 80, 112} by the cost model (0: 32 / 64 only)
+    int gconv_bn_c;        // MI_GCONV_BN_C       64: the cost model's fixed cost per column tile, in columns
+    int gconv_bn_force;    // MI_GCONV_BN_FORCE   0: (measurement) one tile width for every launch
+    int gconv3_wgs;        // MI_GCONV3_WGS       512: three-column stride-1 convs of at least this many 64-wide workgroups take the kernel-row window kernel (0 never, 1 all: tests)
+    int gconv_dbg;         // MI_GC_DBG           0: (measurement) bit 0 skip the main loop, bit 1 the statistics, bit 2 the stores
+    int gw_dbg;            // MI_GW_DBG           0: (measurement) bit 0: weight gradient without its main loop
+    int gwm_steps;         // MI_GWM_STEPS        48: batched weight gradients: K steps of 64 pixels per workgroup
+    int gwm_fused3;        // MI_GWM_FUSED3       1: batched weight gradients: fused kernel rows wherever the geometry allows (0: the one-conv rule)
     int gwgrad3;           // MI_GWGRAD3          1: general weight gradient of three-column kernels as one fused kernel row per workgroup from 65 536 pixels up (0: per tap, 2: always)
     int p3_dbg;            // MI_P3_DBG           0 (-DMI_EXPERIMENTS builds only)
     int pp_trace_wg;       // MI_PP_TRACE_WG      0 (-DMI_PP_TRACE builds only)
