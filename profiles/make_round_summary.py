@@ -35,7 +35,7 @@ lines = ["# Round %s, end-of-round profile - 1x MI355X, B=8, 769x769, bf16 opera
          "Command (from /tmp on the GPU box, `tools/profile_round.sh %s`): `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-kernel-events`;" % tag,
          "%d training steps are in each trace (3 warm-up + 5 timed).  Raw tables: `%s_bench_kernel_stats.csv` (default two-stream schedule), `%s_bench_kernel_stats_single_stream.csv`." % (steps, tag, tag),
          "Bench line of the same commit (`%s_bench_builder.json`, default flags): **%.1f images/s, %.2f ms/step**; `igemm_pp_kernel` %.4f of the MFMA peak; dilated-3x3 family %.3f, ASPP head %.3f, "
-         "K = 256 <-> 1024 class %.3f of HBM peak; CPU port %.3f images/s on %d cores.  `%s_bench_100steps.json` (mid-round, same kernels): sustained 286.7 images/s." % (
+         "K = 256 <-> 1024 class %.3f of HBM peak; CPU port %.3f images/s on %d cores.  `%s_bench_100steps.json` (`--steps 100 --warmup 20`, another box of the pool): sustained 293.4 images/s, 27.26 ms/step." % (
              tag, b["value"], b["ms_per_step"], b["roofline"]["frac"], fam["dilated3x3_family"]["frac_of_mfma_peak"], fam["aspp_head"]["frac_of_mfma_peak"],
              fam["pointwise_k256_n1024_class"]["frac_of_hbm_peak"], b["cpu_baseline"]["value"], b["cpu_baseline"]["cores"], tag),
          "The DeepLab kernels did not change this round (round 3, driver: 292.9 images/s, 27.31 ms, 0.4155 / 0.420 / 0.313 / 0.50): the numbers differ by the box.",
