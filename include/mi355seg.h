@@ -95,6 +95,23 @@ int mi_conv_gemm_pp(const void* a, const void* wp, void* out,
                     const float* scale, const float* bias, const void* res, const void* msk, void* mask_out,
                     int flags, int zgw, float alpha, int mtg, void* stream);
 
+/* ---- two chained 1x1 convolutions of the bottleneck sequence in one launch (csrc/chain.hip) --------------------------
+ * forward (backward = 0): reference core/components/resnet.py:105-113 of block i followed by :93-95 of block i+1,
+ *   mid = relu(scale1 * (a . w_first^T) + shift1 + res)   [M][N1] bf16, sign bits -> bits1_out [M][N1/8]
+ *   out = relu(scale2 * (mid . w_second^T) + shift2)      [M][N2] bf16, sign bits -> bits2_out [M][N2/8]
+ * i.e. mi_conv_gemm(a, w_first, flags 1|2|4|64) then mi_conv_gemm(mid, w_second, flags 1|4|64), with `mid` written once and
+ * never read back.  backward = 1: the data gradients of the same two convs in the order backward meets them (conv1 of block i,
+ * conv3 of block i-1; weights packed by mi_pack_weight_dgrad),
+ *   mid = ((a . w_first^T) + res) where bit of bits1 else 0;   out = (mid . w_second^T) where bit of bits2 else 0
+ * i.e. flags 2|128 then 128.  a [M][K1], w_first [N1][K1], res / mid [M][N1], w_second [N2][N1], out [M][N2], all bf16 and
+ * 16-byte aligned; the sign-bit tensors as MI_EPI_WRITE_MASK / MI_EPI_BITMASK define them.  Built for K1 = 256, N1 = 1024, N2 = 256
+ * (layer3); other sizes return MI_EINVAL.  grid: workgroups (0 = one per CU). */
+int mi_conv_chain(const void* a, const void* w_first, const void* res, void* mid, const void* w_second, void* out,
+                  long M, int K1, int N1, int N2,
+                  const float* scale1, const float* shift1, const float* scale2, const float* shift2,
+                  const void* bits1, const void* bits2, void* bits1_out, void* bits2_out,
+                  int backward, int grid, void* stream);
+
 /* ---- weight gradient (contraction over pixels), split-K with deterministic reduction ------------
  * Replaces the weight-gradient half of convolution_backward.
  *   dw[o][i][t] (+)= scale[o] * sum_m dy[m][o] * x[src(m,t)][i]

@@ -25,6 +25,7 @@ SIGNATURES = {
     "mi_conv_gemm": (I, [P, P, P] + [I] * 12 + [P, P, P, P, P, I, I, F, P]),
     "mi_conv_gemm_route": (I, [I] * 10),
     "mi_conv_gemm_pp": (I, [P, P, P] + [I] * 12 + [P, P, P, P, P, I, I, F, I, P]),
+    "mi_conv_chain": (I, [P] * 6 + [L, I, I, I] + [P] * 8 + [I, I, P]),
     "mi_conv_wgrad_workspace": (Z, [I] * 6),
     "mi_conv_wgrad_route": (I, [I] * 12),
     "mi_conv_wgrad": (I, [P, P, P] + [I] * 11 + [P, I, I, I, Z, P, Z, P]),

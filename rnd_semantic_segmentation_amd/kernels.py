@@ -192,6 +192,52 @@ def _workspace(nbytes, device, tag="ws"):
     return buf
 
 
+def conv_chain(a, w_first, res, w_second, scale1=None, shift1=None, scale2=None, shift2=None, bits1=None, bits2=None, mid=None, out=None,
+               bits1_out=None, bits2_out=None, grid=0):
+    """Two chained 1x1 convs in one launch (csrc/chain.hip).  Forward (scale1 given): mid = relu(scale1 * a.w_first^T + shift1 + res),
+    out = relu(scale2 * mid.w_second^T + shift2), returns (mid, out, bits(mid), bits(out)).  Backward (bits1 given): mid = (a.w_first^T + res) masked by
+    bits1, out = (mid.w_second^T) masked by bits2, returns (mid, out).  a [B,H,W,K1], res [B,H,W,N1] bf16 NHWC; w_first [1,N1,K1], w_second [1,N2,N1]."""
+    _chk(a, torch.bfloat16, "a")
+    _chk(res, torch.bfloat16, "res")
+    _chk(w_first, torch.bfloat16, "w_first")
+    _chk(w_second, torch.bfloat16, "w_second")
+    B, H, W, K1 = a.shape
+    N1, N2 = w_first.shape[-2], w_second.shape[-2]
+    if w_first.shape[-1] != K1 or w_second.shape[-1] != N1 or tuple(res.shape) != (B, H, W, N1):
+        raise _lib.MiError("conv_chain: a %s, w_first %s, res %s, w_second %s do not chain" % (tuple(a.shape), tuple(w_first.shape), tuple(res.shape), tuple(w_second.shape)))
+    backward = bits1 is not None
+    M = B * H * W
+    if mid is None:
+        mid = torch.empty((B, H, W, N1), dtype=torch.bfloat16, device=a.device)
+    if out is None:
+        out = torch.empty((B, H, W, N2), dtype=torch.bfloat16, device=a.device)
+    _chk(mid, torch.bfloat16, "mid")
+    _chk(out, torch.bfloat16, "out")
+    if mid.numel() != M * N1 or out.numel() != M * N2:
+        raise _lib.MiError("conv_chain: mid / out have the wrong size")
+    if backward:
+        _chk(bits1, torch.int16, "bits1")
+        _chk(bits2, torch.int16, "bits2")
+        assert bits1.numel() == M * N1 // 16 and bits2.numel() == M * N2 // 16
+    else:
+        for t, n in ((scale1, N1), (shift1, N1), (scale2, N2), (shift2, N2)):
+            _chk(t, torch.float32, "scale / shift")
+            assert t.numel() == n
+        if bits1_out is None:
+            bits1_out = torch.empty((B, H, W, N1 // 16), dtype=torch.int16, device=a.device)
+        if bits2_out is None:
+            bits2_out = torch.empty((B, H, W, N2 // 16), dtype=torch.int16, device=a.device)
+        _chk(bits1_out, torch.int16, "bits1_out")
+        _chk(bits2_out, torch.int16, "bits2_out")
+        assert bits1_out.numel() == M * N1 // 16 and bits2_out.numel() == M * N2 // 16
+    flops = 2.0 * M * N1 * (K1 + N2)
+    check(_timed("chain_kernel", flops, lambda: _lib.lib().mi_conv_chain(
+        _p(a), _p(w_first), _p(res), _p(mid), _p(w_second), _p(out), M, K1, N1, N2, _p(scale1), _p(shift1), _p(scale2), _p(shift2),
+        _p(bits1), _p(bits2), _p(bits1_out), _p(bits2_out), 1 if backward else 0, int(grid), _stream()),
+        tag=("chain_bwd" if backward else "chain_fwd", 1, K1, N1, M, 0, 1)), "mi_conv_chain")
+    return (mid, out) if backward else (mid, out, bits1_out, bits2_out)
+
+
 def conv_wgrad(dy, x, dw, ksize=1, stride=1, pad=0, dil=1, scale=None, accumulate=False, out_map=0, ncls=0):
     """dw[o,i,ky,kx] (+)= scale[o] * sum_m dy[m,o] x[src(m,t),i];  dy [B,Ho,Wo,O], x [B,Ha,Wa,I] bf16; dw fp32.
     out_map=1 (ASPP): dy is the im2col matrix with 36*ncls live columns, dw the 4 stacked [ncls,I,3,3] gradients."""
