@@ -46,13 +46,21 @@ const MiSwitches& mi_sw() {
         sw.gconv_bn_c = env("MI_GCONV_BN_C", 64);
         sw.gconv_bn_force = env("MI_GCONV_BN_FORCE", 0);
         sw.gconv3_wgs = env("MI_GCONV3_WGS", 512);
+#ifdef MI_EXPERIMENTS          // measurement switches: experiment builds only (the product library ignores the variables)
         sw.gconv_dbg = env("MI_GC_DBG", 0);
         sw.gw_dbg = env("MI_GW_DBG", 0);
+#else
+        sw.gconv_dbg = sw.gw_dbg = 0;
+#endif
         sw.gwm_steps = env("MI_GWM_STEPS", 48);
         if (sw.gwm_steps < 1) sw.gwm_steps = 48;
         sw.gwm_fused3 = env("MI_GWM_FUSED3", 1);
         sw.gwgrad3 = env("MI_GWGRAD3", 1);
+#ifdef MI_EXPERIMENTS
         sw.p3_dbg = env("MI_P3_DBG", 0);
+#else
+        sw.p3_dbg = 0;
+#endif
         sw.pp_trace_wg = env("MI_PP_TRACE_WG", 0);
     });
     return sw;

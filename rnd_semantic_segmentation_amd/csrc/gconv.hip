@@ -25,6 +25,15 @@
 #include <string.h>
 #include <stdlib.h>
 
+// Measurement switches (MI_GC_DBG / MI_GW_DBG: skip the main loop, the statistics or the stores of a launch to price its phases) exist only in experiment builds
+// (tools/experiments/build.sh, -DMI_EXPERIMENTS): in the product library the tests below are the constant 0 and the environment variables are not read - an
+// exported variable cannot corrupt a training run.
+#ifdef MI_EXPERIMENTS
+#define MI_DBG_BIT(p, b) ((p).dbg & (b))
+#else
+#define MI_DBG_BIT(p, b) 0
+#endif
+
 namespace {
 
 constexpr int GBM = 128;       // pixels per tile
@@ -186,13 +195,13 @@ __device__ __forceinline__ void gconv_epilogue(const GConvP& p, char* smem, f32x
                 const int idx = tid + k * 256;
                 const int row = idx / G, cg = idx - row * G;
                 const int m = m0 + row, n = n0 + cg * OW;
-                if (m < p.M && n < p.N && !(p.dbg & 4)) *reinterpret_cast<bf16x8*>(out + (long)m * p.ldo + n) = v[k];
+                if (m < p.M && n < p.N && !MI_DBG_BIT(p, 4)) *reinterpret_cast<bf16x8*>(out + (long)m * p.ldo + n) = v[k];
             }
         } else
         for (int idx = tid; idx < GBM * G; idx += 256) {
             const int row = idx / G, cg = idx - row * G;
             const int m = m0 + row, n = n0 + cg * OW;
-            if (m < p.M && n < p.N && !(p.dbg & 4)) {
+            if (m < p.M && n < p.N && !MI_DBG_BIT(p, 4)) {
                 __bf16* dst = out + (long)m * p.ldo + n;
                 const __bf16* src = Cs + row * CSW + cg * OW;
                 if constexpr (OVEC == 8) *reinterpret_cast<bf16x8*>(dst) = *reinterpret_cast<const bf16x8*>(src);
@@ -205,7 +214,7 @@ __device__ __forceinline__ void gconv_epilogue(const GConvP& p, char* smem, f32x
                 } else *dst = *src;
             }
         }
-        if (p.stats && !(p.dbg & 2)) {
+        if (p.stats && !MI_DBG_BIT(p, 2)) {
             // thread -> (column, row group): fixed-order sums over the group's rows, then over the groups
             constexpr int RG = GSmem<BN, 32, false>::RG;         // 8 | 4 | 2 row groups
             constexpr int RPG = GBM / RG;
@@ -344,7 +353,7 @@ __global__ __launch_bounds__(256 * KS) void gconv_kernel(GConvP p) {
 
     // two register sets: the chunk after next is in flight while the next one waits in registers and the current one is in LDS
     bf16x8 ra0[2 * AQ], rb0[BROWS], ra1[2 * AQ], rb1[BROWS];
-    const int total_all = (p.dbg & 1) ? 0 : p.T * p.nchunks;
+    const int total_all = MI_DBG_BIT(p, 1) ? 0 : p.T * p.nchunks;
     const int total = (total_all + KS - 1) / KS;          // K steps of this wave group: it takes the chunks grp, grp + KS, ...
     // load() is called for it = 0, 1, 2, ... in order: (tap, chunk, ky, kx) advance with it instead of being divided out of it on every call
     // (counters of one launch: 113 VALU + 143 SALU instructions per wave and K step beside 16 MFMAs - the waves were issuing index arithmetic half
@@ -571,7 +580,7 @@ __global__ __launch_bounds__(256) void gconv3_kernel(GConvP p) {
         boff[j] = (long)(n0 + nr) * p.Cpad + ch * 8;
     }
     const int kh = p.T / 3;
-    const int total = (p.dbg & 1) ? 0 : kh * p.nchunks;      // K steps: (kernel row, 32-channel chunk), chunk fastest
+    const int total = MI_DBG_BIT(p, 1) ? 0 : kh * p.nchunks;      // K steps: (kernel row, 32-channel chunk), chunk fastest
     int l_ky = 0, l_kc = 0;
     bf16x8 ra0[4], rb0[3 * BROWS], ra1[4], rb1[3 * BROWS];
     auto load = [&](int it, bf16x8 (&ra)[4], bf16x8 (&rb)[3 * BROWS]) {
@@ -820,7 +829,7 @@ __device__ __forceinline__ void gwgrad_body(const GWgP& p, int bid, int nblk, ch
     const int ky = t / p.kw, kx = t - ky * p.kw;
     const int m_begin = split * p.rows_per_split;
     const int m_end = min(p.M, m_begin + p.rows_per_split);
-    const int nk = (p.dbg & 1) ? 0 : (m_end > m_begin ? (m_end - m_begin + WKP - 1) / WKP : 0);
+    const int nk = MI_DBG_BIT(p, 1) ? 0 : (m_end > m_begin ? (m_end - m_begin + WKP - 1) / WKP : 0);
     const int lpx = tid >> 3, lch = tid & 7;          // loader: pixel rows lpx and lpx + 32 of the step, 8-channel chunk
     const int hw = p.Ho * p.Wo;
 
@@ -1038,7 +1047,7 @@ __device__ __forceinline__ void gwgrad3_body(const GWgP& p, int bid, int nblk, c
     const int o0 = ot * WTO, i0 = itile * WTI;
     const int m_begin = split * p.rows_per_split;
     const int m_end = min(p.M, m_begin + p.rows_per_split);
-    const int nk = (p.dbg & 1) ? 0 : (m_end > m_begin ? (m_end - m_begin + WKP - 1) / WKP : 0);
+    const int nk = MI_DBG_BIT(p, 1) ? 0 : (m_end > m_begin ? (m_end - m_begin + WKP - 1) / WKP : 0);
     const int lpx = tid >> 3, lch = tid & 7;
     const int hw = p.Ha * p.Wa;
     const int dyoff = ky * p.dh - p.ph;                      // source row - output row

@@ -44,8 +44,8 @@ struct MiSwitches {
     int gconv_bn_c;        // MI_GCONV_BN_C       64: the cost model's fixed cost per column tile, in columns
     int gconv_bn_force;    // MI_GCONV_BN_FORCE   0: (measurement) one tile width for every launch
     int gconv3_wgs;        // MI_GCONV3_WGS       512: three-column stride-1 convs of at least this many 64-wide workgroups take the kernel-row window kernel (0 never, 1 all: tests)
-    int gconv_dbg;         // MI_GC_DBG           0: (measurement) bit 0 skip the main loop, bit 1 the statistics, bit 2 the stores
-    int gw_dbg;            // MI_GW_DBG           0: (measurement) bit 0: weight gradient without its main loop
+    int gconv_dbg;         // MI_GC_DBG           0: (-DMI_EXPERIMENTS builds only) bit 0 skip the main loop, bit 1 the statistics, bit 2 the stores
+    int gw_dbg;            // MI_GW_DBG           0: (-DMI_EXPERIMENTS builds only) bit 0: weight gradient without its main loop
     int gwm_steps;         // MI_GWM_STEPS        48: batched weight gradients: K steps of 64 pixels per workgroup
     int gwm_fused3;        // MI_GWM_FUSED3       1: batched weight gradients: fused kernel rows wherever the geometry allows (0: the one-conv rule)
     int gwgrad3;           // MI_GWGRAD3          1: general weight gradient of three-column kernels as one fused kernel row per workgroup from 65 536 pixels up (0: per tap, 2: always)

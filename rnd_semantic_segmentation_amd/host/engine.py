@@ -264,6 +264,27 @@ class StageEngine:
             self._pack_sig = sig
             self._have_dgrad = train
 
+    # -- chained 1x1 pairs (csrc/chain.hip): conv3 of a block + conv1 of the next in one launch, and the mirrored pair of data gradients
+    @staticmethod
+    def chain_mode():
+        """MI_CHAIN: 'all' (default) forward and backward, 'fwd', 'bwd', '0' off."""
+        return os.environ.get("MI_CHAIN", "all")
+
+    def _chain_pair(self, bi):
+        """(conv3 of block bi, conv1 of block bi+1) when the pair has the shape mi_conv_chain is built for (256 -> 1024 -> 256, stride 1: the 22
+        identity hand-overs of layer3), else None."""
+        if bi < 0 or bi + 1 >= len(self.blocks) or self.batch_stats:
+            return None
+        (_, rts), (nblk, nrts) = self.blocks[bi], self.blocks[bi + 1]
+        c3, c1 = rts[2].spec, nrts[0].spec
+        ok = (not nblk.down and c3.k == 1 and c1.k == 1 and c3.stride == 1 and c1.stride == 1 and (c3.cin, c3.cout) == (256, 1024)
+              and (c1.cin, c1.cout) == (1024, 256))
+        return (rts[2], nrts[0]) if ok else None
+
+    @staticmethod
+    def _chain_fits(x):
+        return x.is_cuda and x.shape[0] * x.shape[1] * x.shape[2] * 2048 < 2 ** 31
+
     # -- forward
     @staticmethod
     def _fwd_conv(x, rt, relu, res=None, want_mask=False):
@@ -308,15 +329,26 @@ class StageEngine:
         fork.record(main)
         extra.wait_event(fork)
         xin = x
-        for (blk, rts), t in zip(self.blocks, plan):
+        chain = save and self.chain_mode() in ("all", "fwd") and self._chain_fits(x)
+        ahead = False                              # this block's a1 / b1 were written by the previous block's chained launch
+        for bi, ((blk, rts), t) in enumerate(zip(self.blocks, plan)):
+            pair = self._chain_pair(bi) if chain else None
+            tn = plan[bi + 1] if pair is not None else None
             for lane, h in enumerate(halves):
                 with torch.cuda.stream(extra) if lane else contextlib.nullcontext():
                     sl = lambda name: None if t.get(name) is None else t[name][h]
-                    self._conv_into(xin[h], rts[0], True, sl("a1"), sl("b1"))
+                    if not ahead:
+                        self._conv_into(xin[h], rts[0], True, sl("a1"), sl("b1"))
                     self._conv_into(sl("a1"), rts[1], True, sl("a2"), sl("b2"))
                     if blk.down:
                         self._conv_into(xin[h], rts[3], False, sl("idn"))
-                    self._conv_into(sl("a2"), rts[2], True, sl("out"), sl("ob"), res=sl("idn") if blk.down else xin[h])
+                    res = sl("idn") if blk.down else xin[h]
+                    if pair is not None:
+                        K.conv_chain(sl("a2"), pair[0].wp, res, pair[1].wp, pair[0].scale, pair[0].shift, pair[1].scale, pair[1].shift,
+                                     mid=sl("out"), out=tn["a1"][h], bits1_out=sl("ob"), bits2_out=tn["b1"][h])
+                    else:
+                        self._conv_into(sl("a2"), rts[2], True, sl("out"), sl("ob"), res=res)
+            ahead = pair is not None
             xin = t["out"]
         main.wait_stream(extra)
         saved, xbits, xin = [], None, x
@@ -333,8 +365,13 @@ class StageEngine:
             return self._forward_lanes(x, save, extra)
         saved = []
         xbits = None
-        for blk, rts in self.blocks:
-            if save:
+        chain = save and self.chain_mode() in ("all", "fwd") and self._chain_fits(x)
+        ahead = None                               # (a1, bits(a1)) of this block when the previous block's chained launch produced them
+        for bi, (blk, rts) in enumerate(self.blocks):
+            if ahead is not None:
+                a1, b1 = ahead
+                a2, b2 = self._fwd_conv(a1, rts[1], True, want_mask=True)
+            elif save:
                 a1, b1 = self._fwd_conv(x, rts[0], True, want_mask=True)
                 a2, b2 = self._fwd_conv(a1, rts[1], True, want_mask=True)
             else:
@@ -342,7 +379,14 @@ class StageEngine:
                 a2 = self._fwd_conv(a1, rts[1], True)
                 b1 = b2 = None
             idn = self._fwd_conv(x, rts[3], False) if blk.down else x
-            if save:
+            pair = self._chain_pair(bi) if chain else None
+            ahead = None
+            if pair is not None:                   # conv3 + FrozenBN + residual + ReLU, then the next block's conv1 + FrozenBN + ReLU: one launch
+                out, a1n, obits, b1n = K.conv_chain(a2, pair[0].wp, idn, pair[1].wp, pair[0].scale, pair[0].shift, pair[1].scale, pair[1].shift)
+                ahead = (a1n, b1n)
+                saved.append((x, a1, a2, xbits, b1, b2))
+                xbits = obits
+            elif save:
                 out, obits = self._fwd_conv(a2, rts[2], True, res=idn, want_mask=True)
                 saved.append((x, a1, a2, xbits, b1, b2))
                 xbits = obits
@@ -372,8 +416,10 @@ class StageEngine:
         # block is D3 D2 D1 on the main stream (data gradients: MFMA-, MFMA-, HBM-bound) and W3 W2 W1 behind them on the side stream (weight gradients:
         # HBM-, MFMA-, HBM-bound), i.e. W2 beside D2 (both MFMA-bound) and W1 beside D1 (both HBM-bound).  Deferring W1 to the next block's start puts
         # W3 + W1' beside D3 D2 and W2 beside D1.
-        pair = side is not None and os.environ.get("MI_BWD_PAIR", "0") == "1"
+        bwd_pair = side is not None and os.environ.get("MI_BWD_PAIR", "0") == "1"
         deferred = None
+        chain = self.chain_mode() in ("all", "bwd") and self._chain_fits(dfeat)
+        ga2_ahead = None
 
         def hooks(rts_):
             if store is not None and store.grad_hooks:
@@ -393,17 +439,24 @@ class StageEngine:
                 _off_path(side, lambda: self._wgrad(dga1, dx_, drts[0]), dga1, dx_)
                 hooks(drts)
                 deferred = None
-            ga2 = self._dgrad(g, rts[2], (a2.shape[1], a2.shape[2]), bits=b2)
+            if ga2_ahead is not None:                     # written by the chained launch of the block above (its conv1's data gradient)
+                ga2, ga2_ahead = ga2_ahead, None
+            else:
+                ga2 = self._dgrad(g, rts[2], (a2.shape[1], a2.shape[2]), bits=b2)
             _off_path(side, lambda: self._wgrad(ga2, a1, rts[1]), ga2, a1)
             ga1 = self._dgrad(ga2, rts[1], hw_mid, bits=b1)
             if blk.down:
                 _off_path(side, lambda: self._wgrad(g, x, rts[3]), g, x)
-            if pair and not first:
+            if bwd_pair and not first:
                 deferred = (ga1, x, rts)
             else:
                 _off_path(side, lambda: self._wgrad(ga1, x, rts[0]), ga1, x)
+            pair = self._chain_pair(bi - 1) if chain and not first and not blk.down else None
             if first and not need_dx:
                 g = None
+            elif pair is not None:
+                # conv1's data gradient + skip + the ReLU mask of x, then conv3's data gradient of the block BELOW + its ReLU mask: one launch
+                g, ga2_ahead = K.conv_chain(ga1, rts[0].wpt, g, pair[0].wpt, bits1=xb, bits2=saved[bi - 1][5])
             else:
                 skip = self._dgrad(g, rts[3], hw_in) if blk.down else g
                 g = self._dgrad(ga1, rts[0], hw_in, res=skip, bits=None if first else xb)
@@ -666,32 +719,16 @@ class Fp32Aspp:
         return out
 
 
-def _stem_on_library():
-    """MI_STEM_CONV=miopen: the 7x7/2 stem conv forward on the PyTorch-ROCm library (round 1: SURVEY 8a row A6).  Default (hip): patch matrix +
-    plain GEMM on the implicit-GEMM kernel, so that no library convolution is left in the training step."""
-    return os.environ.get("MI_STEM_CONV", "hip") == "miopen"
-
-
 def stem_conv_forward(x, weight):
-    """x [B,3,H,W] bf16 channels_last, weight fp32 [64,3,7,7] -> (y [B,Hc,Wc,64] bf16 NHWC, what the weight gradient needs)."""
-    if _stem_on_library():
-        w16 = weight.detach().to(torch.bfloat16)
-        return torch.nn.functional.conv2d(x, w16, None, 2, 3).permute(0, 2, 3, 1).contiguous(), (x, w16)
+    """x [B,3,H,W] bf16 channels_last, weight fp32 [64,3,7,7] -> (y [B,Hc,Wc,64] bf16 NHWC, what the weight gradient needs): patch matrix + plain
+    GEMM on the implicit-GEMM kernel - no library convolution anywhere in the step (rounds 1-4 kept an MIOpen branch behind MI_STEM_CONV; removed)."""
     y, col = K.stem_conv_fwd(x, weight)
     return y, (col,)
 
 
 def stem_conv_wgrad(dy_nhwc, saved):
-    """d loss / d conv1.weight.  Default: the 1x1 weight-gradient kernel on the forward's patch matrix (bit-reproducible).  With the library
-    forward: patch matrix built here, or (MI_STEM_WGRAD=miopen) the library's weight gradient, whose atomics were the one
-    nondeterministic launch of the step."""
-    if len(saved) == 1:
-        return K.stem_wgrad(dy_nhwc, col=saved[0])
-    x, w16 = saved
-    if os.environ.get("MI_STEM_WGRAD", "hip") == "miopen":
-        dy = dy_nhwc.permute(0, 3, 1, 2)                                                  # NCHW-shaped, channels_last
-        return torch.ops.aten.convolution_backward(dy, x, w16, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1, [False, True, False])[1].float()
-    return K.stem_wgrad(dy_nhwc, x=x)
+    """d loss / d conv1.weight: the 1x1 weight-gradient kernel on the forward's patch matrix (bit-reproducible)."""
+    return K.stem_wgrad(dy_nhwc, col=saved[0])
 
 
 class StemConvFn(torch.autograd.Function):

@@ -122,8 +122,9 @@ def test_opt_in_kernel_variants_and_single_stream_schedule_stay_correct():
                      ({"MI_WGRAD_S4": "0"}, ["tests/test_gpu_ops.py", "-k", "tiny_and_ragged or wgrad_full or pointwise or aspp_head_2048"]),   # 1x1 weight gradients on the double-buffer kernel
                      ({"MI_WGRAD_TI256": "0"}, ["tests/test_gpu_ops.py", "-k", "wgrad_full or aspp_head_2048 or aspp_head_upsample"]),   # the big 1x1 shapes on the 128 x 128 kernels
                      ({"MI_WGRAD_TI256": "1"}, ["tests/test_gpu_ops.py", "-k", "tiny_and_ragged or wgrad_full or full_size_vs or aspp_head_2048"]),
-                     ({"MI_STEM_CONV": "miopen"}, ["tests/test_gpu_model.py", "-k", "tinynet_three_sgd or tinynet_forward_backward or bit_reproducible"]),   # library stem forward, HIP weight gradient
-                     ({"MI_STEM_CONV": "miopen", "MI_STEM_WGRAD": "miopen"}, ["tests/test_gpu_model.py", "-k", "tinynet_three_sgd or tinynet_forward_backward"]),   # the library's stem conv both ways
+                     ({"MI_CHAIN": "0"}, ["tests/test_gpu_model.py", "-k", "tinynet_three_sgd or r101_769 or bit_reproducible"]),   # the chained 1x1 pairs as two launches each
+                     # measurement switches of experiment builds: the PRODUCT library must ignore them (they would skip main loops / stores)
+                     ({"MI_GC_DBG": "7", "MI_GW_DBG": "1", "MI_P3_DBG": "31"}, ["tests/test_gpu_gops.py", "-k", "forward_and_batch_statistics or data_and_weight_gradient"]),
                      ({"MI_BN_TWO_PASS": "1"}, ["tests/test_gpu_bn.py", "-k", "tinynet_trainable"]),             # BatchNorm statistics as two passes
                      ({"MI_GWGRAD3": "2"}, ["tests/test_gpu_gops.py", "-k", "weight_gradient"]),                  # general family: fused-row weight gradient forced onto the small shapes
                      ({"MI_GWGRAD3": "0", "MI_INLAUNCH": "0", "MI_BN_INLAUNCH": "0"}, ["tests/test_gpu_gops.py", "-k", "weight_gradient or batch_statistics"]),   # per-tap kernel, two-launch reductions

@@ -8,9 +8,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.environ.get("CHAIN_TRACE_LIB") or os.path.join(ROOT, "tools", "experiments", "libchain_trace.so")
-NAMES = ["top -> A0 first half", "wait + barrier", "issue W,R + read A1", "A0 second + A1 first half", "wait + barrier", "issue W + read B0", "A1 second half",
-         "residual wait", "epilogue + stores", "B0 first half", "wait + barrier", "issue W + read B1", "B0 second + B1 first half", "wait + barrier",
-         "issue W + read A0'", "B1 second half -> next top"]
+NAMES = ["A0: read 2nd half + MFMA 1st half", "A0: wait + barrier", "A0: issue W,R + read next 1st half", "A0: MFMA 2nd half + residual wait + epilogue half 0",
+         "A1: read + MFMA 1st half", "A1: wait + barrier", "A1: issue W + read", "A1: MFMA 2nd half + epilogue half 1 + stores",
+         "B0: read + MFMA 1st half", "B0: wait + barrier", "B0: issue W + read", "B0: MFMA 2nd half",
+         "B1: read + MFMA 1st half", "B1: wait + barrier", "B1: issue W + read", "B1: MFMA 2nd half"]
 
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     ps = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("-") else "0"
@@ -33,16 +34,18 @@ for _ in range(3):
     T._chain(ops, bwd)
 torch.cuda.synchronize()
 h = ctypes.CDLL(LIB)
-buf = (ctypes.c_uint * 260)()
-assert h.mi_chain_trace_read(buf, 260) == 0
-t = np.array(buf[:256], dtype=np.int64).reshape(16, 16)
-d = np.zeros((16, 16), dtype=np.int64)
-d[:, :15] = t[:, 1:] - t[:, :15]
-d[:15, 15] = t[1:, 0] - t[:15, 15]
-d &= 0xFFFFFFFF
-print("cycles between stamps, median / min / max over chunks 2..14 (one wave; %s)" % ("backward" if bwd else "forward"))
-for k in range(16):
-    col = d[2:15, k]
-    print("  %2d %-32s %6d %6d %6d" % (k, NAMES[k], np.median(col), col.min(), col.max()))
-print("  chunk total (median): %d cycles" % np.median(d[2:15].sum(1)))
-print("  pass: %d cycles, %.1f us -> clock %.2f GHz" % (buf[256], buf[257] / 100.0, buf[256] / (buf[257] * 10.0)))
+buf = (ctypes.c_uint * 516)()
+assert h.mi_chain_trace_read(buf, 516) == 0
+for grp in range(2):
+    t = np.array(buf[grp * 256:grp * 256 + 256], dtype=np.int64).reshape(16, 16)
+    d = np.zeros((16, 16), dtype=np.int64)
+    d[:, :15] = t[:, 1:] - t[:, :15]
+    d[:15, 15] = t[1:, 0] - t[:15, 15]
+    d &= 0xFFFFFFFF
+    print("group %d: cycles between stamps, median / min / max over chunks 2..14 (one wave; %s)" % (grp, "backward" if bwd else "forward"))
+    for k in range(16):
+        col = d[2:15, k]
+        print("  %2d %-56s %6d %6d %6d" % (k, NAMES[k], np.median(col), col.min(), col.max()))
+    print("  chunk total (median): %d cycles" % np.median(d[2:15].sum(1)))
+    cyc, rt = buf[512 + 2 * grp], buf[513 + 2 * grp]
+    print("  pass: %d cycles, %.1f us -> clock %.2f GHz" % (cyc, rt / 100.0, cyc / (rt * 10.0)))
