@@ -127,6 +127,38 @@ def aux_workload(args, device):
         metric = "train images/sec at %dx%d bf16 (PraNet Res2Net-50, BASELINE config[3]; one step = ONE of the three passes of a reference iteration)" % (H, W)
         workload = ("configs/pranet_src_polyp.yaml: PraNet, one optimizer step = forward, four structure losses, backward, clamped Adam on B=%d %dx%d - the "
                     "reference's iteration (pranet_trainer.py:44-61) runs three such steps per batch (its three 'scales' all resize to trainsize)" % (B, H, W))
+    elif args.workload == "fada":
+        # BASELINE config[4] on one GPU: train_adv.py configs/deeplabv2_r101_adv.yaml - B/2 source + B/2 target crops through AsppFada.train_step
+        # (reference core/combos/aspp_fada.py:80-127: source pass + CE at temperature 1.8, target pass + 0.001 x adversarial loss, both SGDs,
+        # then the two 0.5 x discriminator losses on detached features and Adam; core/models/discriminator.py:31-50)
+        import logging
+        from rnd_semantic_segmentation_amd.host import config as hc, fada, modules
+        from rnd_semantic_segmentation_amd.host import trainer as tr
+        B, H, W = args.batch or 8, args.size or 769, args.size or 769
+        cfg = hc.CfgNode(hc.default_tree())
+        cfg.merge_from_file(os.path.join(ROOT, "configs", "deeplabv2_r101_adv.yaml"))
+        cfg.merge_from_list(["OUTPUT_DIR", "/tmp/mi355seg_bench_fada"])
+        cfg.freeze()
+
+        def formula(m):
+            synth.load_formula_weights(m)
+            return m
+        tr.ASPPTrainer.build_feature_extractor = staticmethod(lambda c: formula(modules.build_feature_extractor(c)))
+        tr.ASPPTrainer.build_classifier = staticmethod(lambda c: formula(modules.build_classifier(c)))
+        fada.FADAAdapter.build_adversarial_discriminator = staticmethod(lambda c: formula(fada.build_adversarial_discriminator(c)))
+        fada.setup_logger = lambda *a, **k: logging.getLogger("bench_fada")
+        combo = fada.AsppFada("aspp_fada", cfg, [], [], 0)
+        hb = B // 2
+        xs = torch.from_numpy(synth.synth_image(hb, H, W, seed=1)).to(device)
+        ys = torch.from_numpy(synth.synth_label(hb, H, W, 19, seed=1)).to(device)
+        xt = torch.from_numpy(synth.synth_image(hb, H, W, seed=2)).to(device)
+
+        def step():
+            return combo.train_step(xs, ys, xt, 10000)["loss_seg"]          # max_iter 10 000: the poly learning rate stays near its base value
+        graphed, runner = None, step
+        metric = "train images/sec at %dx%d bf16 (FADA adversarial iteration, source + target images; BASELINE config[4] on one GPU)" % (W, H)
+        workload = ("train_adv.py configs/deeplabv2_r101_adv.yaml: one AsppFada iteration = %d source + %d target %dx%d crops, DeepLabV2-R101 + ASPP + "
+                    "PixelDiscriminator, 2 x SGD + Adam" % (hb, hb, W, H))
     else:
         B, H, W = args.batch or 6, 720, 1280
         enc, dec = gald.GCPAEncoder().to(device).train(), gald.GCPADecoder().to(device).train()
@@ -249,7 +281,23 @@ def aux_cpu_baseline(workload, H, W, budget_s=30.0):
     cores = granted_cores()
     torch.set_num_threads(cores)
     Bc = 2
-    if workload == "pranet":
+    if workload == "fada":
+        from oracle import ref_model
+        fe, cls, D = ref_model.RefFeatureExtractor(), ref_model.RefASPP(), ref_model.RefPixelDiscriminator(2048, 256, 19)
+        for m in (fe, cls, D):
+            synth.load_formula_weights(m)
+        of, oc = ref_model.make_optimizers(fe, cls, 2.5e-4)
+        od = torch.optim.Adam(D.parameters(), lr=1e-4, betas=(0.9, 0.99))
+        xs = torch.from_numpy(synth.synth_image(1, H, W, seed=1)).float()
+        ys = torch.from_numpy(synth.synth_label(1, H, W, 19, seed=1))
+        xt = torch.from_numpy(synth.synth_image(1, H, W, seed=2)).float()
+        cnt = [0]
+
+        def step():
+            cnt[0] += 1
+            ref_model.ref_fada_step(fe, cls, D, of, oc, od, xs, ys, xt, cnt[0], 40000, 2.5e-4, 1e-4)
+        what = "oracle/ref_model.py:ref_fada_step (1 source + 1 target image per step)"
+    elif workload == "pranet":
         from oracle import ref_pranet
         net = ref_pranet.PraNet().train()
         opt = torch.optim.Adam(net.parameters(), 1e-4)
@@ -282,7 +330,7 @@ def aux_cpu_baseline(workload, H, W, budget_s=30.0):
         what = "oracle/ref_gald.py"
     step()                                            # warm-up (oneDNN primitive creation)
     n, t0 = 0, time.time()
-    while n < 3 and (n == 0 or time.time() - t0 < budget_s):
+    while n < (2 if workload == "fada" else 3) and (n == 0 or time.time() - t0 < budget_s):
         step()
         n += 1
     dt = time.time() - t0
@@ -304,9 +352,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (BASELINE: 8; pranet 16, gald 6)")
     ap.add_argument("--size", type=int, default=None, help="crop side (BASELINE: 769; pranet 352)")
-    ap.add_argument("--workload", choices=("deeplab", "deeplab_bn", "pranet", "gald"), default="deeplab",
+    ap.add_argument("--workload", choices=("deeplab", "deeplab_bn", "pranet", "gald", "fada"), default="deeplab",
                     help="deeplab = BASELINE config[1] (the headline, default); deeplab_bn = the same step with MODEL.FREEZE_BN False (trainable "
-                         "BatchNorm2d on batch statistics); pranet = config[3]; gald = the third model of train_src.py")
+                         "BatchNorm2d on batch statistics); pranet = config[3]; gald = the third model of train_src.py; fada = config[4] on one GPU: train_adv.py's adversarial iteration, 4 source + 4 target crops")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()

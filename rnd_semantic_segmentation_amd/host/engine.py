@@ -267,8 +267,10 @@ class StageEngine:
     # -- chained 1x1 pairs (csrc/chain.hip): conv3 of a block + conv1 of the next in one launch, and the mirrored pair of data gradients
     @staticmethod
     def chain_mode():
-        """MI_CHAIN: 'all' (default) forward and backward, 'fwd', 'bwd', '0' off."""
-        return os.environ.get("MI_CHAIN", "all")
+        """MI_CHAIN: 'all' forward and backward, 'fwd', 'bwd', '0' (default) off.  Off by default on numbers: the
+        launch alone beats the pair it replaces (151 vs 175 us) but owns its CU (154 KiB of LDS), so the weight-gradient stream and the second forward
+        lane stop overlapping with it - the step measured 29.1 ms with it against 28.0 ms without."""
+        return os.environ.get("MI_CHAIN", "0")
 
     def _chain_pair(self, bi):
         """(conv3 of block bi, conv1 of block bi+1) when the pair has the shape mi_conv_chain is built for (256 -> 1024 -> 256, stride 1: the 22

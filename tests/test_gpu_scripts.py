@@ -91,9 +91,10 @@ def test_bench_under_torchrun_nccl_single_rank_exercises_the_reducer():
     assert abs(out2["config"]["final_loss"] - out["config"]["final_loss"]) < 1e-4
 
 
-@pytest.mark.parametrize("workload,extra", [("pranet", ["--batch", "2", "--size", "96"]), ("gald", ["--batch", "1"]), ("deeplab_bn", ["--batch", "2", "--size", "161"])])
+@pytest.mark.parametrize("workload,extra", [("pranet", ["--batch", "2", "--size", "96"]), ("gald", ["--batch", "1"]), ("deeplab_bn", ["--batch", "2", "--size", "161"]),
+                                            ("fada", ["--batch", "2", "--size", "129"])])
 def test_bench_other_workloads_print_the_contract_line(workload, extra):
-    """bench.py --workload pranet | gald | deeplab_bn (BASELINE config[3], the GALD step, the trainable-BatchNorm DeepLab step): one JSON line with the
+    """bench.py --workload pranet | gald | deeplab_bn | fada (BASELINE config[3], the GALD step, the trainable-BatchNorm DeepLab step, config[4] on one GPU): one JSON line with the
     contract's keys, a roofline object for the dominant kernel of the instrumented steps, finite loss."""
     import math
     r = run(["bench.py", "--workload", workload, "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + extra, {})
@@ -122,7 +123,7 @@ def test_opt_in_kernel_variants_and_single_stream_schedule_stay_correct():
                      ({"MI_WGRAD_S4": "0"}, ["tests/test_gpu_ops.py", "-k", "tiny_and_ragged or wgrad_full or pointwise or aspp_head_2048"]),   # 1x1 weight gradients on the double-buffer kernel
                      ({"MI_WGRAD_TI256": "0"}, ["tests/test_gpu_ops.py", "-k", "wgrad_full or aspp_head_2048 or aspp_head_upsample"]),   # the big 1x1 shapes on the 128 x 128 kernels
                      ({"MI_WGRAD_TI256": "1"}, ["tests/test_gpu_ops.py", "-k", "tiny_and_ragged or wgrad_full or full_size_vs or aspp_head_2048"]),
-                     ({"MI_CHAIN": "0"}, ["tests/test_gpu_model.py", "-k", "tinynet_three_sgd or r101_769 or bit_reproducible"]),   # the chained 1x1 pairs as two launches each
+                     ({"MI_CHAIN": "all"}, ["tests/test_gpu_model.py", "-k", "r101_769 or hip_graph_replay"]),   # the 22 conv3 -> conv1 pairs of layer3 and their data gradients as one chained launch each
                      # measurement switches of experiment builds: the PRODUCT library must ignore them (they would skip main loops / stores)
                      ({"MI_GC_DBG": "7", "MI_GW_DBG": "1", "MI_P3_DBG": "31"}, ["tests/test_gpu_gops.py", "-k", "forward_and_batch_statistics or data_and_weight_gradient"]),
                      ({"MI_BN_TWO_PASS": "1"}, ["tests/test_gpu_bn.py", "-k", "tinynet_trainable"]),             # BatchNorm statistics as two passes

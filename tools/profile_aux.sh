@@ -30,10 +30,11 @@ if [ "${PMC:-1}" = "1" ]; then
     pmc pranet adam 1 --workload pranet --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-events
     pmc gald adam 2 --workload gald --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-events
     pmc deeplab_bn sgd_kernel 2 --workload deeplab_bn --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-events
+    pmc fada adam 1 --workload fada --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-events
 fi
 run pranet $root/bench.py --workload pranet --no-cpu-baseline --no-kernel-events
 run gald $root/bench.py --workload gald --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-events
 run deeplab_bn $root/bench.py --workload deeplab_bn --steps 10 --warmup 4 --no-cpu-baseline --no-kernel-events
-run fada $root/tools/fada_bench.py
+run fada $root/bench.py --workload fada --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-events
 run infer $root/tools/infer_bench.py
 tail -3 $root/gpurun_out/${tag}_fada.log $root/gpurun_out/${tag}_infer.log
