@@ -46,6 +46,32 @@ def synthetic_batch(batch, size, rank, device):
     return x.to(device), lab.to(device)
 
 
+def head_commit():
+    """The commit this tree is at: `git rev-parse` where .git exists, else the .commit_stamp file the profiling recipes write before a gpurun call (the
+    GPU box receives the tree without .git), else None."""
+    import subprocess
+    try:
+        r = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10)
+        if r.returncode == 0 and r.stdout.strip():
+            return r.stdout.strip()
+    except (OSError, subprocess.SubprocessError):
+        pass
+    try:
+        return open(os.path.join(ROOT, ".commit_stamp")).read().strip() or None
+    except OSError:
+        return None
+
+
+def counters_stale(profiled):
+    """True when the hardware-counter file a roofline's `traffic` / HBM fraction come from was taken at another commit than the one running (the
+    kernels may have changed since); None when either commit is unknown."""
+    head = head_commit()
+    if not head or not profiled:
+        return None
+    n = min(len(head), len(profiled))
+    return head[:n] != profiled[:n]
+
+
 def granted_cores():
     """Cores this process may actually use: the scheduler affinity capped by the cgroup CPU quota (a 1-GPU box exposes every
     core of the host in the affinity mask but grants a 16-core share; running 100+ threads on it takes minutes per step)."""
@@ -242,7 +268,7 @@ def aux_workload(args, device):
             e = pmc[pmc_class]
             traffic, hbm_frac, busy = e.get("hbm_bytes_per_launch"), e.get("hbm_frac_of_peak"), e.get("mfma_busy_frac")
             src = {"file": "profiles/pmc_%s.json" % args.workload, "class": pmc_class, "profiled_commit": pmc["_meta"].get("commit"), "round": pmc["_meta"].get("round"),
-                   "avg_launch_us_under_counters": e.get("avg_launch_us"), "l2_hit_frac": e.get("l2_hit_frac")}
+                   "avg_launch_us_under_counters": e.get("avg_launch_us"), "l2_hit_frac": e.get("l2_hit_frac"), "counters_stale": counters_stale(pmc["_meta"].get("commit"))}
             whole = {k: pmc["_meta"].get(k) for k in ("kernel_ms_per_step", "launches_per_step", "hbm_read_gb_per_step", "hbm_write_gb_per_step", "hbm_tb_s_over_kernel_time")}
         except (OSError, KeyError, ValueError):
             pass
@@ -510,7 +536,8 @@ def main():
                 if "l2_hit_frac" in pmc[key]:
                     l2 = {"hit_frac": pmc[key]["l2_hit_frac"], "requests_per_launch": pmc[key]["l2_requests_per_launch"],
                           "mfma_busy_frac": pmc[key]["mfma_busy_frac"]}
-                traffic_src = {"file": "profiles/pmc.json", "profiled_commit": pmc.get("_meta", {}).get("commit"), "round": pmc.get("_meta", {}).get("round")}
+                traffic_src = {"file": "profiles/pmc.json", "profiled_commit": pmc.get("_meta", {}).get("commit"), "round": pmc.get("_meta", {}).get("round"),
+                               "counters_stale": counters_stale(pmc.get("_meta", {}).get("commit"))}
             except (OSError, KeyError, ValueError):
                 pass
             if dom == "bn_kernels":      # MODEL.FREEZE_BN False: the elementwise BatchNorm passes together outweigh any one conv kernel - HBM-bound

@@ -255,7 +255,7 @@ __device__ __forceinline__ void gconv_epilogue(const GConvP& p, char* smem, f32x
             if constexpr (BN == 32 || BN == 64) {
             if (p.fin_out) {
                 // The column tile's last workgroup turns the row tiles' sums into mean / invstd / folded affine and updates the running statistics with
-                // mi_gbn_finalize's arithmetic in its order - for at most 128 row tiles every tile is its own lane and the lanes are added in ascending order
+                // mi_gbn_finalize's arithmetic in its order - for at most MI_INLAUNCH_MAX_PARTS = 64 row tiles (the launcher's limit) every tile is its own lane and the lanes are added in ascending order
                 // (double): the same bits as the separate launch.  The loads of a channel are spread over the L = 256 / BN threads that share it (a few
                 // independent loads each, no register arrays that would cost the main loop its occupancy) and meet in LDS, one statistic at a time
                 // ([64][BN] floats: 16 KB at BN = 64); one thread per channel adds them.

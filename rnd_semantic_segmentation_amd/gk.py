@@ -104,6 +104,15 @@ def tickets(device, n=256):
     return t
 
 
+def _check_tickets(rc, what, device):
+    """check() for the launches that use the ticket words: a launch that failed may have left words non-zero (some workgroups drew tickets, the last
+    arriver never reset them); the next launch on the stream would then find no 'last arriver' and leave its second-level results unwritten, silently.
+    Drop the stream's buffer: the next call allocates a zeroed one."""
+    if rc != 0:
+        _tickets.pop((device.index, _stream().value), None)
+    check(rc, what)
+
+
 _inlaunch_px = [None]
 
 
@@ -129,8 +138,8 @@ def gconv_bn(a, wp, N, geom, bn_weight, bn_bias, running_mean, running_var, mome
     tk = tickets(a.device, (N + 31) // 32)
     if _K.PROFILE is not None:
         _work[0], _work[1] = 2.0 * B * Ho * Wo * N * Ca * kh * kw, ("gconv", kh, kw, Ca, N, B * Ho * Wo, GATHER_FWD)
-    check(L.mi_gconv_bn(pa, lda, _p(wp), po, ldo, B, Ha, Wa, Ca, Ho, Wo, N, kh, kw, sh, sw, ph, pw, dh, dw, _p(bias), _p(st), _p(tk), _p(bn_weight), _p(bn_bias),
-                        _p(running_mean), _p(running_var), float(momentum), float(eps), _p(fin), _stream()), "mi_gconv_bn")
+    _check_tickets(L.mi_gconv_bn(pa, lda, _p(wp), po, ldo, B, Ha, Wa, Ca, Ho, Wo, N, kh, kw, sh, sw, ph, pw, dh, dw, _p(bias), _p(st), _p(tk), _p(bn_weight), _p(bn_bias),
+                                 _p(running_mean), _p(running_var), float(momentum), float(eps), _p(fin), _stream()), "mi_gconv_bn", a.device)
     return out, fin
 
 
@@ -148,8 +157,8 @@ def gconv_wgrad(dy, x, dw, geom, accumulate=False):
     if _K.PROFILE is not None:
         _work[0], _work[1] = 2.0 * B * Ho * Wo * O * I * kh * kw, ("gwgrad", kh, kw, I, O, B * Ho * Wo, 0)
     tk = tickets(dy.device, 256 + 4096)[256:] if INLAUNCH else None          # (words 0 .. 255: the conv / column-sum reductions)
-    check(L.mi_gconv_wgrad(py, ldy, px, ldx, _p(dw), B, Ha, Wa, I, Ho, Wo, O, kh, kw, sh, sw, ph, pw, dh, dw_, int(accumulate), _p(ws), ws.numel(), _p(tk),
-                           tk.numel() if tk is not None else 0, _stream()), "mi_gconv_wgrad")
+    _check_tickets(L.mi_gconv_wgrad(py, ldy, px, ldx, _p(dw), B, Ha, Wa, I, Ho, Wo, O, kh, kw, sh, sw, ph, pw, dh, dw_, int(accumulate), _p(ws), ws.numel(), _p(tk),
+                                    tk.numel() if tk is not None else 0, _stream()), "mi_gconv_wgrad", dy.device)
     return dw
 
 

@@ -108,6 +108,9 @@ def _basic(name, cin, cout, k, pad=0):
     return _Unit(name + ".conv", name + ".bn", cin, cout, k, 1, pad)
 
 
+_WQ_BUDGET = int(float(os.environ.get("MI_WGRAD_QUEUE_MB", "2048")) * (1 << 20))
+
+
 # ------------------------------------------------------------------------------------------------ tape
 class _Var:
     """A tensor of the schedule with its gradient slot.  `own`: the gradient tensor belongs to this variable alone (in-place accumulation is
@@ -178,6 +181,7 @@ class _Run:
     def __init__(self, net, train, rec):
         self.net, self.train, self.rec, self.tape, self.side = net, train, rec, [], None
         self.wq, self.wq_slots, self.wq_fix = None, None, []            # weight gradients queued during backward (see _conv_backward)
+        self.wq_bytes = 0
         # fp32: the evaluation forward in the reference's precision (csrc/gf32.hip; _Engine.set_precision): every activation fp32, every conv with
         # its eval()-BatchNorm affine, residual and activation in one launch
         self.f32 = (not train) and getattr(net, "precision", "bf16") == "fp32"
@@ -311,6 +315,12 @@ class _Run:
                 self.flush_wgrads()
             self.wq.append((dy, x.t, slot, u.geom, acc))
             self.wq_slots.add(slot.data_ptr())
+            # the queue keeps every dy alive (and its flush sums a private split-K slab per job): bounded, so that backward's peak memory does not
+            # grow with the depth of the net - MI_WGRAD_QUEUE_MB of queued gradients (default 2048: PraNet at 16 x 352 x 352 and GALD at 6 x 720 x 1280
+            # never reach it; a flush costs one more pair of launches)
+            self.wq_bytes += dy.numel() * dy.element_size()
+            if self.wq_bytes > _WQ_BUDGET:
+                self.flush_wgrads()
         else:
             _off_path(side, lambda: gk.gconv_wgrad(dy, x.t, slot, u.geom, accumulate=acc), dy, x.t)
         if x.needs:
@@ -482,6 +492,7 @@ class _Run:
                 slot.add_(wide[:, :cin]) if acc else slot.copy_(wide[:, :cin])
         if self.wq is not None:
             self.wq, self.wq_slots, self.wq_fix = [], set(), []
+        self.wq_bytes = 0
 
     def backward(self):
         self.side = _SideStream.get(self.net._store.data.device) if os.environ.get("MI_TAPE_WGRAD_STREAM", "0") == "1" else None
@@ -977,6 +988,9 @@ class FlatAdam(torch.optim.Adam):
         if g.get("amsgrad") or g.get("weight_decay", 0) != 0 or g.get("maximize"):
             raise NotImplementedError("FlatAdam implements the reference's configuration (pranet_trainer.py:20)")
         self._steps += 1
+        # a backward pass that never reached this module (detached features, a loss that bypasses it) ran no zero_stale(): the previous pass's gradients
+        # would still sit in the flat buffer and be applied.  Cleared here: what torch's zero_grad(set_to_none=False) leaves (a no-op after a normal pass)
+        st.zero_stale()
         if self.device_hyper is not None:
             if not torch.cuda.is_current_stream_capturing():
                 self.push_hyper()
