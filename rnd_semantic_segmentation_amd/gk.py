@@ -91,7 +91,9 @@ def gconv(a, wp, N, geom, out=None, mode=GATHER_FWD, out_hw=None, bias=None, sta
 
 
 _tickets = {}
-INLAUNCH = __import__("os").environ.get("MI_INLAUNCH", "1") != "0"      # second-level reductions inside the first launch where they are small
+# second-level reductions inside the first launch where they are small: OFF by default since round 5 (measured neutral under graph replay and in GALD's
+# eager step; they pay only in eager PraNet, which is not the trainer's default): MI_INLAUNCH=1 turns them on (same bits either way)
+INLAUNCH = __import__("os").environ.get("MI_INLAUNCH", "0") == "1"
 
 
 def tickets(device, n=256):

@@ -240,8 +240,9 @@ class _Run:
             y, _ = _conv_forward(x.t, u, bias, False, net=net)
             return self.var(gk.gbn_apply(y, sc, sh, act, add=None if add is None else add.t, out=out, out_f32=out_f32), False)
         hw = gk.conv_out_hw(x.t.shape[1], x.t.shape[2], *u.geom)
-        if not _mfma_tile_ok(u, x.t) and gk.gconv_bn_fits(x.t.shape[0], *hw) and os.environ.get("MI_BN_INLAUNCH", "1") != "0":
-            # small maps: the conv's last workgroup finalizes the statistics itself (one launch instead of two)
+        if not _mfma_tile_ok(u, x.t) and gk.gconv_bn_fits(x.t.shape[0], *hw) and os.environ.get("MI_BN_INLAUNCH", "0") == "1":
+            # small maps, opt-in (MI_BN_INLAUNCH=1): the conv's last workgroup finalizes the statistics itself (one launch instead of two; the same bits).
+            # Off by default since round 5: under the HIP-graph replay PraNetTrainer runs it costs 1 % (1 035 vs 1 045 images/s, profiles/r05_inlaunch_ab.txt)
             y, fin = gk.gconv_bn(x.t, u.wp, u.cout, u.geom, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, bias=bias)
             M = y.shape[0] * y.shape[1] * y.shape[2]
         else:

@@ -128,7 +128,7 @@ def test_opt_in_kernel_variants_and_single_stream_schedule_stay_correct():
                      ({"MI_GC_DBG": "7", "MI_GW_DBG": "1", "MI_P3_DBG": "31"}, ["tests/test_gpu_gops.py", "-k", "forward_and_batch_statistics or data_and_weight_gradient"]),
                      ({"MI_BN_TWO_PASS": "1"}, ["tests/test_gpu_bn.py", "-k", "tinynet_trainable"]),             # BatchNorm statistics as two passes
                      ({"MI_GWGRAD3": "2"}, ["tests/test_gpu_gops.py", "-k", "weight_gradient"]),                  # general family: fused-row weight gradient forced onto the small shapes
-                     ({"MI_GWGRAD3": "0", "MI_INLAUNCH": "0", "MI_BN_INLAUNCH": "0"}, ["tests/test_gpu_gops.py", "-k", "weight_gradient or batch_statistics"]),   # per-tap kernel, two-launch reductions
+                     ({"MI_GWGRAD3": "0", "MI_INLAUNCH": "1", "MI_BN_INLAUNCH": "1"}, ["tests/test_gpu_gops.py", "tests/test_gpu_pranet.py", "-k", "weight_gradient or batch_statistics or graph_replay or running_statistics"]),   # per-tap kernel, in-launch reductions (opt-in since round 5)
                      ({"MI_WGRAD_BATCH": "0", "MI_GCONV_REMAP": "0"}, ["tests/test_gpu_pranet.py", "-k", "building_blocks or graph_replay or stale"]),     # tape: every weight gradient its own launch (the queue off), plain tile order
                      ({"MI_GCONV3_WGS": "1"}, ["tests/test_gpu_gops.py", "-k", "gconv"]),                                          # kernel-row window conv on every eligible (tiny) shape
                      ({"MI_GCONV_BN_ANY": "0", "MI_GCONV_KS2_WGS": "0", "MI_GCONV3_WGS": "0"}, ["tests/test_gpu_gops.py", "-k", "gconv"]),   # 32 / 64-wide tiles, one wave group, no window kernel
