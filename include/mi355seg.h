@@ -131,6 +131,18 @@ int mi_conv_wgrad(const void* dy, const void* x, float* dw,
                   const float* scale_o, int accumulate, int out_map, int ncls, size_t dw_elems,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* mi_conv_wgrad in two parts (round 5): _partial runs the main kernel only - the split-K slabs stay in `workspace`, which the caller keeps alive and
+ * untouched until the reduction - and writes the reducer's arguments to `job` (mi_conv_wgrad_job_bytes() bytes of host memory); mi_conv_wgrad_reduce runs
+ * the reducers of up to 4 consecutive job records as ONE launch (the three weight gradients of a bottleneck: one launch instead of three on the
+ * weight-gradient stream).  Same fixed summation order per conv: the same bits as mi_conv_wgrad. */
+size_t mi_conv_wgrad_job_bytes(void);
+int mi_conv_wgrad_partial(const void* dy, const void* x, float* dw,
+                          int B, int Ha, int Wa, int I, int Ho, int Wo, int O,
+                          int ksize, int stride, int pad, int dil,
+                          const float* scale_o, int accumulate, int out_map, int ncls, size_t dw_elems,
+                          void* workspace, size_t workspace_bytes, void* job, void* stream);
+int mi_conv_wgrad_reduce(const void* jobs, int n, void* stream);
+
 /* ---- ASPP head (reference core/models/classifiers/aspp/classifier.py:6-32) ---------------------
  * forward:  Z = X * Wall^T as ONE plain GEMM (mi_conv_gemm, ksize 1, MI_EPI_ZSPLIT, zgw 20) over all
  * 4 rates x 9 taps x 19 classes, then mi_aspp_col2im sums the 36 shifted planes (+ the 4 biases):

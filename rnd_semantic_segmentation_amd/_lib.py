@@ -29,6 +29,9 @@ SIGNATURES = {
     "mi_conv_wgrad_workspace": (Z, [I] * 6),
     "mi_conv_wgrad_route": (I, [I] * 12),
     "mi_conv_wgrad": (I, [P, P, P] + [I] * 11 + [P, I, I, I, Z, P, Z, P]),
+    "mi_conv_wgrad_job_bytes": (Z, []),
+    "mi_conv_wgrad_partial": (I, [P, P, P] + [I] * 11 + [P, I, I, I, Z, P, Z, P, P]),
+    "mi_conv_wgrad_reduce": (I, [P, I, P]),
     "mi_aspp_pack_fwd": (I, [P, P, I, I, P]),
     "mi_aspp_pack_dgrad": (I, [P, P, I, I, P]),
     "mi_aspp_col2im": (I, [P, P, P, I, I, I, I, P, P]),

@@ -618,6 +618,71 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// The reducers of several weight gradients in ONE launch (mi_conv_wgrad_reduce: the three convs of a bottleneck, round 5).  Alone each reducer is a 10-us
+// launch of 33 MB that, on the weight-gradient stream beside the data-gradient chain, waits ~35 us for its turn on the CUs - three times per block, with the
+// next weight gradient queued behind it.  The jobs travel in the kernel arguments; a workgroup finds its job by the prefix sums of their grids and then runs
+// wgrad_reduce_kernel's body unchanged (same fixed order, same bits).
+constexpr int MI_REDUCE_MAX_JOBS = 4;
+struct WgradReduceJob {
+    const float* slab;
+    float* dw;
+    const float* scale;
+    int S, T, O, I, accumulate, out_map, ncls, gx, gy;       // gx * gy workgroups: (i blocks, output rows)
+};
+struct WgradReduceTable {
+    WgradReduceJob job[MI_REDUCE_MAX_JOBS];
+    int first[MI_REDUCE_MAX_JOBS + 1];
+    int n;
+};
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ slab, float* __restrict__ dw, const float* __restrict__ scale, int S, int T, int O, int I,
+                                                  int accumulate, int out_map, int ncls, int bx, int o, float* tile) {
+    const int IB = (T == 1) ? 256 : 64;
+    const int ib = bx * IB;
+    const long plane = (long)O * I;
+    const float sc = scale ? scale[o] : 1.f;
+    const int ni = min(IB, I - ib);
+    for (int item = threadIdx.x; item < T * IB; item += 256) {
+        const int t = item / IB, ii = item - t * IB;
+        float s = 0.f;
+        if (ii < ni) {
+            const float* src = slab + (long)t * plane + (long)o * I + ib + ii;
+            const long sstride = (long)T * plane;
+            int k = 0;
+            for (; k + 8 <= S; k += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[(long)(k + u) * sstride];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+            for (; k < S; ++k) s += src[(long)k * sstride];
+        }
+        tile[ii * T + t] = s * sc;
+    }
+    __syncthreads();
+    if (out_map == 0) {
+        float* dst = dw + ((long)o * I + ib) * T;
+        for (int e = threadIdx.x; e < ni * T; e += 256) dst[e] = accumulate ? dst[e] + tile[e] : tile[e];
+    } else {
+        const int grp = o / ncls, cls = o - grp * ncls;
+        const int r = grp / 9, tap = grp - r * 9;
+        for (int e = threadIdx.x; e < ni; e += 256) {
+            const long d = (((long)r * ncls + cls) * I + ib + e) * 9 + tap;
+            dw[d] = accumulate ? dw[d] + tile[e] : tile[e];
+        }
+    }
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WgradReduceTable tab) {
+    __shared__ float tile[9 * 64];
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < MI_REDUCE_MAX_JOBS; ++k) j += (k < tab.n && (int)blockIdx.x >= tab.first[k]) ? 1 : 0;
+    const WgradReduceJob q = tab.job[j];
+    const int local = (int)blockIdx.x - tab.first[j];
+    const int o = local / q.gx, bx = local - o * q.gx;
+    wgrad_reduce_body(q.slab, q.dw, q.scale, q.S, q.T, q.O, q.I, q.accumulate, q.out_map, q.ncls, bx, o, tile);
+}
+
 // =====================================================================================================================
 // 3x3 weight gradient with the three taps of a kernel row FUSED, wide-K ping-pong main loop (the dilated 3x3 family of
 // layer3 / layer4: reference core/components/resnet.py:22-25,100).
@@ -1199,9 +1264,22 @@ extern "C" int mi_conv_wgrad_route(int B, int Ha, int Wa, int I, int Ho, int Wo,
     return 0;
 }
 
-extern "C" int mi_conv_wgrad(const void* dy, const void* x, float* dw, int B, int Ha, int Wa, int I, int Ho, int Wo, int O,
-                             int ksize, int stride, int pad, int dil, const float* scale_o, int accumulate, int out_map, int ncls,
-                             size_t dw_elems, void* workspace, size_t workspace_bytes, void* stream) {
+// One reducer launch (defer == nullptr: right behind the main kernel, as always) or a job for mi_conv_wgrad_reduce (defer != nullptr)
+static int wgrad_finish(WgradReduceJob* defer, hipStream_t stream, const float* slab, float* dw, const float* scale, int S, int T, int O, int I, int accumulate,
+                        int out_map, int ncls, int o_real) {
+    const int gx = (I + (T == 1 ? 255 : 63)) / (T == 1 ? 256 : 64);
+    if (defer) {
+        *defer = WgradReduceJob{slab, dw, scale, S, T, O, I, accumulate, out_map, ncls, gx, o_real};
+        return MI_OK;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)gx, (unsigned)o_real), dim3(256), 0, stream, slab, dw, scale, S, T, O, I, accumulate, out_map, ncls);
+    MI_CHECK_LAUNCH("mi_conv_wgrad reduce");
+    return MI_OK;
+}
+
+static int mi_conv_wgrad_impl(const void* dy, const void* x, float* dw, int B, int Ha, int Wa, int I, int Ho, int Wo, int O,
+                              int ksize, int stride, int pad, int dil, const float* scale_o, int accumulate, int out_map, int ncls,
+                              size_t dw_elems, void* workspace, size_t workspace_bytes, void* stream, WgradReduceJob* defer) {
     MI_REQUIRE(dy && x && dw && workspace, "mi_conv_wgrad: null operand");
     MI_REQUIRE(B > 0 && Ha > 0 && Wa > 0 && Ho > 0 && Wo > 0, "mi_conv_wgrad: non-positive dimension");
     MI_REQUIRE(O % 8 == 0 && I % 8 == 0, "mi_conv_wgrad: O=%d, I=%d must be multiples of 8", O, I);
@@ -1239,10 +1317,7 @@ extern "C" int mi_conv_wgrad(const void* dy, const void* x, float* dw, int B, in
         if (p3_plan(B, Ho, Wo, O, I, dil, q3_mode == 2, pl, true) && (size_t)pl.S * 9 * O * I * sizeof(float) <= workspace_bytes) {
             launch_p3(dy, x, (float*)workspace, Ho, Wo, O, I, dil, pl, B * Ho, (hipStream_t)stream, true);
             MI_CHECK_LAUNCH("mi_conv_wgrad (fused 3x3 rows, 4 waves)");
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((I + 63) / 64), (unsigned)O), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dw,
-                               scale_o, pl.S, 9, O, I, accumulate, 0, 1);
-            MI_CHECK_LAUNCH("mi_conv_wgrad reduce");
-            return MI_OK;
+            return wgrad_finish(defer, (hipStream_t)stream, (const float*)workspace, dw, scale_o, pl.S, 9, O, I, accumulate, 0, 1, O);
         }
     }
     if (p3_mode && out_map == 0 && ksize == 3 && stride == 1 && Ha == Ho && Wa == Wo && pad == dil) {
@@ -1250,10 +1325,7 @@ extern "C" int mi_conv_wgrad(const void* dy, const void* x, float* dw, int B, in
         if (p3_plan(B, Ho, Wo, O, I, dil, p3_mode == 2, pl) && (size_t)pl.S * 9 * O * I * sizeof(float) <= workspace_bytes) {
             launch_p3(dy, x, (float*)workspace, Ho, Wo, O, I, dil, pl, B * Ho, (hipStream_t)stream);
             MI_CHECK_LAUNCH("mi_conv_wgrad (fused 3x3 rows)");
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((I + 63) / 64), (unsigned)O), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dw,
-                               scale_o, pl.S, 9, O, I, accumulate, 0, 1);
-            MI_CHECK_LAUNCH("mi_conv_wgrad reduce");
-            return MI_OK;
+            return wgrad_finish(defer, (hipStream_t)stream, (const float*)workspace, dw, scale_o, pl.S, 9, O, I, accumulate, 0, 1, O);
         }
     }
     WgradParams p;
@@ -1325,8 +1397,41 @@ extern "C" int mi_conv_wgrad(const void* dy, const void* x, float* dw, int B, in
     int o_real = O;
     if (out_map == 1) o_real = 36 * ncls;
     else ncls = 1;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((I + (p.T == 1 ? 255 : 63)) / (p.T == 1 ? 256 : 64)), (unsigned)o_real), dim3(256), 0, (hipStream_t)stream, p.slab, dw,
-                       scale_o, p.S, p.T, O, I, accumulate, out_map, ncls);
-    MI_CHECK_LAUNCH("mi_conv_wgrad reduce");
+    return wgrad_finish(defer, (hipStream_t)stream, p.slab, dw, scale_o, p.S, p.T, O, I, accumulate, out_map, ncls, o_real);
+}
+
+extern "C" int mi_conv_wgrad(const void* dy, const void* x, float* dw, int B, int Ha, int Wa, int I, int Ho, int Wo, int O,
+                             int ksize, int stride, int pad, int dil, const float* scale_o, int accumulate, int out_map, int ncls,
+                             size_t dw_elems, void* workspace, size_t workspace_bytes, void* stream) {
+    return mi_conv_wgrad_impl(dy, x, dw, B, Ha, Wa, I, Ho, Wo, O, ksize, stride, pad, dil, scale_o, accumulate, out_map, ncls, dw_elems, workspace, workspace_bytes,
+                              stream, nullptr);
+}
+
+// The same without the slab reducer: the split-K slabs stay in `workspace` (which must then outlive the call until mi_conv_wgrad_reduce has run) and the
+// reducer's arguments are written to `job` (mi_conv_wgrad_job_bytes() bytes of HOST memory).
+extern "C" size_t mi_conv_wgrad_job_bytes(void) { return sizeof(WgradReduceJob); }
+extern "C" int mi_conv_wgrad_partial(const void* dy, const void* x, float* dw, int B, int Ha, int Wa, int I, int Ho, int Wo, int O,
+                                     int ksize, int stride, int pad, int dil, const float* scale_o, int accumulate, int out_map, int ncls,
+                                     size_t dw_elems, void* workspace, size_t workspace_bytes, void* job, void* stream) {
+    MI_REQUIRE(job, "mi_conv_wgrad_partial: null job");
+    return mi_conv_wgrad_impl(dy, x, dw, B, Ha, Wa, I, Ho, Wo, O, ksize, stride, pad, dil, scale_o, accumulate, out_map, ncls, dw_elems, workspace, workspace_bytes,
+                              stream, (WgradReduceJob*)job);
+}
+// jobs: n consecutive job records written by mi_conv_wgrad_partial (n <= 4): their reducers as ONE launch, each summing its slabs in its fixed order
+extern "C" int mi_conv_wgrad_reduce(const void* jobs, int n, void* stream) {
+    MI_REQUIRE(jobs && n >= 1 && n <= MI_REDUCE_MAX_JOBS, "mi_conv_wgrad_reduce: 1 .. %d jobs", MI_REDUCE_MAX_JOBS);
+    WgradReduceTable tab;
+    tab.n = n;
+    int total = 0;
+    for (int j = 0; j < n; ++j) {
+        tab.job[j] = ((const WgradReduceJob*)jobs)[j];
+        MI_REQUIRE(tab.job[j].slab && tab.job[j].dw && tab.job[j].gx > 0 && tab.job[j].gy > 0, "mi_conv_wgrad_reduce: job %d is not a record of mi_conv_wgrad_partial", j);
+        tab.first[j] = total;
+        total += tab.job[j].gx * tab.job[j].gy;
+    }
+    for (int j = n; j <= MI_REDUCE_MAX_JOBS; ++j) tab.first[j] = total;
+    for (int j = n; j < MI_REDUCE_MAX_JOBS; ++j) tab.job[j] = tab.job[0];
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, tab);
+    MI_CHECK_LAUNCH("mi_conv_wgrad_reduce");
     return MI_OK;
 }

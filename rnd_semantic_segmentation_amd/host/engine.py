@@ -399,10 +399,10 @@ class StageEngine:
 
     # -- backward
     @staticmethod
-    def _wgrad(dy, xin, rt):
+    def _wgrad(dy, xin, rt, batch=None):
         c = rt.spec
         dw, acc = grad_slot(rt.weight)
-        K.conv_wgrad(dy, xin, dw, c.k, c.stride, c.pad, c.dil, scale=rt.scale, accumulate=acc)
+        K.conv_wgrad(dy, xin, dw, c.k, c.stride, c.pad, c.dil, scale=rt.scale, accumulate=acc, batch=batch)
 
     @staticmethod
     def _dgrad(dy, rt, in_hw, res=None, bits=None):
@@ -429,13 +429,17 @@ class StageEngine:
                 with torch.cuda.stream(side.stream) if side is not None else contextlib.nullcontext():
                     for hook in store.grad_hooks:         # the all-reduce of this range is ordered after its weight gradients
                         hook(store, lo, hi)
+        # MI_WGRAD_REDUCE_BATCH=1 (default): the slab reducers of a block's weight gradients run as ONE launch at the end of the block (K.WgradBatch)
+        # instead of one 10-us launch behind each weight gradient - on the side stream each of those waited ~35 us for its turn beside the data-gradient chain
+        batching = os.environ.get("MI_WGRAD_REDUCE_BATCH", "1") != "0" and not bwd_pair and K.PROFILE is None
         for bi in range(len(self.blocks) - 1, -1, -1):
             blk, rts = self.blocks[bi]
             x, a1, a2, xb, b1, b2 = saved[bi]
             first = bi == 0
             hw_in = (x.shape[1], x.shape[2])
             hw_mid = (a1.shape[1], a1.shape[2])
-            _off_path(side, lambda: self._wgrad(g, a2, rts[2]), g, a2)
+            wb = K.WgradBatch() if batching else None
+            _off_path(side, lambda: self._wgrad(g, a2, rts[2], wb), g, a2)
             if deferred is not None:                      # the previous block's W1 (and its hooks) ride beside this block's D3 / D2
                 dga1, dx_, drts = deferred
                 _off_path(side, lambda: self._wgrad(dga1, dx_, drts[0]), dga1, dx_)
@@ -445,14 +449,16 @@ class StageEngine:
                 ga2, ga2_ahead = ga2_ahead, None
             else:
                 ga2 = self._dgrad(g, rts[2], (a2.shape[1], a2.shape[2]), bits=b2)
-            _off_path(side, lambda: self._wgrad(ga2, a1, rts[1]), ga2, a1)
+            _off_path(side, lambda: self._wgrad(ga2, a1, rts[1], wb), ga2, a1)
             ga1 = self._dgrad(ga2, rts[1], hw_mid, bits=b1)
             if blk.down:
-                _off_path(side, lambda: self._wgrad(g, x, rts[3]), g, x)
+                _off_path(side, lambda: self._wgrad(g, x, rts[3], wb), g, x)
             if bwd_pair and not first:
                 deferred = (ga1, x, rts)
             else:
-                _off_path(side, lambda: self._wgrad(ga1, x, rts[0]), ga1, x)
+                _off_path(side, lambda: self._wgrad(ga1, x, rts[0], wb), ga1, x)
+            if wb is not None:
+                _off_path(side, wb.flush)
             pair = self._chain_pair(bi - 1) if chain and not first and not blk.down else None
             if first and not need_dx:
                 g = None

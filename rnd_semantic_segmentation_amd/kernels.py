@@ -238,9 +238,38 @@ def conv_chain(a, w_first, res, w_second, scale1=None, shift1=None, scale2=None,
     return (mid, out) if backward else (mid, out, bits1_out, bits2_out)
 
 
-def conv_wgrad(dy, x, dw, ksize=1, stride=1, pad=0, dil=1, scale=None, accumulate=False, out_map=0, ncls=0):
+class WgradBatch:
+    """The slab reducers of up to four weight gradients as ONE launch (mi_conv_wgrad_partial + mi_conv_wgrad_reduce): conv_wgrad(..., batch=b) runs the
+    main kernel only and keeps its split-K slabs in a workspace of its own; b.flush() (same stream, after the last of them) sums them all.  Same bits as
+    the one-call form.  A full batch flushes itself."""
+    MAX = 4
+
+    def __init__(self):
+        self._n = 0
+        self._size = int(_lib.lib().mi_conv_wgrad_job_bytes())
+        self._jobs = ctypes.create_string_buffer(self.MAX * self._size)
+        self._keep = []
+
+    def slot(self):
+        if self._n == self.MAX:
+            self.flush()
+        return self._n, ctypes.c_void_p(ctypes.addressof(self._jobs) + self._n * self._size)
+
+    def added(self, *tensors):
+        self._n += 1
+        self._keep.extend(tensors)
+
+    def flush(self):
+        if self._n:
+            check(_timed("wgrad_reduce_multi_kernel", 0.0, lambda: _lib.lib().mi_conv_wgrad_reduce(self._jobs, self._n, _stream()), tag=("wgrad_reduce", 1, 0, 0, 0, 0, 1)),
+                  "mi_conv_wgrad_reduce")
+            self._n, self._keep = 0, []
+
+
+def conv_wgrad(dy, x, dw, ksize=1, stride=1, pad=0, dil=1, scale=None, accumulate=False, out_map=0, ncls=0, batch=None):
     """dw[o,i,ky,kx] (+)= scale[o] * sum_m dy[m,o] x[src(m,t),i];  dy [B,Ho,Wo,O], x [B,Ha,Wa,I] bf16; dw fp32.
-    out_map=1 (ASPP): dy is the im2col matrix with 36*ncls live columns, dw the 4 stacked [ncls,I,3,3] gradients."""
+    out_map=1 (ASPP): dy is the im2col matrix with 36*ncls live columns, dw the 4 stacked [ncls,I,3,3] gradients.
+    batch (a WgradBatch): the slab reducer is deferred to batch.flush()."""
     _chk(dy, torch.bfloat16, "dy")
     _chk(x, torch.bfloat16, "x")
     _chk(dw, torch.float32, "dw")
@@ -257,6 +286,14 @@ def conv_wgrad(dy, x, dw, ksize=1, stride=1, pad=0, dil=1, scale=None, accumulat
     if PROFILE is not None:
         kern = ("wgrad_tn_kernel", "wgrad_tn256_kernel", "wgrad_p3_kernel", "wgrad_q3_kernel", "wgrad_s4_kernel")[
             L.mi_conv_wgrad_route(B, Ha, Wa, I, Ho, Wo, O, ksize, stride, pad, dil, out_map)] + "+reduce"
+    if batch is not None:
+        idx, job = batch.slot()
+        ws = _workspace(need, dy.device, "wgrad_b%d" % idx)             # its slabs must survive until the flush: one buffer per batch slot and stream
+        check(_timed(kern.replace("+reduce", ""), flops, lambda: L.mi_conv_wgrad_partial(
+            _p(dy), _p(x), _p(dw), B, Ha, Wa, I, Ho, Wo, O, ksize, stride, pad, dil, _p(scale),
+            int(accumulate), out_map, int(ncls), dw.numel(), _p(ws), ws.numel(), job, _stream()), tag=("wgrad", ksize, I, O, B * Ho * Wo, out_map, dil)), "mi_conv_wgrad_partial")
+        batch.added(ws, dw, scale)
+        return dw
     check(_timed(kern, flops, lambda: L.mi_conv_wgrad(
         _p(dy), _p(x), _p(dw), B, Ha, Wa, I, Ho, Wo, O, ksize, stride, pad, dil, _p(scale),
         int(accumulate), out_map, int(ncls), dw.numel(), _p(ws), ws.numel(), _stream()), tag=("wgrad", ksize, I, O, B * Ho * Wo, out_map, dil)), "mi_conv_wgrad")

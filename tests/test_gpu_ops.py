@@ -276,6 +276,38 @@ def test_wgrad_full_size_linearity_and_reproducibility():
     assert err < 1e-3 * out[2].abs().max().item()
 
 
+def test_batched_slab_reducers_equal_the_one_call_weight_gradients_bit_for_bit():
+    """K.WgradBatch (mi_conv_wgrad_partial x n + ONE mi_conv_wgrad_reduce launch: the three weight gradients of a bottleneck) against mi_conv_wgrad per
+    conv: every kernel route (fused-row 3x3, deep-stream 1x1, the 128 x 256 tile, the per-tap kernel with stride 2), FrozenBN scale, accumulation,
+    a fifth job (a full batch flushes itself) - the same fixed summation order, hence the same bits."""
+    g = torch.Generator(device="cpu").manual_seed(11)
+    r = lambda *shape: torch.randn(shape, generator=g).to(DEV).to(torch.bfloat16)
+    B, H, W = 2, 33, 29
+    cases = [   # (dy, x, k, stride, pad, dil)
+        (r(B, H, W, 64), r(B, H, W, 64), 3, 1, 2, 2),
+        (r(B, H, W, 256), r(B, H, W, 64), 1, 1, 0, 1),
+        (r(B, H, W, 512), r(B, H, W, 1024), 1, 1, 0, 1),
+        (r(B, 17, 15, 128), r(B, H, W, 64), 3, 2, 1, 1),
+        (r(B, H, W, 64), r(B, H, W, 256), 1, 1, 0, 1),
+    ]
+    scales = [torch.rand(c[0].shape[-1], generator=g).to(DEV) + 0.5 for c in cases]
+    want, got = [], []
+    for (dy, x, k, st, pd, dl), sc in zip(cases, scales):
+        O, I = dy.shape[-1], x.shape[-1]
+        base = torch.randn((O, I, k, k), generator=g).to(DEV)
+        w = base.clone()
+        K.conv_wgrad(dy, x, w, k, st, pd, dl, scale=sc, accumulate=True)
+        want.append(w)
+        got.append(base.clone())
+    batch = K.WgradBatch()
+    for (dy, x, k, st, pd, dl), sc, w in zip(cases, scales, got):
+        K.conv_wgrad(dy, x, w, k, st, pd, dl, scale=sc, accumulate=True, batch=batch)
+    batch.flush()
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), "job %d differs from the one-call weight gradient" % i
+
+
 # ------------------------------------------------------------------------------------------------ ASPP head chain
 def _aspp_forward(xd, w4, b4, rates=(6, 12, 18, 24)):
     B, H, W, C = xd.shape
