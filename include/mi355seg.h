@@ -133,7 +133,7 @@ int mi_conv_wgrad(const void* dy, const void* x, float* dw,
 
 /* mi_conv_wgrad in two parts (round 5): _partial runs the main kernel only - the split-K slabs stay in `workspace`, which the caller keeps alive and
  * untouched until the reduction - and writes the reducer's arguments to `job` (mi_conv_wgrad_job_bytes() bytes of host memory); mi_conv_wgrad_reduce runs
- * the reducers of up to 4 consecutive job records as ONE launch (the three weight gradients of a bottleneck: one launch instead of three on the
+ * the reducers of up to 8 consecutive job records as ONE launch (the three weight gradients of a bottleneck: one launch instead of three on the
  * weight-gradient stream).  Same fixed summation order per conv: the same bits as mi_conv_wgrad. */
 size_t mi_conv_wgrad_job_bytes(void);
 int mi_conv_wgrad_partial(const void* dy, const void* x, float* dw,

@@ -622,7 +622,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // launch of 33 MB that, on the weight-gradient stream beside the data-gradient chain, waits ~35 us for its turn on the CUs - three times per block, with the
 // next weight gradient queued behind it.  The jobs travel in the kernel arguments; a workgroup finds its job by the prefix sums of their grids and then runs
 // wgrad_reduce_kernel's body unchanged (same fixed order, same bits).
-constexpr int MI_REDUCE_MAX_JOBS = 4;
+constexpr int MI_REDUCE_MAX_JOBS = 8;
 struct WgradReduceJob {
     const float* slab;
     float* dw;
@@ -1417,7 +1417,7 @@ extern "C" int mi_conv_wgrad_partial(const void* dy, const void* x, float* dw, i
     return mi_conv_wgrad_impl(dy, x, dw, B, Ha, Wa, I, Ho, Wo, O, ksize, stride, pad, dil, scale_o, accumulate, out_map, ncls, dw_elems, workspace, workspace_bytes,
                               stream, (WgradReduceJob*)job);
 }
-// jobs: n consecutive job records written by mi_conv_wgrad_partial (n <= 4): their reducers as ONE launch, each summing its slabs in its fixed order
+// jobs: n consecutive job records written by mi_conv_wgrad_partial (n <= 8): their reducers as ONE launch, each summing its slabs in its fixed order
 extern "C" int mi_conv_wgrad_reduce(const void* jobs, int n, void* stream) {
     MI_REQUIRE(jobs && n >= 1 && n <= MI_REDUCE_MAX_JOBS, "mi_conv_wgrad_reduce: 1 .. %d jobs", MI_REDUCE_MAX_JOBS);
     WgradReduceTable tab;

@@ -107,7 +107,7 @@ class _SideStream:
     _by_device = {}
 
     def __init__(self, device):
-        self.stream = torch.cuda.Stream(device=device)
+        self.stream = torch.cuda.Stream(device=device)          # (high priority for it measured 288.4 vs 290.7 images/s: profiles/r05_wgrad_sched_ab.txt)
         self.dirty = False
 
     @classmethod
@@ -432,6 +432,8 @@ class StageEngine:
         # MI_WGRAD_REDUCE_BATCH=1 (default): the slab reducers of a block's weight gradients run as ONE launch at the end of the block (K.WgradBatch)
         # instead of one 10-us launch behind each weight gradient - on the side stream each of those waited ~35 us for its turn beside the data-gradient chain
         batching = os.environ.get("MI_WGRAD_REDUCE_BATCH", "1") != "0" and not bwd_pair and K.PROFILE is None
+        # (Tried, profiles/r05_wgrad_sched_ab.txt: the block's three weight gradients on two / three streams - 281 / 280 images/s against 297 on one, the
+        #  streams' workgroups evict each other's L2 lines; reducers batched over two blocks - 298.4 against 297.5, inside the noise.  Neither is kept.)
         for bi in range(len(self.blocks) - 1, -1, -1):
             blk, rts = self.blocks[bi]
             x, a1, a2, xb, b1, b2 = saved[bi]

@@ -239,10 +239,10 @@ def conv_chain(a, w_first, res, w_second, scale1=None, shift1=None, scale2=None,
 
 
 class WgradBatch:
-    """The slab reducers of up to four weight gradients as ONE launch (mi_conv_wgrad_partial + mi_conv_wgrad_reduce): conv_wgrad(..., batch=b) runs the
+    """The slab reducers of up to eight weight gradients as ONE launch (mi_conv_wgrad_partial + mi_conv_wgrad_reduce): conv_wgrad(..., batch=b) runs the
     main kernel only and keeps its split-K slabs in a workspace of its own; b.flush() (same stream, after the last of them) sums them all.  Same bits as
     the one-call form.  A full batch flushes itself."""
-    MAX = 4
+    MAX = 8
 
     def __init__(self):
         self._n = 0
