@@ -517,12 +517,15 @@ class StageEngine:
         store = getattr(self.convs[0].weight, "_mi_store", None)
         side = _SideStream.get(dfeat.device)
 
+        batching = os.environ.get("MI_WGRAD_REDUCE_BATCH", "1") != "0" and K.PROFILE is None
+        wb = [None]                                   # the block's slab reducers as one launch (K.WgradBatch), as in backward()
+
         def wgrad(dy, xin, rt):
             c = rt.spec
 
             def go():
                 dw, acc = grad_slot(rt.weight)
-                K.conv_wgrad(dy, xin, dw, c.k, c.stride, c.pad, c.dil, accumulate=acc)
+                K.conv_wgrad(dy, xin, dw, c.k, c.stride, c.pad, c.dil, accumulate=acc, batch=wb[0])
             _off_path(side, go, dy, xin)
 
         for bi in range(len(self.blocks) - 1, -1, -1):
@@ -530,6 +533,7 @@ class StageEngine:
             x, xb, (u1, u2, u3, ud) = saved[bi]
             first = bi == 0
             hw_in = (x.shape[1], x.shape[2])
+            wb[0] = K.WgradBatch() if batching else None
             dy3 = bn_backward(g, u3[1], u3[2], u3[3], rts[2].bn)
             wgrad(dy3, u2[0], rts[2])
             ga2 = self._dgrad(dy3, rts[2], (u2[0].shape[1], u2[0].shape[2]))
@@ -548,6 +552,8 @@ class StageEngine:
                 skip = self._dgrad(dyd, rts[3], hw_in) if blk.down else g
                 g = self._dgrad(dy1, rts[0], hw_in, res=skip, bits=None if first else xb)
             saved[bi] = None
+            if wb[0] is not None:
+                _off_path(side, wb[0].flush)
             if store is not None and store.grad_hooks:
                 lo, hi = store.span([p for rt in rts for p in (rt.weight, rt.bn.weight, rt.bn.bias)])
                 with torch.cuda.stream(side.stream) if side is not None else contextlib.nullcontext():
