@@ -37,4 +37,4 @@ run gald $root/bench.py --workload gald --steps 10 --warmup 3 --no-cpu-baseline 
 run deeplab_bn $root/bench.py --workload deeplab_bn --steps 10 --warmup 4 --no-cpu-baseline --no-kernel-events
 run fada $root/bench.py --workload fada --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-events
 run infer $root/tools/infer_bench.py
-tail -3 $root/gpurun_out/${tag}_fada.log $root/gpurun_out/${tag}_infer.log
+tail -n 3 $root/gpurun_out/${tag}_fada.log $root/gpurun_out/${tag}_infer.log
