@@ -73,7 +73,7 @@ int mi_pack_weights_multi(const float* wflat, const float* sflat, void* wp_bf16,
  * the fused epilogue, the FrozenBN / ReLU / residual that follow it (resnet.py:93-113).
  *   out[b][ho][wo][n] = epi( sum_{t,c} a[b][src_h(ho,t)][src_w(wo,t)][c] * wp[t][n][c] )
  * a: [B][Ha][Wa][Ca] bf16, wp: [k*k][N][Ca] bf16, out: [B][Ho][Wo][N] bf16 (or fp32).
- * Requirements: Ca % 64 == 0, N % 8 == 0, 16-byte aligned pointers; N % 16 == 0 with MI_EPI_BITMASK / MI_EPI_WRITE_MASK
+ * Requirements: Ca % 32 == 0 (Ca % 64 != 0: stride-1 / same-size launches without a residual or mask tile only - the 32-channel main loop), N % 8 == 0, 16-byte aligned pointers; N % 16 == 0 with MI_EPI_BITMASK / MI_EPI_WRITE_MASK
  * (one uint16 of sign bits per 16 channels), and when N % 128 == 0 those packed-bit tensors must be 16-byte aligned too
  * (a tile row's 16 mask bytes move as one access).  Violations return MI_EINVAL. */
 int mi_conv_gemm(const void* a, const void* wp, void* out,

@@ -29,6 +29,11 @@ const MiSwitches& mi_sw() {
         sw.igemm_bn = env("MI_IGEMM_BN", 0);
         sw.igemm_pref = env("MI_IGEMM_PREF", 1);
         sw.pp_korder = env("MI_IGEMM_PP_KORDER", 1);
+#ifdef MI_EXPERIMENTS
+        sw.pp_loop = env("MI_IGEMM_PP_LOOP", 0);
+#else
+        sw.pp_loop = 0;
+#endif
         sw.igemm_pw = env("MI_IGEMM_PW", 0);
         sw.wgrad_s4_slots = env("MI_WGRAD_S4_SLOTS", 512);
         if (sw.wgrad_s4_slots < 64) sw.wgrad_s4_slots = 512;

@@ -387,7 +387,12 @@ int mi_conv_gemm_impl(const void* a, const void* wp, void* out, int B, int Ha, i
     MI_REQUIRE(a && wp && out, "mi_conv_gemm: null operand");
     MI_REQUIRE(((flags & MI_EPI_STATS) != 0) == (st != nullptr) && (!st || flags == MI_EPI_STATS), "mi_conv_gemm: MI_EPI_STATS comes alone, through mi_conv_gemm_stats");
     MI_REQUIRE(B > 0 && Ha > 0 && Wa > 0 && Ho > 0 && Wo > 0 && N > 0, "mi_conv_gemm: non-positive dimension");
-    MI_REQUIRE(Ca > 0 && Ca % 64 == 0, "mi_conv_gemm: Ca=%d must be a multiple of 64", Ca);
+    // Ca % 64 == 0: either main loop.  Ca % 32 == 0 only (the 32-padded operands of the general family's packs: HarDNet's 466 -> 480 channel
+    // gathers): the 32-channel slabs of igemm_pp_kernel take it, whatever the dispatch rule says - stride-1 / same-size launches without a residual tile
+    const bool pp_only = Ca > 0 && Ca % 64 != 0;
+    MI_REQUIRE(Ca > 0 && Ca % 32 == 0, "mi_conv_gemm: Ca=%d must be a multiple of 32", Ca);
+    MI_REQUIRE(!pp_only || (stride == 1 && Ha == Ho && Wa == Wo && !(flags & (MI_EPI_RESIDUAL | MI_EPI_MASK | MI_EPI_LEAKY))),
+               "mi_conv_gemm: Ca=%d is not a multiple of 64: stride-1, same-size launches without residual / mask / LeakyReLU only", Ca);
     MI_REQUIRE(N % 8 == 0, "mi_conv_gemm: N=%d must be a multiple of 8", N);
     MI_REQUIRE(ksize == 1 || ksize == 3, "mi_conv_gemm: ksize=%d (1 or 3)", ksize);
     MI_REQUIRE(stride >= 1 && dil >= 1 && pad >= 0, "mi_conv_gemm: bad stride/dil/pad");
@@ -411,6 +416,13 @@ int mi_conv_gemm_impl(const void* a, const void* wp, void* out, int B, int Ha, i
     // L2 bytes per kFLOP.  Measured per shape against this kernel in one process (tools/ppexp.py, B = 8, 97 x 97): 3x3 256 +16 %,
     // 3x3 512 +13 %, 1x1 2048->512 +18 %, 1x1 1024->256 / 1024->2048 / ASPP forward +6 %; the short contractions (K < 512)
     // are epilogue-bound and stay here.  MI_IGEMM_PP=0 switches the dispatch off.
+    if (pp_only) {
+        MI_REQUIRE((long)B * Ha * Wa * Ca * 2 + 2L * ((long)(ksize - 1) * dil + pad) * (Wa + 1) * Ca * 2 < (1L << 31) - (1L << 20) &&
+                       (long)ksize * ksize * N * Ca * 2 < (1L << 31) - (1L << 20),
+                   "mi_conv_gemm: Ca=%d is not a multiple of 64 and the operands exceed the 2 GiB the 32-channel main loop addresses", Ca);
+        return mi_conv_gemm_pp_impl(a, wp, out, B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, pad, dil, gather_mode, scale, bias, res, msk, mask_out, flags, zgw,
+                                    alpha, 0, stream, st);
+    }
     if (mi_conv_gemm_route(B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, flags) &&
         (long)B * Ha * Wa * Ca * 2 + 2L * ((long)(ksize - 1) * dil + pad) * (Wa + 1) * Ca * 2 < (1L << 31) - (1L << 20))     // its exact 32-bit offset bound
         return mi_conv_gemm_pp_impl(a, wp, out, B, Ha, Wa, Ca, Ho, Wo, N, ksize, stride, pad, dil, gather_mode, scale, bias, res, msk, mask_out, flags, zgw,

@@ -21,6 +21,14 @@
 //   after B_2p+2 the slab is visible to group 0 and after B_2p+3 to group 1;
 //   slab p+3 lands in the slot of slab p-1, whose last reader (G1 in I_2p-1) finished its ds_reads (lgkmcnt(0)) before B_2p.
 // (Tried and dropped: issuing a slab's DMA pieces inside the MFMA segment instead of the read segment - see PP_DMA_SEG below.)
+// RR (template parameter; round 5, experiment builds only): the "rolling" main loop.  No groups and no hand-over: BOTH waves of a SIMD stream MFMAs all the
+//   time, each wave software-pipelines its own fragment reads - the A fragment of the row tile four ahead goes into a five-slot register ring (20 VGPRs
+//   instead of 40), the next slab's four W fragments into a second set right behind the slab's one barrier (which sits in the middle of the slab: own DMA
+//   pieces of slab s+1 landed -> barrier -> issue the pieces of slab s+3, read slab s+1).  229 VGPRs, no spills, the waits are the compiler's counted
+//   lgkmcnt.  Same tile, same LDS image, same order of the fp32 sums: bit-equal outputs.  Measured (tools/rrexp.py, profiles/r05_pp_rolling_loop_ab.txt):
+//   3x3 256 85.4 vs 82.0 us (main loop alone 70.3 vs 69.4), 3x3 512 287.5 vs 278.9, 1x1 2048 -> 512 164 vs 152; the training step 291.5 vs 296.5 images/s.
+//   The loop was not waiting for the hand-over: at 1.28 PFLOP/s on random operands it runs at the clock the chip allows under this load
+//   (MI355X_MICROARCH.md "DVFS give-back": cycles saved in an MFMA-dense loop return as a lower clock), so a denser issue stream buys nothing.
 // LDS image of a slab: A rows then W rows, 64 B (32 channels) per row, lane-linear per 1-KiB DMA piece (16 rows); the 16-B chunk
 // c of row r sits at chunk c ^ s(r), applied to the per-lane SOURCE address and to the ds_read_b128 address, with
 // s_A(r) = (-(r >> 2)) & 3 and s_W(r) = ((r >> 3) & 1) << 1: both make every ds_read_b128 lane group hit 64 distinct banks
@@ -62,7 +70,7 @@ __device__ unsigned g_pp_clock[4];
 #define PP_T(k)
 #endif
 
-template <int MTG, int EPI>
+template <int MTG, int EPI, bool RR = false>
 __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmParams p) {
     using G = PPGeo<MTG>;
     constexpr int BM = G::BM, BN = G::BN, BMG = G::BMG, SLAB = G::SLAB, SLAB_A = G::SLAB_A, NPA = G::NPA, NPW = G::NPW;
@@ -239,6 +247,63 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmParams p) {
         advance_slab();
     };
 
+    if constexpr (RR) {
+        // ---- rolling main loop (round 5; the header's "RR" paragraph) ------------------------------------------------------------
+        constexpr int RING = (MTG % 5 == 0) ? 5 : 4, LEAD = RING - 1, BR = MTG - NPMAX;
+        static_assert(MTG % RING == 0 && BR >= 0 && BR <= MTG - LEAD && MTG >= 4, "rolling loop: ring / barrier row do not fit this tile height");
+        for (int s = 0; s < 3 && s < ns; ++s) stage_next();
+        if (ns >= 3) {
+            if (grp == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        bf16x8 wr[2][4], ar[RING];
+        auto ld_w = [&](int slab, int i) { return *reinterpret_cast<const bf16x8*>(smem + (slab & 3) * SLAB + w_off + (32 * (i >> 1) + 4 * (i & 1)) * 64); };
+        auto ld_a = [&](int slab, int j) { return *reinterpret_cast<const bf16x8*>(smem + (slab & 3) * SLAB + a_off + j * 1024); };
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wr[0][i] = ld_w(0, i);
+#pragma unroll
+        for (int j = 0; j < LEAD; ++j) ar[j] = ld_a(0, j);
+        __builtin_amdgcn_sched_barrier(0);
+        auto slab_body = [&](auto par, int s) {
+            constexpr int P = decltype(par)::value;
+            char* dst = nullptr;
+#pragma unroll
+            for (int j = 0; j < MTG; ++j) {
+                if (j == BR) {
+                    // every wave's pieces of slab s+1 have landed (its pieces of slab s+2 may be in flight); after the barrier slab s+1 is readable by
+                    // everyone, and slab s-1 - whose last fragment was read MTG rows ago - gives its slot to slab s+3
+                    if (grp == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPA) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+                    __builtin_amdgcn_s_barrier();
+                    piece_sources();
+                    dst = smem + (ld_s & 3) * SLAB + (grp == 0 ? wq * (NPA * 1024) : SLAB_A + wq * (NPW * 1024));
+                }
+                // fragment LEAD rows ahead, into the ring slot the previous row's MFMAs have just released
+                ar[(j + LEAD) % RING] = (j + LEAD < MTG) ? ld_a(s, j + LEAD) : ld_a(s + 1, j + LEAD - MTG);
+                if (j == BR || j == BR + 1) {          // the next slab's weight fragments, right behind the barrier: three rows or more before their first use
+                    wr[P ^ 1][2 * (j - BR)] = ld_w(s + 1, 2 * (j - BR));
+                    wr[P ^ 1][2 * (j - BR) + 1] = ld_w(s + 1, 2 * (j - BR) + 1);
+                }
+                if (j >= BR && j - BR < NPMAX) {
+                    const int i = j - BR;
+                    if (i < NPMIN || (NPA > NPW ? grp == 0 : grp == 1)) blds16(rsrc, src[i], src_soff, dst + i * 1024);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[P][i], ar[j % RING], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            advance_slab();
+        };
+        int s = 0;
+        for (; s + 1 < ns; s += 2) {
+            slab_body(std::integral_constant<int, 0>{}, s);
+            slab_body(std::integral_constant<int, 1>{}, s + 1);
+        }
+        if (s < ns) slab_body(std::integral_constant<int, 0>{}, s);
+    } else {
     // ---- prologue: three slabs in flight, slab 0 landed -------------------------------------------------------------------------
     for (int s = 0; s < 3 && s < ns; ++s) stage_next();
     if (ns >= 3) {
@@ -310,6 +375,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmParams p) {
     }
 #endif
     if (grp == 0) __builtin_amdgcn_s_barrier();                     // group 0 leaves one interval early: keep the barrier counts equal
+    }   // ping-pong loop
 
     if (EPI < 0 && (p.flags & (1 << 30))) {   // perf experiment: main loop only (keeps the accumulators alive, stores nothing)
 #pragma unroll
@@ -546,10 +612,10 @@ void launch_pw(dim3 grid, hipStream_t stream, const IgemmParams& p) {
 }
 #endif  // MI_EXPERIMENTS
 
-template <int MTG, int EPI>
+template <int MTG, int EPI, bool RR>
 void launch_pp(dim3 grid, hipStream_t stream, const IgemmParams& p) {
     static std::atomic<uint64_t> attr_done{0};
-    auto kern = igemm_pp_kernel<MTG, EPI>;
+    auto kern = igemm_pp_kernel<MTG, EPI, RR>;
 #ifdef MI_PP_TRACE
     constexpr int lds = PPGeo<MTG>::LDS_BYTES + 2 * PP_TRACE_STEPS * PP_TRACE_PTS * 4;
 #else
@@ -559,15 +625,15 @@ void launch_pp(dim3 grid, hipStream_t stream, const IgemmParams& p) {
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p);
 }
 
-template <int MTG>
+template <int MTG, bool RR>
 void launch_pp_flags(dim3 grid, hipStream_t stream, const IgemmParams& p) {
-    if (p.flags == 69) return launch_pp<MTG, 69>(grid, stream, p);       // FrozenBN + ReLU + sign bits (conv forward)
-    if (p.flags == 128) return launch_pp<MTG, 128>(grid, stream, p);     // ReLU backward from sign bits (data gradient)
-    if (p.flags == 0) return launch_pp<MTG, 0>(grid, stream, p);         // plain bf16 store (downsample data gradient, ASPP data gradient)
-    if (p.flags == 1) return launch_pp<MTG, 1>(grid, stream, p);         // FrozenBN only (downsample forward)
-    if (p.flags == 48) return launch_pp<MTG, 48>(grid, stream, p);       // fp32 tap planes (ASPP forward)
-    if (p.flags == MI_EPI_STATS) return launch_pp<MTG, MI_EPI_STATS>(grid, stream, p);      // plain store + BatchNorm tile statistics
-    launch_pp<MTG, -1>(grid, stream, p);
+    if (p.flags == 69) return launch_pp<MTG, 69, RR>(grid, stream, p);       // FrozenBN + ReLU + sign bits (conv forward)
+    if (p.flags == 128) return launch_pp<MTG, 128, RR>(grid, stream, p);     // ReLU backward from sign bits (data gradient)
+    if (p.flags == 0) return launch_pp<MTG, 0, RR>(grid, stream, p);         // plain bf16 store (downsample data gradient, ASPP data gradient)
+    if (p.flags == 1) return launch_pp<MTG, 1, RR>(grid, stream, p);         // FrozenBN only (downsample forward)
+    if (p.flags == 48) return launch_pp<MTG, 48, RR>(grid, stream, p);       // fp32 tap planes (ASPP forward)
+    if (p.flags == MI_EPI_STATS) return launch_pp<MTG, MI_EPI_STATS, RR>(grid, stream, p);      // plain store + BatchNorm tile statistics
+    launch_pp<MTG, -1, RR>(grid, stream, p);
 }
 
 }  // namespace
@@ -666,6 +732,9 @@ int mi_conv_gemm_pp_impl(const void* a, const void* wp, void* out, int B, int Ha
         const long w_bytes = (long)ksize * ksize * N * Ca * 2;
         MI_REQUIRE(a_bytes < (1L << 31) - (1L << 20) && w_bytes < (1L << 31) - (1L << 20), "mi_conv_gemm_pp: operand larger than 2 GiB");
     }
+    bool rolling = mi_sw().pp_loop != 0;   // MI_IGEMM_PP_LOOP (read in experiment builds only); an explicit mtg of 108 / 110 (8 / 10) selects the rolling (ping-pong) loop
+    if (mtg == 108 || mtg == 110) rolling = true, mtg -= 100;
+    else if (mtg == 8 || mtg == 10) rolling = false;
     if (mtg != 8 && mtg != 10) {           // fewest rounds on 256 CUs, then the least padding
         auto rounds = [&](int bm) { return (((M + bm - 1) / bm) * ((N + 255) / 256) + 255) / 256; };
         mtg = rounds(320) < rounds(256) ? 10 : (rounds(256) < rounds(320) ? 8 : (((M + 319) / 320) * 320 <= ((M + 255) / 256) * 256 ? 10 : 8));
@@ -675,8 +744,18 @@ int mi_conv_gemm_pp_impl(const void* a, const void* wp, void* out, int B, int Ha
     p.n_tiles = (N + 255) / 256;
     const dim3 grid(p.m_tiles * p.n_tiles);
     if (st) st->nparts = 2 * p.m_tiles;                    // one partial row per wave group (MTG*16 rows)
-    if (mtg == 10) launch_pp_flags<10>(grid, (hipStream_t)stream, p);
-    else launch_pp_flags<8>(grid, (hipStream_t)stream, p);
+#ifdef MI_EXPERIMENTS      // the rolling loop does not win (header): experiment builds only (tools/experiments/build.sh, tools/rrexp.py)
+    if (rolling) {
+        if (mtg == 10) launch_pp_flags<10, true>(grid, (hipStream_t)stream, p);
+        else launch_pp_flags<8, true>(grid, (hipStream_t)stream, p);
+        MI_CHECK_LAUNCH("mi_conv_gemm_pp (rolling loop)");
+        return MI_OK;
+    }
+#else
+    if (rolling) return mi_set_error(MI_EINVAL, "mi_conv_gemm_pp: the rolling main loop (mtg 108 / 110, MI_IGEMM_PP_LOOP=1) exists in experiment builds only");
+#endif
+    if (mtg == 10) launch_pp_flags<10, false>(grid, (hipStream_t)stream, p);
+    else launch_pp_flags<8, false>(grid, (hipStream_t)stream, p);
     MI_CHECK_LAUNCH("mi_conv_gemm_pp");
     return MI_OK;
 }

@@ -28,6 +28,7 @@ struct MiSwitches {
     int igemm_bn;          // MI_IGEMM_BN         0: 128-wide tiles (256: the experiment tile, builds with -DMI_EXPERIMENTS only)
     int igemm_pref;        // MI_IGEMM_PREF       1: epilogue operands prefetched before the main loop
     int pp_korder;         // MI_IGEMM_PP_KORDER  1: channel-chunk-major contraction of a 3x3 (0: tap-major, bit-equal to igemm_nt)
+    int pp_loop;           // MI_IGEMM_PP_LOOP    0: two-group ping-pong main loop, 1: rolling fragment ring (both waves of a SIMD stream MFMAs)
     int igemm_pw;          // MI_IGEMM_PW         0: shared-window 3x3 kernel off (-DMI_EXPERIMENTS builds only)
     int wgrad_s4_slots;    // MI_WGRAD_S4_SLOTS   512: workgroup slots the 1x1 weight-gradient split picker plans for
     int wgrad_ti256;       // MI_WGRAD_TI256      -1: 128 x 256 weight-gradient tile by rule (0 never, 1 always)

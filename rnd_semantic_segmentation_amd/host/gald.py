@@ -26,7 +26,7 @@ from .. import kernels as K
 from . import arch
 from .metrics import AverageMeter, adjust_learning_rate, confusion_matrix, dump_json, intersectionAndUnionGPU
 from .plugin import BaseTrainer
-from .pranet import FlatAdam, _acc, _Engine, _grad_target, _Run, _Unit
+from .pranet import FlatAdam, _acc, _Engine, _grad_target, _Run, _rup32, _tile_route, _Unit
 
 
 class _GaldRun(_Run):
@@ -215,7 +215,12 @@ def _hard_block(run, x, layers, links, out_ch):
     for li, (u, lk) in enumerate(zip(layers, links), 1):
         if len(lk) > 1:
             cin = sum(outs[j].t.shape[-1] for j in lk)
-            buf = gk.new(B, H, W, cin, x.t.device, x.t.dtype)
+            # a layer the MFMA-tile kernels take (pranet._tile_route: the big gathered layers, 466 -> 168 ...) reads a gather buffer of the 32-padded
+            # channel count, pad channels zero: the kernels' operand as it is
+            cbuf = _rup32(cin) if (not run.f32 and _tile_route(u, B * H * W)) else cin
+            buf = gk.new(B, H, W, cbuf, x.t.device, x.t.dtype)
+            if cbuf != cin:
+                buf[..., cin:].zero_()
             pieces, o = [], 0
             for j in lk:
                 c = outs[j].t.shape[-1]

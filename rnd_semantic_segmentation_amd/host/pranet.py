@@ -137,31 +137,51 @@ def _acc(v, t, own):
         v.g, v.own = gk.gbinary(gk.OP_ADD, v.g, t), True
 
 
-def _mfma_tile_ok(u, x, out=None, out_f32=False):
-    """A conv the implicit-GEMM kernels of the DeepLab path (csrc/igemm_nt.hip / igemm_pp.hip / igemm_tn.hip: 128 .. 320-row MFMA tiles, LDS-DMA
-    staging, 4x the throughput of the general kernel on large shapes) can take: square 1x1 / 3x3 taps with one stride / padding / dilation,
-    64-channel multiples on both sides (then the general kernel's padded packs ARE those kernels' operand layouts), contiguous NHWC operands,
-    enough pixels to fill the chip."""
+def _rup32(c):
+    return (c + 31) // 32 * 32
+
+
+def _tile_route(u, pixels):
+    """Geometry half of _mfma_tile_ok: a conv whose shape the implicit-GEMM kernels of the DeepLab path can take (csrc/igemm_nt.hip / igemm_pp.hip /
+    igemm_tn.hip: 128 .. 320-row MFMA tiles, LDS-DMA staging, 4x the throughput of the general kernel on large shapes): square 1x1 / 3x3 taps with one
+    stride / padding / dilation, enough pixels to fill the chip, and channel counts that are either 64-multiples on both sides or - stride 1 - pad to
+    32-multiples with less than 1.6x the work (HarDNet's gathered layers, 466 -> 168 as 480 -> 192: the general kernel's packs are zero-padded to 32 on
+    both sides, i.e. they ARE the [taps][N][Ca] operands of those kernels for the padded shape; round 5)."""
     kh, kw, sh, sw, ph, pw, dh, dw = u.geom
-    if out_f32 or u.depthwise or kh != kw or kh not in (1, 3) or sh != sw or ph != pw or dh != dw or u.cin % 64 or u.cout % 64:
+    if u.depthwise or kh != kw or kh not in (1, 3) or sh != sw or ph != pw or dh != dw or pixels < 16384:
         return False
-    if not x.is_contiguous() or (out is not None and not out.is_contiguous()):
+    if u.cin % 64 == 0 and u.cout % 64 == 0:
+        return True
+    ci, co = _rup32(u.cin), _rup32(u.cout)
+    work = 2.0 * pixels * u.cin * u.cout * kh * kw              # the small ones stay where they are: nothing to win on a 5 GFLOP launch
+    return sh == 1 and 2 * ph == dh * (kh - 1) and work >= 8e9 and ci * co < 1.6 * u.cin * u.cout and os.environ.get("MI_TILE_PAD", "1") != "0"
+
+
+def _mfma_tile_ok(u, x, out=None, out_f32=False):
+    """The conv goes to the MFMA-tile kernels: _tile_route() and an input that IS the kernels' operand - a contiguous NHWC tensor of the 32-padded channel
+    count (64-multiples: the tensor itself; otherwise a gather buffer its producer allocated padded, pad channels zero: gald._hard_block)."""
+    if out_f32 or not _tile_route(u, x.shape[0] * x.shape[1] * x.shape[2]) or x.shape[-1] != _rup32(u.cin):
         return False
-    return x.shape[0] * x.shape[1] * x.shape[2] >= 16384
+    return x.is_contiguous() and (out is None or (out.is_contiguous() and out.shape[-1] == _rup32(u.cout)))
 
 
 def _conv_forward(x, u, bias, stats, out=None, out_f32=False, net=None):
     """(y, statistics partials or None): the general kernel, or the MFMA-tile kernels with the BatchNorm sums out of their epilogue (mi_conv_gemm_stats;
-    one extra pass of column sums where a bias or a slot output rules that entry out)."""
+    one extra pass of column sums where a bias or a slot output rules that entry out).  With padded channel counts y is the [.., :cout] view of the
+    kernels' 32-padded output (pad columns: products with the pack's zero rows)."""
     if not _mfma_tile_ok(u, x, out, out_f32):
         return gk.gconv(x, u.wp, u.cout, u.geom, out=out, bias=bias, stats=stats, out_f32=out_f32)
     k, s, p, d = u.geom[0], u.geom[2], u.geom[4], u.geom[6]
     hw = gk.conv_out_hw(x.shape[1], x.shape[2], *u.geom)
-    wp = u.wp.view(k * k, u.cout, u.cin)
+    np_, cp = _rup32(u.cout), _rup32(u.cin)
+    wp = u.wp.view(k * k, np_, cp)
+    cut = (lambda t: t) if np_ == u.cout else (lambda t: t[..., :u.cout])
     if stats and bias is None and out is None:          # sum y and sum y^2 out of the conv's own epilogue (pilot 0: raw sums)
-        y, sums, _ = K.conv_gemm_stats(x, wp, hw, k, s, p, d, net._zeros(u.cout))
-        return y, sums.view(-1)
-    y = K.conv_gemm(x, wp, hw, k, s, p, d, K.GATHER_FWD, scale=None if bias is None else net._ones(u.cout), bias=bias, out=out)
+        y, sums, _ = K.conv_gemm_stats(x, wp, hw, k, s, p, d, net._zeros(np_))
+        return cut(y), (sums if np_ == u.cout else sums[:, :u.cout].contiguous()).view(-1)
+    if bias is not None and np_ != u.cout:
+        bias = torch.cat([bias, bias.new_zeros(np_ - u.cout)])
+    y = cut(K.conv_gemm(x, wp, hw, k, s, p, d, K.GATHER_FWD, scale=None if bias is None else net._ones(np_), bias=bias, out=out))
     st = None
     if stats:                       # sum y and sum y^2 in one pass: the backward-sums kernel with g = y, mean = 0, invstd = 1
         st = torch.empty((2, u.cout), dtype=torch.float32, device=x.device)
@@ -273,11 +293,16 @@ class _Run:
                 gk.gbn_bwd_sums(g, y, mask, fin[0], fin[1], db1, dg1, relu6=act == 2)
             else:
                 db1, dg1 = dbeta, dgamma
-            dy = gk.gbn_bwd_apply(g, y, mask, fin[0], fin[1], bn.weight, db1, dg1, M, relu6=act == 2)
+            dyp = None
+            if u.cout % 32 and _mfma_tile_ok(u, x.t):
+                # the MFMA-tile kernels contract over the 32-padded channel count: d loss / d y goes into the real columns of a padded tensor, pads zero
+                dyp = gk.new(y.shape[0], y.shape[1], y.shape[2], _rup32(u.cout), y.device)
+                dyp[..., u.cout:].zero_()
+            dy = gk.gbn_bwd_apply(g, y, mask, fin[0], fin[1], bn.weight, db1, dg1, M, out=None if dyp is None else dyp[..., :u.cout], relu6=act == 2)
             if u.bias is not None:
                 slot, acc = net._grad_slot(u.bias)
                 gk.gbn_bwd_sums(dy, None, None, None, None, slot, None, accumulate=acc)
-            self._conv_backward(x, u, dy)
+            self._conv_backward(x, u, dy if dyp is None else dyp)
         self.record(back)
         return ov
 
@@ -290,13 +315,21 @@ class _Run:
         # -10 % as a graph (659 vs 734 images/s: a second stream in the capture changes how the whole graph is scheduled), GALD +1 % (110.9 vs 109.7)
         work = 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * u.cout * (1 if u.depthwise else u.cin) * u.geom[0] * u.geom[1]
         side = self.side if work >= 8e9 else None
-        if _mfma_tile_ok(u, x.t) and dy.is_contiguous():
+        if _mfma_tile_ok(u, x.t) and dy.is_contiguous() and dy.shape[-1] == _rup32(u.cout):
             k, s, p, d = u.geom[0], u.geom[2], u.geom[4], u.geom[6]
-            _off_path(side, lambda: K.conv_wgrad(dy, x.t, slot, k, s, p, d, accumulate=acc), dy, x.t)
+            np_, cp = _rup32(u.cout), _rup32(u.cin)
+            if np_ == u.cout and cp == u.cin:
+                _off_path(side, lambda: K.conv_wgrad(dy, x.t, slot, k, s, p, d, accumulate=acc), dy, x.t)
+            else:           # padded operands: the gradient of the padded weight, its real corner into the parameter's slot
+                def padded_wgrad():
+                    wide = torch.empty((np_, cp, k, k), dtype=torch.float32, device=dy.device)
+                    K.conv_wgrad(dy, x.t, wide, k, s, p, d)
+                    slot.add_(wide[:u.cout, :u.cin]) if acc else slot.copy_(wide[:u.cout, :u.cin])
+                _off_path(side, padded_wgrad, dy, x.t)
             if x.needs:
                 tgt = _grad_target(x)
-                dx = K.conv_gemm(dy, u.wpt.view(k * k, u.cin, u.cout), (x.t.shape[1], x.t.shape[2]), k, s, p, d, K.GATHER_DGRAD,
-                                 out=tgt if (tgt is not None and tgt.is_contiguous()) else None)
+                dx = K.conv_gemm(dy, u.wpt.view(k * k, cp, np_), (x.t.shape[1], x.t.shape[2]), k, s, p, d, K.GATHER_DGRAD,
+                                 out=tgt if (tgt is not None and tgt.is_contiguous() and tgt.shape[-1] == cp) else None)
                 _acc(x, dx, True)
             return
         if x.t.shape[-1] != u.cin and not u.depthwise:

@@ -48,15 +48,17 @@ def test_argument_validation_needs_no_gpu(built):
 
 
 def test_documented_divisibility_rules_are_enforced(built):
-    """include/mi355seg.h: mi_conv_gemm needs Ca % 64 == 0, N % 8 == 0 (N % 16 with sign-bit masks); checked before any launch."""
+    """include/mi355seg.h: mi_conv_gemm needs Ca % 32 == 0 (and, when Ca % 64 != 0, a stride-1 / same-size launch), N % 8 == 0 (N % 16 with sign-bit masks);
+    checked before any launch."""
     one = ctypes.c_void_p(16)          # non-null, 16-byte aligned dummy: validation fails before it is dereferenced
 
-    def gemm(N, Ca=64, flags=0, mask_out=None):
-        return built.mi_conv_gemm(one, one, one, 1, 1, 1, Ca, 1, 1, N, 1, 1, 0, 1, 0, None, None, None, None, mask_out, flags, 0, 0.0, None)
+    def gemm(N, Ca=64, flags=0, mask_out=None, stride=1, Ha=1):
+        return built.mi_conv_gemm(one, one, one, 1, Ha, Ha, Ca, 1, 1, N, 1, stride, 0, 1, 0, None, None, None, None, mask_out, flags, 0, 0.0, None)
 
     assert gemm(4) == -22 and b"multiple of 8" in built.mi_last_error()
     assert gemm(12) == -22 and b"multiple of 8" in built.mi_last_error()
-    assert gemm(8, Ca=32) == -22 and b"multiple of 64" in built.mi_last_error()
+    assert gemm(8, Ca=48) == -22 and b"multiple of 32" in built.mi_last_error()
+    assert gemm(8, Ca=32, stride=2, Ha=2) == -22 and b"not a multiple of 64" in built.mi_last_error()      # 32-channel slabs: the stride-1 main loop only
     assert gemm(8, flags=64, mask_out=one) == -22 and b"N % 16" in built.mi_last_error()
     # mi_conv_wgrad: out_map 1 is bounded by ncls and by the size of dw
     ws = ctypes.c_void_p(4096)

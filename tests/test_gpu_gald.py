@@ -122,6 +122,9 @@ def _gald_cases():
          [np.maximum(_u("famw.left", (2, 128, 96, 96), 3), 0), np.maximum(_u("famw.down", (2, 256, 48, 48), 3), 0), np.maximum(_u("famw.right", (2, 256, 48, 48), 3), 0)]),
         # HarDNet-68's third block: 16 layers, growth 20 (widths 20 .. 160, inputs up to 466 channels: 4-byte aligned slices everywhere)
         ("hdb_16", "hdb16", lambda: gald.HarDBlock(256, 20, 1.7, 16), lambda: rg.HarDBlock(256, 20, 1.7, 16), [np.maximum(_u("hdb16.x", (2, 256, 22, 22), 3), 0)]),
+        # the same block on 16 928 pixels: its two big gathered layers (368 -> 98 and 466 -> 168 channels, 11 and 24 GFLOP) read gather buffers padded to
+        # 384 / 480 channels and run on the MFMA-tile kernels as 384 -> 128 and 480 -> 192 convs (pranet._tile_route; the test checks that they did)
+        ("hdb_16_pad", "hdb16", lambda: gald.HarDBlock(256, 20, 1.7, 16), lambda: rg.HarDBlock(256, 20, 1.7, 16), [np.maximum(_u("hdb16p.x", (2, 256, 92, 92), 3), 0)]),
     ]
 
 
@@ -129,17 +132,23 @@ def _gald_cases():
 # zero-mean regime the reference's fixtures were written in (half of the units at the ReLU kink: a flipped mask switches an input-gradient element
 # on or off, hence dx ~ 1e-1 eight layers deep - the reference's own autocast run measures the same); the oracle-only cases in the conditioned one.
 _GALD_BARS = {"hdb": (2.8e-2, 0.3, 6e-2, 2.7e-2), "fam": (1.9e-2, 0.33, 6.2e-2, 2.2e-2), "cca": (1.5e-2, 1.2e-2, 3.4e-2, 3e-4), "lam": (1.6e-2, 0.11, 4.6e-2, 4.8e-2),
-              "cca_twice": (5.4e-2, 0.11, 0.1, 2.2e-3), "fam_wide": (1.6e-2, 0.13, 2.1e-2, 1.2e-2), "hdb_16": (2.5e-2, 0.1, 9.3e-2, 2.1e-2)}
+              "cca_twice": (5.4e-2, 0.11, 0.1, 2.2e-3), "fam_wide": (1.6e-2, 0.13, 2.1e-2, 1.2e-2), "hdb_16": (2.5e-2, 0.1, 9.3e-2, 2.1e-2),
+              "hdb_16_pad": (2.5e-2, 0.1, 9.3e-2, 2.1e-2)}
 # measured: hdb 9.1e-3 / 1.0e-1 / 2.0e-2 / 8.7e-3;  fam 6.3e-3 / 1.1e-1 / 2.0e-2 / 7.1e-3;  cca 5.0e-3 / 3.7e-3 / 1.1e-2 / 7.9e-5;  lam 5.3e-3 / 3.7e-2 / 1.5e-2 / 1.6e-2;
 #           cca_twice 1.8e-2 / 3.7e-2 / 3.4e-2 / 7.2e-4;  fam_wide 5.2e-3 / 4.2e-2 / 6.8e-3 / 3.7e-3;  hdb_16 8.3e-3 / 3.4e-2 / 3.1e-2 / 7.0e-3
 
 
-@pytest.mark.parametrize("idx", range(7))
-def test_gald_product_modules_vs_reference_golden(idx):
+@pytest.mark.parametrize("idx", range(8))
+def test_gald_product_modules_vs_reference_golden(idx, monkeypatch):
     import _parity as P
     tag, prefix, make, make_ref, inputs = _gald_cases()[idx]
     mod, refm = make(), make_ref()
-    shift = synth.COND_BN_BIAS if tag in ("fam_wide", "hdb_16") else 0.0          # (the reference's fixtures were written in the zero-mean regime)
+    shift = synth.COND_BN_BIAS if tag in ("fam_wide", "hdb_16", "hdb_16_pad") else 0.0          # (the reference's fixtures were written in the zero-mean regime)
+    tile_shapes = []
+    if tag == "hdb_16_pad":
+        from rnd_semantic_segmentation_amd import kernels as KK
+        real = KK.conv_gemm_stats
+        monkeypatch.setattr(KK, "conv_gemm_stats", lambda a, wp, *r, **k: (tile_shapes.append((a.shape[-1], wp.shape[1])), real(a, wp, *r, **k))[1])
     synth.load_formula_weights(mod, prefix=prefix + ".", bn_bias=shift)
     synth.load_formula_weights(refm, prefix=prefix + ".", bn_bias=shift)
     assert list(mod.state_dict().keys()) == list(refm.state_dict().keys())
@@ -186,6 +195,8 @@ def test_gald_product_modules_vs_reference_golden(idx):
     e_norm = max(abs(float(np.linalg.norm(got_pg[k]) / np.linalg.norm(want_pg[k])) - 1) for k in live)
     e_cos = max(1 - P.cos(got_pg[k], want_pg[k]) for k in live)
     print("\n[gald %s] out %.2e  dx %.2e  |grad| %.2e  1-cos %.2e  (%d live parameter tensors)" % (tag, e_out, e_dx, e_norm, e_cos, len(live)))
+    if tag == "hdb_16_pad":
+        assert sorted(tile_shapes) == [(384, 128), (480, 192)], tile_shapes          # (padded Cin, padded Cout) of the layers that took the MFMA-tile kernels
     b = _GALD_BARS[tag]
     assert e_out < b[0] and e_dx < b[1] and e_norm < b[2] and e_cos < b[3], (tag, e_out, e_dx, e_norm, e_cos)
 
