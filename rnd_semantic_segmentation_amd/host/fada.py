@@ -290,6 +290,12 @@ class AsppFada:
     adapter_cls = FADAAdapter
     TEMPERATURE = 1.8
     FUSED = True        # False: literal order of operations on materialised tensors even when the modules offer the fused entry points
+    # Source and target crops through the backbone as ONE batch (round 5).  aspp_fada.py:80-104 runs the feature extractor twice, forward and backward,
+    # on 2 x B/2 crops and lets the two backward passes accumulate into .grad; with FrozenBatchNorm every sample is processed independently, so one
+    # forward over the concatenated batch, the two losses on its halves and ONE backward with d features = [d source | d target] give the same
+    # gradients (the sums over pixels run in another order: fp32 rounding only).  Why: at 4 crops a conv launch fills 118 of 256 CUs - the tile
+    # kernels take the same time for 4 crops as for 8.  Needs equal crop sizes and a frozen-BatchNorm backbone; False restores the two passes.
+    BATCHED = True
 
     def __init__(self, name, cfg, src_train_loader, tgt_train_loader, local_rank):
         self.cfg = cfg
@@ -343,7 +349,42 @@ class AsppFada:
         src_size, tgt_size = tuple(src_input.shape[-2:]), tuple(tgt_input.shape[-2:])
         T = self.TEMPERATURE
         fused = self.FUSED and hasattr(a.classifier, "loss") and hasattr(f.model_D, "soft_loss")
-        if fused:
+        batched = (fused and self.BATCHED and src_input.shape[1:] == tgt_input.shape[1:] and getattr(a.feature_extractor, "freeze_bn", False)
+                   and dev.type == "cuda")
+        if batched:
+            ns = src_input.shape[0]
+            fea = a.feature_extractor(torch.cat((src_input, tgt_input), 0))
+            halves = fea.detach()
+            src_fea, tgt_fea = halves[:ns].requires_grad_(True), halves[ns:].requires_grad_(True)
+            loss_seg = a.classifier.loss(src_fea, src_label, self.cfg.INPUT.IGNORE_LABEL, temperature=T)
+            src_low = a.classifier.last_low
+            self._overlap(True)                                 # every gradient a backward below touches is final when it returns
+            loss_seg.backward()                                 # classifier gradients + d source features
+            with torch.no_grad():
+                tgt_low = a.classifier(tgt_fea)
+            d_params = list(f.model_D.parameters())
+            for p in d_params:
+                p.requires_grad_(False)
+            loss_adv_tgt = f.model_D.soft_loss(tgt_fea, tgt_low, 0, tgt_size, weight=0.001, temperature=T)
+            loss_adv_tgt.backward()                             # d target features
+            for p in d_params:
+                p.requires_grad_(True)
+            dfea = torch.empty_like(fea)
+            dfea[:ns].copy_(src_fea.grad)
+            dfea[ns:].copy_(tgt_fea.grad)
+            fea.backward(dfea)                                  # the backbone's backward, once, over both halves
+            self._reduce(a)
+            a.optimizer_fea.step()
+            a.optimizer_cls.step()
+            f.optimizer_D.zero_grad()
+            src_fea, tgt_fea = halves[:ns], halves[ns:]
+            loss_D_src = f.model_D.soft_loss(src_fea, src_low, 0, src_size, weight=0.5, temperature=T)
+            loss_D_src.backward()
+            loss_D_tgt = f.model_D.soft_loss(tgt_fea, tgt_low, 1, tgt_size, weight=0.5, temperature=T)
+            loss_D_tgt.backward()
+            self._reduce(f)
+            f.optimizer_D.step()
+        elif fused:
             src_fea = a.feature_extractor(src_input)
             loss_seg = a.classifier.loss(src_fea, src_label, self.cfg.INPUT.IGNORE_LABEL, temperature=T)
             src_low = a.classifier.last_low                     # 1/8-resolution logits (detached) -> soft labels

@@ -310,26 +310,36 @@ def test_two_fada_iterations_track_reference_losses(tmp_path, monkeypatch):
     assert rel(D.cls1.bias, g["d_cls1_bias_after"]) < 5e-2                   # Adam's sign-like first steps: lr-sized moves agree
 
 
-def test_fused_iteration_equals_literal_iteration_on_product_modules(tmp_path, monkeypatch):
-    """The fused schedule (soft labels in-kernel, discriminator weight gradients skipped in the generator pass, classifier not
-    differentiated on the target pass) and the literal order of operations of aspp_fada.py give the same losses and updates."""
+def test_fused_and_batched_iterations_equal_the_literal_iteration_on_product_modules(tmp_path, monkeypatch):
+    """Three schedules of one iteration give the same losses and updates: the literal order of operations of aspp_fada.py; the fused schedule (soft
+    labels in-kernel, discriminator weight gradients skipped in the generator pass, classifier not differentiated on the target pass) with the
+    reference's two backbone passes; and the default - fused, source and target crops through the backbone as ONE batch with one backward
+    (AsppFada.BATCHED: per-sample independent under FrozenBatchNorm, so only the order of the fp32 sums over pixels differs)."""
     xs, ys, xt = fada_inputs()
     res = []
-    for fused in (True, False):
+    for fused, batched in ((False, False), (True, False), (True, True)):
         combo = _combo(tmp_path, monkeypatch, (1, 1, 1, 1))
-        combo.FUSED = fused
+        combo.FUSED, combo.BATCHED = fused, batched
+        calls = []
+        fe = combo.aspp.feature_extractor
+        fe.register_forward_pre_hook(lambda m, args: calls.append(args[0].shape[0]))
         r = [combo.train_step(xs, ys, xt, 40) for _ in range(2)]
+        assert calls == ([4, 4] if batched else [2, 2, 2, 2]), calls          # one backbone pass over source + target, or two
         sd = {k: v.detach().clone() for k, v in combo.fada.model_D.state_dict().items()}
-        fe_sd = {k: v.detach().clone() for k, v in combo.aspp.feature_extractor.state_dict().items() if k.endswith("conv1.weight")}
-        res.append((r, sd, fe_sd))
-    (ra, da, fa), (rb, db, fb) = res
-    for a, b in zip(ra, rb):
-        for k in ("loss_seg", "loss_adv_tgt", "loss_D_src", "loss_D_tgt"):
-            assert abs(float(a[k]) - float(b[k])) < 2e-3 * abs(float(b[k])), k
-    # Adam's first steps move every weight by ~lr * sign(g): entries whose gradient is within rounding distance of zero may move
-    # in opposite directions in the two schedules, so compare the bulk (mean deviation << the 2e-4 total move), not the max
-    for k in da:
-        assert float((da[k] - db[k]).abs().mean()) < 0.05 * 2e-4, k
-        assert float((da[k] - db[k]).abs().max()) <= 2.1 * 2e-4, k
-    for k in fa:
-        assert rel(fa[k], fb[k]) < 1e-3, k
+        fe_sd = {k: v.detach().clone() for k, v in fe.state_dict().items() if k.endswith("conv1.weight")}
+        cls_sd = {k: v.detach().clone() for k, v in combo.aspp.classifier.state_dict().items()}
+        res.append((r, sd, fe_sd, cls_sd))
+    rb, db, fb, cb = res[0]
+    for ra, da, fa, ca in res[1:]:
+        for a, b in zip(ra, rb):
+            for k in ("loss_seg", "loss_adv_tgt", "loss_D_src", "loss_D_tgt"):
+                assert abs(float(a[k]) - float(b[k])) < 2e-3 * abs(float(b[k])), k
+        # Adam's first steps move every weight by ~lr * sign(g): entries whose gradient is within rounding distance of zero may move
+        # in opposite directions in the two schedules, so compare the bulk (mean deviation << the 2e-4 total move), not the max
+        for k in da:
+            assert float((da[k] - db[k]).abs().mean()) < 0.05 * 2e-4, k
+            assert float((da[k] - db[k]).abs().max()) <= 2.1 * 2e-4, k
+        for k in fa:
+            assert rel(fa[k], fb[k]) < 1e-3, k
+        for k in ca:
+            assert rel(ca[k], cb[k]) < 1e-3, k
