@@ -350,38 +350,44 @@ class AsppFada:
         T = self.TEMPERATURE
         fused = self.FUSED and hasattr(a.classifier, "loss") and hasattr(f.model_D, "soft_loss")
         batched = (fused and self.BATCHED and src_input.shape[1:] == tgt_input.shape[1:] and getattr(a.feature_extractor, "freeze_bn", False)
-                   and dev.type == "cuda")
+                   and dev.type == "cuda" and isinstance(f.model_D, PixelDiscriminator))
         if batched:
             ns = src_input.shape[0]
             fea = a.feature_extractor(torch.cat((src_input, tgt_input), 0))
             halves = fea.detach()
-            src_fea, tgt_fea = halves[:ns].requires_grad_(True), halves[ns:].requires_grad_(True)
+            src_fea = halves[:ns].requires_grad_(True)
             loss_seg = a.classifier.loss(src_fea, src_label, self.cfg.INPUT.IGNORE_LABEL, temperature=T)
             src_low = a.classifier.last_low
             self._overlap(True)                                 # every gradient a backward below touches is final when it returns
             loss_seg.backward()                                 # classifier gradients + d source features
             with torch.no_grad():
-                tgt_low = a.classifier(tgt_fea)
-            d_params = list(f.model_D.parameters())
-            for p in d_params:
-                p.requires_grad_(False)
-            loss_adv_tgt = f.model_D.soft_loss(tgt_fea, tgt_low, 0, tgt_size, weight=0.001, temperature=T)
-            loss_adv_tgt.backward()                             # d target features
-            for p in d_params:
-                p.requires_grad_(True)
+                tgt_low = a.classifier(halves[ns:])             # the classifier receives no gradient from the target pass
+            # The discriminator runs forward ONCE, over both halves: aspp_fada.py evaluates model_D(tgt_fea) twice (:98 for the adversarial loss, :119
+            # for its own) and model_D(src_fea) once, on the same features and the same weights - the logits are the same tensors.  Its backward for
+            # the adversarial loss (data gradients only, target half) comes now; the one for its own two losses (weight gradients, both halves at
+            # once: loss_D_src + loss_D_tgt accumulate in .grad either way) after the generator's update, as in the reference.
+            D = f.model_D
+            eng = D._engine
+            D.ensure_flat()
+            eng.prepare(True)
+            dlow, saved = eng.forward(D._nhwc(halves), save=True)
+            seg = lambda low: low.detach().permute(0, 2, 3, 1).contiguous().float()
+            seg_s, seg_t = seg(src_low), seg(tgt_low)
+            out_adv, dd_adv = K.upsample_softce(seg_t, dlow[ns:], tgt_size, 0, T, 0.9, want_grad=True, grad_scale=0.001)
+            loss_adv_tgt = out_adv[0] * 0.001
+            dx_tgt = eng.backward(tuple(t[ns:] for t in saved), dd_adv, True, False)
             dfea = torch.empty_like(fea)
             dfea[:ns].copy_(src_fea.grad)
-            dfea[ns:].copy_(tgt_fea.grad)
+            dfea[ns:].copy_(dx_tgt.permute(0, 3, 1, 2))
             fea.backward(dfea)                                  # the backbone's backward, once, over both halves
             self._reduce(a)
             a.optimizer_fea.step()
             a.optimizer_cls.step()
             f.optimizer_D.zero_grad()
-            src_fea, tgt_fea = halves[:ns], halves[ns:]
-            loss_D_src = f.model_D.soft_loss(src_fea, src_low, 0, src_size, weight=0.5, temperature=T)
-            loss_D_src.backward()
-            loss_D_tgt = f.model_D.soft_loss(tgt_fea, tgt_low, 1, tgt_size, weight=0.5, temperature=T)
-            loss_D_tgt.backward()
+            out_s, dd_s = K.upsample_softce(seg_s, dlow[:ns], src_size, 0, T, 0.9, want_grad=True, grad_scale=0.5)
+            out_t, dd_t = K.upsample_softce(seg_t, dlow[ns:], tgt_size, 1, T, 0.9, want_grad=True, grad_scale=0.5)
+            eng.backward(saved, torch.cat((dd_s, dd_t), 0), False, True)
+            loss_D_src, loss_D_tgt = out_s[0] * 0.5, out_t[0] * 0.5
             self._reduce(f)
             f.optimizer_D.step()
         elif fused:
