@@ -62,10 +62,16 @@ def head_commit():
         return None
 
 
-def counters_stale(profiled):
-    """True when the hardware-counter file a roofline's `traffic` / HBM fraction come from was taken at another commit than the one running (the
-    kernels may have changed since); None when either commit is unknown."""
-    head = head_commit()
+def counters_stale(meta):
+    """True when the kernels / host schedule have changed since the hardware-counter file a roofline's `traffic` / HBM fraction come from was taken.
+    `meta`: the file's `_meta`.  Compared by a digest of rnd_semantic_segmentation_amd/{csrc,host,*.py} (profiles/_digest.py; a docs-only commit does not
+    make counters stale); files written before that digest existed fall back to the commit (None when either commit is unknown)."""
+    meta = meta or {}
+    if meta.get("sources_sha"):
+        sys.path.insert(0, os.path.join(ROOT, "profiles"))
+        from _digest import sources_sha
+        return sources_sha() != meta["sources_sha"]
+    head, profiled = head_commit(), meta.get("commit")
     if not head or not profiled:
         return None
     n = min(len(head), len(profiled))
@@ -268,7 +274,7 @@ def aux_workload(args, device):
             e = pmc[pmc_class]
             traffic, hbm_frac, busy = e.get("hbm_bytes_per_launch"), e.get("hbm_frac_of_peak"), e.get("mfma_busy_frac")
             src = {"file": "profiles/pmc_%s.json" % args.workload, "class": pmc_class, "profiled_commit": pmc["_meta"].get("commit"), "round": pmc["_meta"].get("round"),
-                   "avg_launch_us_under_counters": e.get("avg_launch_us"), "l2_hit_frac": e.get("l2_hit_frac"), "counters_stale": counters_stale(pmc["_meta"].get("commit"))}
+                   "avg_launch_us_under_counters": e.get("avg_launch_us"), "l2_hit_frac": e.get("l2_hit_frac"), "counters_stale": counters_stale(pmc["_meta"])}
             whole = {k: pmc["_meta"].get(k) for k in ("kernel_ms_per_step", "launches_per_step", "hbm_read_gb_per_step", "hbm_write_gb_per_step", "hbm_tb_s_over_kernel_time")}
         except (OSError, KeyError, ValueError):
             pass
@@ -537,7 +543,7 @@ def main():
                     l2 = {"hit_frac": pmc[key]["l2_hit_frac"], "requests_per_launch": pmc[key]["l2_requests_per_launch"],
                           "mfma_busy_frac": pmc[key]["mfma_busy_frac"]}
                 traffic_src = {"file": "profiles/pmc.json", "profiled_commit": pmc.get("_meta", {}).get("commit"), "round": pmc.get("_meta", {}).get("round"),
-                               "counters_stale": counters_stale(pmc.get("_meta", {}).get("commit"))}
+                               "counters_stale": counters_stale(pmc.get("_meta", {}))}
             except (OSError, KeyError, ValueError):
                 pass
             if dom == "bn_kernels":      # MODEL.FREEZE_BN False: the elementwise BatchNorm passes together outweigh any one conv kernel - HBM-bound
@@ -549,7 +555,7 @@ def main():
                     cls = {k: v for k, v in pj.items() if k != "_meta" and ("bn_apply" in k or "bn_bwd_apply" in k or "bn_partial" in k)}
                     gb, ln = sum(v["hbm_gb_per_step"] for v in cls.values()), sum(v["launches_per_step"] for v in cls.values())
                     bn_traffic = round(gb * 1e9 / ln)
-                    bn_src = {"file": "profiles/pmc_deeplab_bn.json", "classes": sorted(cls), "hbm_gb_per_step": round(gb, 2), "profiled_commit": pj["_meta"].get("commit"),
+                    bn_src = {"file": "profiles/pmc_deeplab_bn.json", "classes": sorted(cls), "hbm_gb_per_step": round(gb, 2), "profiled_commit": pj["_meta"].get("commit"), "counters_stale": counters_stale(pj["_meta"]),
                               "hbm_frac_of_peak": {k: v.get("hbm_frac_of_peak") for k, v in cls.items()}}
                 except (OSError, KeyError, ValueError, ZeroDivisionError):
                     pass

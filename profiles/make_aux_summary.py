@@ -8,7 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 names = {"pranet": "PraNet, 16 x 352 x 352 training step (`bench.py --workload pranet`; BASELINE config[3])",
          "gald": "GALD, 6 x 720 x 1280 training step (`bench.py --workload gald`)",
-         "deeplab_bn": "DeepLabV2-R101 with MODEL.FREEZE_BN False, 8 x 769 x 769 (`bench.py --workload deeplab_bn`)"}
+         "deeplab_bn": "DeepLabV2-R101 with MODEL.FREEZE_BN False, 8 x 769 x 769 (`bench.py --workload deeplab_bn`)",
+         "fada": "FADA adversarial iteration, 4 source + 4 target crops of 769 x 769 (`bench.py --workload fada`; BASELINE config[4] on one GPU)"}
 out = ["# Round %s: the workloads beside the headline - bench lines and hardware counters (1x MI355X)\n" % tag[1:].lstrip("0"),
        "`bash tools/profile_aux.sh %s`: per workload four separate `rocprofv3 --kernel-trace --pmc ...` passes (SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE; FETCH_SIZE; WRITE_SIZE;\n"
        "TCC_REQ / HIT / MISS; eager, the program straight after `--`) -> `profiles/pmc_<workload>.json` (`profiles/make_pmc_any.py`: FETCH_SIZE x 2 x 1024, WRITE_SIZE x 1024 per\n"

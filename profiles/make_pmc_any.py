@@ -86,7 +86,9 @@ def main():
     stamp = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".commit_stamp")
     if os.path.exists(stamp):
         commit = open(stamp).read().strip()
-    meta = {"commit": commit, "round": args[4] if len(args) > 4 else None, "steps_in_trace": steps,
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _digest import sources_sha
+    meta = {"sources_sha": sources_sha(), "commit": commit, "round": args[4] if len(args) > 4 else None, "steps_in_trace": steps,
             "note": "per launch, averaged over every launch of the kernel class in the profiled command (counter passes serialise the kernels)"}
     if steps:
         meta.update({"kernel_ms_per_step": round(tot["us"] / steps / 1e3, 3), "launches_per_step": round(tot["launches"] / steps, 1),

@@ -65,7 +65,9 @@ def main():
             commit = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
         except OSError:
             commit = None
-    out["_meta"] = {"commit": commit or None, "round": sys.argv[5] if len(sys.argv) > 5 else None,
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _digest import sources_sha
+    out["_meta"] = {"sources_sha": sources_sha(), "commit": commit or None, "round": sys.argv[5] if len(sys.argv) > 5 else None,
                     "note": "per launch, averaged over every launch of the kernel in `bench.py --steps 5 --warmup 3` (single-stream schedule)"}
     dst = sys.argv[4] if len(sys.argv) > 4 else "profiles/pmc.json"
     json.dump(out, open(dst, "w"), indent=1)

@@ -30,15 +30,18 @@ def table(path, top=28):
 
 pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc.json")))
 b = json.load(open(os.path.join(ROOT, "profiles", "%s_bench_builder.json" % tag)))
+b100 = json.load(open(os.path.join(ROOT, "profiles", "%s_bench_100steps.json" % tag)))
 fam = b["kernel_families"]
 lines = ["# Round %s, end-of-round profile - 1x MI355X, B=8, 769x769, bf16 operands (commit %s)\n" % (tag[1:].lstrip("0"), pmc["_meta"].get("commit")),
          "Command (from /tmp on the GPU box, `tools/profile_round.sh %s`): `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-kernel-events`;" % tag,
          "%d training steps are in each trace (3 warm-up + 5 timed).  Raw tables: `%s_bench_kernel_stats.csv` (default two-stream schedule), `%s_bench_kernel_stats_single_stream.csv`." % (steps, tag, tag),
          "Bench line of the same commit (`%s_bench_builder.json`, default flags): **%.1f images/s, %.2f ms/step**; `igemm_pp_kernel` %.4f of the MFMA peak; dilated-3x3 family %.3f, ASPP head %.3f, "
-         "K = 256 <-> 1024 class %.3f of HBM peak; CPU port %.3f images/s on %d cores.  `%s_bench_100steps.json` (`--steps 100 --warmup 20`, another box of the pool): sustained 293.4 images/s, 27.26 ms/step." % (
+         "K = 256 <-> 1024 class %.3f of HBM peak; CPU port %.3f images/s on %d cores.  `%s_bench_100steps.json` (`--steps 100 --warmup 20`, same box): sustained %.1f images/s, %.2f ms/step." % (
              tag, b["value"], b["ms_per_step"], b["roofline"]["frac"], fam["dilated3x3_family"]["frac_of_mfma_peak"], fam["aspp_head"]["frac_of_mfma_peak"],
-             fam["pointwise_k256_n1024_class"]["frac_of_hbm_peak"], b["cpu_baseline"]["value"], b["cpu_baseline"]["cores"], tag),
-         "The DeepLab kernels did not change this round (round 3, driver: 292.9 images/s, 27.31 ms, 0.4155 / 0.420 / 0.313 / 0.50): the numbers differ by the box.",
+             fam["pointwise_k256_n1024_class"]["frac_of_hbm_peak"], b["cpu_baseline"]["value"], b["cpu_baseline"]["cores"], tag, b100["value"], b100["ms_per_step"]),
+         "Driver, round 4 (`BENCH_r04.json`): 291.2 images/s, 27.475 ms, 0.4159 / 0.4197 / 0.3101; round 5 changed the schedule of the weight-gradient stream (slab reducers "
+         "batched per block: +1.6 %% in an interleaved A/B on one box, `r05_reduce_batch_ab.txt`), not the conv kernels; boxes of the pool differ by 2 - 3 %% (this one: %.1f images/s; "
+         "the A/B box: 300.0 with, 295.4 without)." % b["value"],
          "The other workloads and their counters: `%s_aux_summary.md`.\n" % tag,
          "## A. single-stream schedule (MI_WGRAD_STREAM=0 MI_BATCH_LANES=1): one kernel at a time, durations are the kernels' own\n",
          table(os.path.join(ROOT, "profiles", "%s_bench_kernel_stats_single_stream.csv" % tag)),
