@@ -16,7 +16,7 @@ import sys
 from collections import defaultdict
 
 KERNELS = {"igemm_nt_kernel": "igemm_nt_kernel", "igemm_pp_kernel": "igemm_pp_kernel", "wgrad_tn_kernel": "wgrad_tn_kernel", "wgrad_q3_kernel": "wgrad_q3_kernel", "wgrad_s4_kernel": "wgrad_s4_kernel", "wgrad_tn256_kernel": "wgrad_tn256_kernel",
-           "wgrad_reduce_kernel": "wgrad_reduce_kernel", "upce_pass1_kernel": "upce_pass1_kernel"}
+           "wgrad_reduce_multi_kernel": "wgrad_reduce_multi_kernel", "wgrad_reduce_kernel": "wgrad_reduce_kernel", "upce_pass1_kernel": "upce_pass1_kernel"}
 
 
 def load(d):

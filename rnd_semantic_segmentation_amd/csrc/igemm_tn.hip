@@ -938,6 +938,11 @@ constexpr int Q3_YROWB = 128;
 constexpr int Q3_DY_BYTES = P3_KS * Q3_YROWB, Q3_STAGE = Q3_DY_BYTES + P3_X_BYTES;      // 8 KiB + 20 KiB
 constexpr int Q3_LDS = 2 * Q3_STAGE;                                                    // 56 KiB: two workgroups per CU
 
+#ifdef MI_EXPERIMENTS      // phase toggles of MI_P3_DBG (tools/wgexp.py toggles): experiment builds only, the constant 0 in the product library
+#define Q3_DBG(b) (p.dbg & (b))
+#else
+#define Q3_DBG(b) 0
+#endif
 __global__ __launch_bounds__(256, 2) void wgrad_q3_kernel(WgradP3Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1070,6 +1075,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_q3_kernel(WgradP3Params p) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             union { bf16x8 v; s16x4 h[2]; } yf[4], xf[3][2];
+            if (Q3_DBG(2)) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) yf[b].h[0] = yf[b].h[1] = s16x4{(short)lane, 1, 2, 3};
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) xf[kx][a].h[0] = xf[kx][a].h[1] = s16x4{(short)lane, 3, 2, 1};
+            }
+            if (!Q3_DBG(2)) {
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const unsigned base = sb + y_off + ((b ^ y_sw) << 5);
@@ -1094,8 +1108,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_q3_kernel(WgradP3Params p) {
                         xf[kx][a].h[1] = tr_read_lds<48 * ROWB>(base);
                     }
                 }
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            if (!Q3_DBG(4)) {
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
@@ -1103,6 +1119,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_q3_kernel(WgradP3Params p) {
 #pragma unroll
                     for (int b = 0; b < 4; ++b)
                         acc[kx][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kx][a].v, yf[b].v, acc[kx][a][b], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) asm volatile("" ::"v"(yf[b].v));
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) asm volatile("" ::"v"(xf[kx][a].v));
+            }
         }
     };
 
@@ -1112,7 +1136,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_q3_kernel(WgradP3Params p) {
         __syncthreads();
         for (int s = 0; s < ns; ++s) {
             const int cur = s & 1;
-            if (s + 1 < ns) stage(cur ^ 1);
+            if (s + 1 < ns && !Q3_DBG(1)) stage(cur ^ 1);
             compute(cur);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -1120,6 +1144,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_q3_kernel(WgradP3Params p) {
     }
 
     const int fcol = lane & 15, fq = lane >> 4;
+    if (Q3_DBG(8)) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) asm volatile("" ::"v"(acc[kx][a][b]));
+        return;
+    }
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
         float* plane = p.slab + ((long)(split * 9 + ky * 3 + kx) * p.O) * p.I;

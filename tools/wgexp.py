@@ -10,16 +10,22 @@ from tools.kbench import timeit  # noqa: E402
 
 B, H = 8, 97
 if len(sys.argv) > 1 and sys.argv[1] == "toggles":
-    ci = co = 256
-    x = torch.randn((B, H, H, ci), device="cuda").to(torch.bfloat16)
-    dy = torch.randn((B, H, H, co), device="cuda").to(torch.bfloat16)
-    dw = torch.empty((co, ci, 3, 3), device="cuda")
-    for dbg, name in ((0, "all"), (8, "no stores"), (9, "no DMA, no stores"), (10, "no reads, no stores"), (12, "no MFMA, no stores"), (11, "MFMA only"), (14, "DMA only"), (13, "reads only"), (15, "barriers only"), (30, "DMA only, L2-hot rows"), (24, "no stores, L2-hot rows")):
-        os.environ["MI_P3_DBG"] = str(dbg)
+    # phase toggles of the fused-row 3x3 kernel (wgrad_q3_kernel; experiment builds: MI355SEG_LIB=tools/experiments/libmi355seg_exp.so).  The library reads
+    # MI_P3_DBG once per process, so every setting runs in a child process.
+    import subprocess
+    if len(sys.argv) > 2:
+        ci = co = 256
+        x = torch.randn((B, H, H, ci), device="cuda").to(torch.bfloat16)
+        dy = torch.randn((B, H, H, co), device="cuda").to(torch.bfloat16)
+        dw = torch.empty((co, ci, 3, 3), device="cuda")
         f = lambda: K.conv_wgrad(dy, x, dw, 3, 1, 2, 2)
         f()
         t = min(timeit(f, 20) for _ in range(3))
-        print("p3 256 d2  %-22s %7.1f us (kernel + reducer)" % (name, t * 1e6))
+        print("q3 256 d2  %-22s %7.1f us (kernel + reducer)" % (sys.argv[2], t * 1e6), flush=True)
+        sys.exit(0)
+    for dbg, name in ((0, "all"), (8, "no stores"), (1, "no DMA"), (9, "no DMA, no stores"), (10, "no reads, no stores"), (12, "no MFMA, no stores"), (11, "MFMA only"), (14, "DMA only"),
+                      (13, "reads only"), (15, "barriers only")):
+        subprocess.run([sys.executable, os.path.abspath(__file__), "toggles", name], env=dict(os.environ, MI_P3_DBG=str(dbg)), check=True)
     sys.exit(0)
 for ci, co, k, d in ((256, 256, 3, 2), (512, 512, 3, 4), (256, 256, 3, 1), (128, 128, 3, 1), (256, 1024, 1, 1), (1024, 256, 1, 1)):
     x = torch.randn((B, H, H, ci), device="cuda").to(torch.bfloat16)
