@@ -303,3 +303,29 @@ def test_pranet_warmup_cosine_schedule_equals_the_references_scheduler_chain():
     assert len(lrs) == 40 and lrs[6] > lrs[5] == 8 * base                        # the overshoot is in the fixture
     for k, want in enumerate(lrs):
         assert abs(warmup_cosine_lr(base, k) / want - 1) < 1e-12, (k, warmup_cosine_lr(base, k), want)
+
+
+def test_tile_route_of_the_tape_engines_is_consistent_with_the_padded_gathers():
+    """host/pranet.py:_tile_route decides, from shapes alone, which convs of the tape engines (PraNet, GALD) go to the MFMA-tile kernels: 64-multiples on
+    both sides as before, and (round 5) stride-1 layers whose channel counts pad to 32-multiples with < 1.6x the work, >= 16 384 pixels and >= 8 GFLOP -
+    HarDNet-68's big gathered layers.  gald._hard_block pads a gather buffer exactly when this predicate holds, and _mfma_tile_ok takes the conv only when
+    its input has the padded width: the two must agree or the general kernel would be handed a tensor wider than the conv's Cin."""
+    from rnd_semantic_segmentation_amd.host import gald, pranet
+    rup = pranet._rup32
+    assert [rup(c) for c in (1, 32, 33, 466, 480)] == [32, 32, 64, 480, 480]
+    layers, links, out_ch = gald._hard_block_units("b.", 256, 20, 1.7, 16)           # HarDNet-68's third block (hardnet_68.py:163-262: growth 20, 16 layers)
+    assert out_ch == 328 and [(u.cin, u.cout) for u in layers][15] == (466, 168) and len(links[15]) == 5
+    px = 6 * 90 * 160                                                                 # the block's map at 6 x 720 x 1280
+    routed = [(u.cin, u.cout) for u, lk in zip(layers, links) if len(lk) > 1 and pranet._tile_route(u, px)]
+    assert routed == [(310, 58), (368, 98), (152, 58), (466, 168)], routed
+    # too few pixels, too little work, too much padding, strided, depthwise: the general kernel keeps them
+    assert not pranet._tile_route(layers[15], 16383)
+    assert not pranet._tile_route(pranet._Unit("c", "n", 96, 96, 3, 1, 1), 30976)                 # 5 GFLOP (PraNet's 96 -> 96 at 44 x 44 x 16)
+    assert not pranet._tile_route(pranet._Unit("c", "n", 102, 40, 3, 1, 1), 345600)               # 2.0x the work when padded
+    assert not pranet._tile_route(pranet._Unit("c", "n", 466, 168, 3, 2, 1), px)
+    assert pranet._tile_route(pranet._Unit("c", "n", 256, 256, 3, 1, 1), 16384)                   # 64-multiples: as before, any stride
+    assert pranet._tile_route(pranet._Unit("c", "n", 128, 64, 3, 2, 1), 16384)
+    # the input the MFMA-tile kernels take for a padded layer is the padded gather buffer, nothing else
+    u = layers[15]
+    ok = lambda c: pranet._mfma_tile_ok(u, torch.empty((6, 90, 160, c), dtype=torch.bfloat16, device="meta"))
+    assert ok(480) and not ok(466) and not ok(512)
