@@ -134,7 +134,9 @@ int mi_conv_wgrad(const void* dy, const void* x, float* dw,
 /* mi_conv_wgrad in two parts (round 5): _partial runs the main kernel only - the split-K slabs stay in `workspace`, which the caller keeps alive and
  * untouched until the reduction - and writes the reducer's arguments to `job` (mi_conv_wgrad_job_bytes() bytes of host memory); mi_conv_wgrad_reduce runs
  * the reducers of up to 8 consecutive job records as ONE launch (the three weight gradients of a bottleneck: one launch instead of three on the
- * weight-gradient stream).  Same fixed summation order per conv: the same bits as mi_conv_wgrad. */
+ * weight-gradient stream).  Same fixed summation order per conv, hence the same bits as mi_conv_wgrad - with one exception: this form is the one that runs
+ * BESIDE a data-gradient chain, and the fused-row 3x3 route plans its K split for that (448 instead of 512 workgroup slots, MI_WGRAD_Q3_SLOTS_BESIDE:
+ * fewer, longer splits = another partition of the fp32 sums; deterministic, and within fp32 rounding of the one-call result). */
 size_t mi_conv_wgrad_job_bytes(void);
 int mi_conv_wgrad_partial(const void* dy, const void* x, float* dw,
                           int B, int Ha, int Wa, int I, int Ho, int Wo, int O,

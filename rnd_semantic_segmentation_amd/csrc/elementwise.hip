@@ -35,6 +35,8 @@ const MiSwitches& mi_sw() {
         sw.pp_loop = 0;
 #endif
         sw.igemm_pw = env("MI_IGEMM_PW", 0);
+        sw.wgrad_q3_slots = env("MI_WGRAD_Q3_SLOTS", 512);
+        sw.wgrad_q3_slots_beside = env("MI_WGRAD_Q3_SLOTS_BESIDE", 448);
         sw.wgrad_s4_slots = env("MI_WGRAD_S4_SLOTS", 512);
         if (sw.wgrad_s4_slots < 64) sw.wgrad_s4_slots = 512;
         sw.wgrad_ti256 = env("MI_WGRAD_TI256", -1);

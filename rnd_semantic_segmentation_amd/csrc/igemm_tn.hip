@@ -1173,7 +1173,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_q3_kernel(WgradP3Params p) {
 // Split / grid of the fused 3x3 kernel; returns false when the shape should stay on the per-tap kernel.
 struct P3Plan { int S, slabs_per_split; long Q; int WP, o_tiles, i_tiles; };
 // q3: the 4-wave / two-per-CU kernel (64-channel o tiles, 512 workgroup slots) instead of the 8-wave ping-pong kernel (128, 256)
-bool p3_plan(int B, int H, int W, int O, int I, int dil, bool force, P3Plan& pl, bool q3 = false) {
+bool p3_plan(int B, int H, int W, int O, int I, int dil, bool force, P3Plan& pl, bool q3 = false, bool beside = false) {
     if (dil < 1 || dil > 8) return false;
     pl.WP = W + 2 * dil;
     pl.Q = (long)B * H * pl.WP;
@@ -1181,7 +1181,11 @@ bool p3_plan(int B, int H, int W, int O, int I, int dil, bool force, P3Plan& pl,
     pl.i_tiles = (I + TI - 1) / TI;
     const long ns = (pl.Q + P3_KS - 1) / P3_KS;
     const int groups = pl.o_tiles * pl.i_tiles * 3;
-    long S = (q3 ? 512 : 256) / groups;
+    // Workgroup slots the split fills.  A launch that runs alone wants both residents of every CU (512: 127 us at 256 -> 256 against 134 / 160 with 384 / 256
+    // slots).  A launch that runs BESIDE a data-gradient chain (the deferred-reducer form, mi_conv_wgrad_partial: the DeepLab engines' side stream) is
+    // better off leaving an eighth of the slots to its neighbour and writing 14 % fewer partial planes: the training step 288.9 vs 286.4 images/s with
+    // 448, 288.5 with 384, 283.8 with 320 (three interleaved rounds, profiles/r05_wgrad_slots_ab.txt); FADA +1.0 %, trainable-BatchNorm step +2.0 %.
+    long S = (q3 ? (beside ? mi_sw().wgrad_q3_slots_beside : mi_sw().wgrad_q3_slots) : 256) / groups;
     if (S < 1) S = 1;
     if (S > ns) S = ns;
     pl.slabs_per_split = (int)((ns + S - 1) / S);
@@ -1347,7 +1351,7 @@ static int mi_conv_wgrad_impl(const void* dy, const void* x, float* dw, int B, i
     const int q3_mode = mi_sw().wgrad_q3;
     if (q3_mode && !p3_mode && out_map == 0 && ksize == 3 && stride == 1 && Ha == Ho && Wa == Wo && pad == dil) {
         P3Plan pl;
-        if (p3_plan(B, Ho, Wo, O, I, dil, q3_mode == 2, pl, true) && (size_t)pl.S * 9 * O * I * sizeof(float) <= workspace_bytes) {
+        if (p3_plan(B, Ho, Wo, O, I, dil, q3_mode == 2, pl, true, defer != nullptr) && (size_t)pl.S * 9 * O * I * sizeof(float) <= workspace_bytes) {
             launch_p3(dy, x, (float*)workspace, Ho, Wo, O, I, dil, pl, B * Ho, (hipStream_t)stream, true);
             MI_CHECK_LAUNCH("mi_conv_wgrad (fused 3x3 rows, 4 waves)");
             return wgrad_finish(defer, (hipStream_t)stream, (const float*)workspace, dw, scale_o, pl.S, 9, O, I, accumulate, 0, 1, O);

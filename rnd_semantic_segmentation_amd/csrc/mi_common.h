@@ -30,6 +30,8 @@ struct MiSwitches {
     int pp_korder;         // MI_IGEMM_PP_KORDER  1: channel-chunk-major contraction of a 3x3 (0: tap-major, bit-equal to igemm_nt)
     int pp_loop;           // MI_IGEMM_PP_LOOP    0: two-group ping-pong main loop, 1: rolling fragment ring (both waves of a SIMD stream MFMAs)
     int igemm_pw;          // MI_IGEMM_PW         0: shared-window 3x3 kernel off (-DMI_EXPERIMENTS builds only)
+    int wgrad_q3_slots;    // MI_WGRAD_Q3_SLOTS   512: workgroup slots the fused-row 3x3 weight gradient's split fills when the launch runs alone (mi_conv_wgrad)
+    int wgrad_q3_slots_beside;   // MI_WGRAD_Q3_SLOTS_BESIDE   448: ... when it runs beside a data-gradient chain (mi_conv_wgrad_partial)
     int wgrad_s4_slots;    // MI_WGRAD_S4_SLOTS   512: workgroup slots the 1x1 weight-gradient split picker plans for
     int wgrad_ti256;       // MI_WGRAD_TI256      -1: 128 x 256 weight-gradient tile by rule (0 never, 1 always)
     int wgrad_p3;          // MI_WGRAD_P3         0: 8-wave fused-row 3x3 weight gradient off (-DMI_EXPERIMENTS builds only)

@@ -279,7 +279,9 @@ def test_wgrad_full_size_linearity_and_reproducibility():
 def test_batched_slab_reducers_equal_the_one_call_weight_gradients_bit_for_bit():
     """K.WgradBatch (mi_conv_wgrad_partial x n + ONE mi_conv_wgrad_reduce launch: the three weight gradients of a bottleneck) against mi_conv_wgrad per
     conv: every kernel route (fused-row 3x3, deep-stream 1x1, the 128 x 256 tile, the per-tap kernel with stride 2), FrozenBN scale, accumulation,
-    a fifth job (a full batch flushes itself) - the same fixed summation order, hence the same bits."""
+    a fifth job (a full batch flushes itself) - the same fixed summation order, hence the same bits.  (At these sizes the 3x3 case takes the per-tap
+    kernel; the fused-row route, chosen from 256 x 256 channels up, is the one place where the two forms differ by design - the deferred form splits K for a
+    launch that runs beside a data-gradient chain, include/mi355seg.h - and is checked against the one-call result within fp32 rounding below.)"""
     g = torch.Generator(device="cpu").manual_seed(11)
     r = lambda *shape: torch.randn(shape, generator=g).to(DEV).to(torch.bfloat16)
     B, H, W = 2, 33, 29
@@ -306,6 +308,18 @@ def test_batched_slab_reducers_equal_the_one_call_weight_gradients_bit_for_bit()
     torch.cuda.synchronize()
     for i, (a, b) in enumerate(zip(got, want)):
         assert torch.equal(a, b), "job %d differs from the one-call weight gradient" % i
+    # fused-row 3x3 route (256 -> 256, enough pixels for >= 8 K steps per split): the two forms partition K differently; both are deterministic
+    dy, x = r(4, 65, 61, 256), r(4, 65, 61, 256)
+    one = torch.zeros((256, 256, 3, 3), device=DEV)
+    K.conv_wgrad(dy, x, one, 3, 1, 2, 2)
+    two = [torch.zeros_like(one) for _ in range(2)]
+    for t in two:
+        b2 = K.WgradBatch()
+        K.conv_wgrad(dy, x, t, 3, 1, 2, 2, batch=b2)
+        b2.flush()
+    torch.cuda.synchronize()
+    assert torch.equal(two[0], two[1])
+    assert float((two[0] - one).abs().max()) <= 2e-6 * float(one.abs().max()) + 1e-6
 
 
 # ------------------------------------------------------------------------------------------------ ASPP head chain
