@@ -59,6 +59,8 @@ def test_documented_divisibility_rules_are_enforced(built):
     assert gemm(12) == -22 and b"multiple of 8" in built.mi_last_error()
     assert gemm(8, Ca=48) == -22 and b"multiple of 32" in built.mi_last_error()
     assert gemm(8, Ca=32, stride=2, Ha=2) == -22 and b"not a multiple of 64" in built.mi_last_error()      # 32-channel slabs: the stride-1 main loop only
+    rc = built.mi_conv_gemm(one, one, one, 1, 1, 1, 96, 1, 1, 8, 1, 1, 0, 1, 0, None, None, one, None, None, 2, 0, 0.0, None)      # ... and no residual tile
+    assert rc == -22 and b"not a multiple of 64" in built.mi_last_error()
     assert gemm(8, flags=64, mask_out=one) == -22 and b"N % 16" in built.mi_last_error()
     # mi_conv_wgrad: out_map 1 is bounded by ncls and by the size of dw
     ws = ctypes.c_void_p(4096)
