@@ -146,7 +146,8 @@ def _tile_route(u, pixels):
     igemm_tn.hip: 128 .. 320-row MFMA tiles, LDS-DMA staging, 4x the throughput of the general kernel on large shapes): square 1x1 / 3x3 taps with one
     stride / padding / dilation, enough pixels to fill the chip, and channel counts that are either 64-multiples on both sides or - stride 1 - pad to
     32-multiples with less than 1.6x the work (HarDNet's gathered layers, 466 -> 168 as 480 -> 192: the general kernel's packs are zero-padded to 32 on
-    both sides, i.e. they ARE the [taps][N][Ca] operands of those kernels for the padded shape; round 5)."""
+    both sides, i.e. they ARE the [taps][N][Ca] operands of those kernels for the padded shape; round 5) - unless the padded Cin is no 64-multiple AND the
+    layer has fewer than 192 output columns: such a launch can only take the 256-column main loop and would leave most of it empty (152 -> 58, 218 -> 78)."""
     kh, kw, sh, sw, ph, pw, dh, dw = u.geom
     if u.depthwise or kh != kw or kh not in (1, 3) or sh != sw or ph != pw or dh != dw or pixels < 16384:
         return False
@@ -154,6 +155,8 @@ def _tile_route(u, pixels):
         return True
     ci, co = _rup32(u.cin), _rup32(u.cout)
     work = 2.0 * pixels * u.cin * u.cout * kh * kw              # the small ones stay where they are: nothing to win on a 5 GFLOP launch
+    if ci % 64 and co < 192:      # a padded Cin that only the 256-column main loop takes (mi_conv_gemm: Ca % 64 != 0), with too few output columns to fill it
+        return False
     return sh == 1 and 2 * ph == dh * (kh - 1) and work >= 8e9 and ci * co < 1.6 * u.cin * u.cout and os.environ.get("MI_TILE_PAD", "1") != "0"
 
 
