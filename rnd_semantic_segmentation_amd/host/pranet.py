@@ -141,6 +141,9 @@ def _rup32(c):
     return (c + 31) // 32 * 32
 
 
+_TILE_MIN_PIXELS = 16384          # below this the MFMA-tile kernels do not fill the chip (4096 measured: GALD 169.1 vs 170.1, PraNet 1040 vs 1046 images/s)
+
+
 def _tile_route(u, pixels):
     """Geometry half of _mfma_tile_ok: a conv whose shape the implicit-GEMM kernels of the DeepLab path can take (csrc/igemm_nt.hip / igemm_pp.hip /
     igemm_tn.hip: 128 .. 320-row MFMA tiles, LDS-DMA staging, 4x the throughput of the general kernel on large shapes): square 1x1 / 3x3 taps with one
@@ -149,7 +152,7 @@ def _tile_route(u, pixels):
     both sides, i.e. they ARE the [taps][N][Ca] operands of those kernels for the padded shape; round 5) - unless the padded Cin is no 64-multiple AND the
     layer has fewer than 192 output columns: such a launch can only take the 256-column main loop and would leave most of it empty (152 -> 58, 218 -> 78)."""
     kh, kw, sh, sw, ph, pw, dh, dw = u.geom
-    if u.depthwise or kh != kw or kh not in (1, 3) or sh != sw or ph != pw or dh != dw or pixels < 16384:
+    if u.depthwise or kh != kw or kh not in (1, 3) or sh != sw or ph != pw or dh != dw or pixels < _TILE_MIN_PIXELS:
         return False
     if u.cin % 64 == 0 and u.cout % 64 == 0:
         return True
