@@ -390,6 +390,12 @@ int mi_gbn_fold(const float* gamma, const float* beta, const float* running_mean
 /* out = act(y * scale[c] + shift[c] (+ add)); relu: 0 none, 1 ReLU, 2 ReLU6 (hardnet_68.py:78); out bf16, or fp32 when out_f32 */
 int mi_gbn_apply(const void* y, long ldy, const float* scale, const float* shift, const void* add, long ldadd, void* out, long ldo, int out_f32, long M, int C,
                  int relu, void* stream);
+/* mi_gbn_apply (bf16 output) with up to 4 extra destinations (round 5): channels [c0[k], c1[k]) of the result AS STORED (rounded to bf16), plus add2[k] when
+ * that is not NULL, also go to the view dst[k] (ldd[k] elements per pixel row; add2[k] likewise a view of c1 - c0 channels).  Replaces the stand-alone copies of
+ * a HarDBlock's gathers (reference hardnet_68.py:137-160), the pass-through group of a Res2Net bottleneck and its `sp = sp + spx[i]` (Res2Net_v1b.py:72-84)
+ * with bit-identical results.  `out` may be NULL when only the extra destinations are wanted.  The arrays are HOST memory (read during the call). */
+int mi_gbn_apply_multi(const void* y, long ldy, const float* scale, const float* shift, const void* add, long ldadd, void* out, long ldo, long M, int C, int relu,
+                       int n_extra, const int* c0, const int* c1, void* const* dst, const long* ldd, const void* const* add2, const long* lda2, void* stream);
 /* dbeta[c] (+)= sum_m g'[m][c], dgamma[c] (+)= sum_m g'[m][c] * (y[m][c] - mean[c]) * invstd[c]; g' = g where mask > 0 (mask: the layer's
  * ReLU output, or NULL); y NULL: dbeta only (a conv bias gradient).  g fp32 when g_f32; mask_f32 is a flag word: bit 0 = the mask is fp32,
  * bit 1 = the mask is a ReLU6 output (the gradient passes where 0 < mask < 6).  The same flags in mi_gbn_bwd_apply. */

@@ -91,6 +91,7 @@ SIGNATURES = {
     "mi_gbn_finalize": (I, [P, I, I, L, P, P, P, P, F, F, P, P, P, P, P]),
     "mi_gbn_fold": (I, [P, P, P, P, F, P, P, I, P]),
     "mi_gbn_apply": (I, [P, L, P, P, P, L, P, L, I, L, I, I, P]),
+    "mi_gbn_apply_multi": (I, [P, L, P, P, P, L, P, L, L, I, I, I, P, P, P, P, P, P, P]),
     "mi_gcolsum_workspace": (Z, [L, I]),
     "mi_gbn_bwd_sums": (I, [P, L, I, P, L, P, L, I, P, P, L, I, P, P, I, P, Z, P]),
     "mi_gbn_bwd_apply": (I, [P, L, I, P, L, P, L, I, P, P, P, P, P, F, P, L, L, I, P]),

@@ -169,6 +169,65 @@ __global__ __launch_bounds__(256) void gbn_apply_kernel(const __bf16* y, long ld
     }
 }
 
+// The same pass with up to four EXTRA destinations (round 5): channel range [c0, c1) of the result, as it is stored (rounded to bf16), optionally plus a second
+// operand, also goes to another view - what a stand-alone copy (HarDBlock gathers: hardnet_68.py:137-160; the pass-through group of a Res2Net bottleneck:
+// Res2Net_v1b.py:79-84) or a stand-alone add (sp = sp + spx[i], Res2Net_v1b.py:72-74) would produce from the stored tensor, bit for bit, without its launch
+// and without reading the tensor back.
+constexpr int APPLY_MAX_EXTRA = 4;
+struct GApplyExtras {
+    int n;
+    int c0[APPLY_MAX_EXTRA], c1[APPLY_MAX_EXTRA];
+    __bf16* dst[APPLY_MAX_EXTRA];
+    long ldd[APPLY_MAX_EXTRA];
+    const __bf16* add[APPLY_MAX_EXTRA];
+    long lda[APPLY_MAX_EXTRA];
+};
+template <int VEC>
+__global__ __launch_bounds__(256) void gbn_apply_multi_kernel(const __bf16* y, long ldy, const float* scale, const float* shift, const __bf16* add, long ldadd,
+                                                              __bf16* out, long ldo, long M, int C, int relu, GApplyExtras ex) {
+    const int cv = C / VEC;
+    const long n = M * cv;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const long m = e / cv;
+        const int c0 = (int)(e - m * cv) * VEC;
+        float v[VEC], a[VEC], sc[VEC], sh[VEC];
+        ldv<VEC>(y + m * ldy + c0, v);
+        ldp<VEC>(scale + c0, sc);
+        ldp<VEC>(shift + c0, sh);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[j] = v[j] * sc[j] + sh[j];
+        ldv<VEC>(add ? add + m * ldadd + c0 : reinterpret_cast<const __bf16*>(g_nzero), a);
+        if (add) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v[j] += a[j];
+        }
+        if (relu) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v[j] = relu == 2 ? fminf(fmaxf(v[j], 0.f), 6.f) : fmaxf(v[j], 0.f);
+        }
+        if (out) stv<VEC>(out + m * ldo + c0, v);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[j] = (float)(__bf16)v[j];            // the value a later pass would read back
+#pragma unroll
+        for (int k = 0; k < APPLY_MAX_EXTRA; ++k) {
+            if (k < ex.n && c0 >= ex.c0[k] && c0 < ex.c1[k]) {
+                const int cc = c0 - ex.c0[k];
+                float r[VEC];
+                if (ex.add[k]) {
+                    float b[VEC];
+                    ldv<VEC>(ex.add[k] + m * ex.lda[k] + cc, b);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) r[j] = v[j] + b[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) r[j] = v[j];
+                }
+                stv<VEC>(ex.dst[k] + m * ex.ldd[k] + cc, r);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ column sums (BatchNorm backward, bias gradients)
 // partial[blk][0][c] = sum_m g'[m][c], partial[blk][1][c] = sum_m g'[m][c] * (y[m][c] - mean[c]) * invstd[c] over the block's rows;
 // g' = g where mask[m][c] > 0 (mask = the layer's ReLU output) or g itself when mask is NULL; y NULL: the first sum only.
@@ -1007,6 +1066,41 @@ int mi_gbn_apply(const void* y, long ldy, const float* scale, const float* shift
     else if (vec == 2) hipLaunchKernelGGL((gbn_apply_kernel<2, __bf16>), dim3(grid_for(M * C / 2)), dim3(256), 0, s, yy, ldy, scale, shift, aa, ldadd, (__bf16*)out, ldo, M, C, relu);
     else hipLaunchKernelGGL((gbn_apply_kernel<1, __bf16>), dim3(grid_for(M * C)), dim3(256), 0, s, yy, ldy, scale, shift, aa, ldadd, (__bf16*)out, ldo, M, C, relu);
     MI_CHECK_LAUNCH("gbn_apply_kernel");
+    return MI_OK;
+}
+
+int mi_gbn_apply_multi(const void* y, long ldy, const float* scale, const float* shift, const void* add, long ldadd, void* out, long ldo, long M, int C, int relu,
+                       int n_extra, const int* c0, const int* c1, void* const* dst, const long* ldd, const void* const* add2, const long* lda2, void* stream) {
+    MI_REQUIRE(y && scale && shift, "mi_gbn_apply_multi: null operand");
+    MI_REQUIRE(M > 0 && C > 0 && ldy >= C && (!out || ldo >= C) && (!add || ldadd >= C), "mi_gbn_apply_multi: bad shape");
+    MI_REQUIRE(n_extra >= 0 && n_extra <= APPLY_MAX_EXTRA && (n_extra == 0 || (c0 && c1 && dst && ldd && add2 && lda2)), "mi_gbn_apply_multi: 0 .. %d extra destinations", APPLY_MAX_EXTRA);
+    MI_REQUIRE(out || n_extra > 0, "mi_gbn_apply_multi: nothing to write");
+    GApplyExtras ex;
+    ex.n = n_extra;
+    int vec = common_vec(C, {{y, ldy}, {out, ldo}, {add, ldadd}});
+    if (vec == 8 && ((reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15)) vec = 2;
+    for (int k = 0; k < APPLY_MAX_EXTRA; ++k) {
+        const bool live = k < n_extra;
+        ex.c0[k] = live ? c0[k] : 0;
+        ex.c1[k] = live ? c1[k] : 0;
+        ex.dst[k] = live ? (__bf16*)dst[k] : nullptr;
+        ex.ldd[k] = live ? ldd[k] : 0;
+        ex.add[k] = live ? (const __bf16*)add2[k] : nullptr;
+        ex.lda[k] = live ? lda2[k] : 0;
+        if (!live) continue;
+        const int w = c1[k] - c0[k];
+        MI_REQUIRE(dst[k] && c0[k] >= 0 && w > 0 && c1[k] <= C && ldd[k] >= w && (!add2[k] || lda2[k] >= w), "mi_gbn_apply_multi: extra destination %d: bad range or view", k);
+        int vk = common_vec(w, {{dst[k], ldd[k]}, {add2[k], lda2[k]}});          // the widest access this range and its views allow ...
+        while (vk > 1 && c0[k] % vk) vk = vk == 8 ? 2 : 1;                       // ... at a start channel that is a multiple of it
+        if (vk < vec) vec = vk;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const __bf16* yy = (const __bf16*)y;
+    const __bf16* aa = (const __bf16*)add;
+    if (vec == 8) hipLaunchKernelGGL((gbn_apply_multi_kernel<8>), dim3(grid_for(M * C / 8)), dim3(256), 0, s, yy, ldy, scale, shift, aa, ldadd, (__bf16*)out, ldo, M, C, relu, ex);
+    else if (vec == 2) hipLaunchKernelGGL((gbn_apply_multi_kernel<2>), dim3(grid_for(M * C / 2)), dim3(256), 0, s, yy, ldy, scale, shift, aa, ldadd, (__bf16*)out, ldo, M, C, relu, ex);
+    else hipLaunchKernelGGL((gbn_apply_multi_kernel<1>), dim3(grid_for(M * C)), dim3(256), 0, s, yy, ldy, scale, shift, aa, ldadd, (__bf16*)out, ldo, M, C, relu, ex);
+    MI_CHECK_LAUNCH("gbn_apply_multi_kernel");
     return MI_OK;
 }
 

@@ -248,6 +248,40 @@ def gbn_apply(y, scale, shift, relu, add=None, out=None, out_f32=False):
     return out
 
 
+APPLY_MAX_EXTRA = 4
+
+
+def gbn_apply_multi(y, scale, shift, relu, extras, add=None, out=None):
+    """gbn_apply (bf16) whose result also goes to other views: extras = [(c0, c1, dst, add2 or None), ...] (at most APPLY_MAX_EXTRA) - channels [c0, c1) of
+    the stored result (+ add2) into dst, what a copy / add kernel reading `out` back would write, bit for bit.  Returns out."""
+    B, H, W, C = y.shape
+    if out is None:
+        out = new(B, H, W, C, y.device)
+    n = len(extras)
+    if n > APPLY_MAX_EXTRA:
+        raise _lib.MiError("gbn_apply_multi: %d extra destinations (at most %d)" % (n, APPLY_MAX_EXTRA))
+    py, ldy = view(y, torch.bfloat16)
+    po, ldo = view(out, torch.bfloat16)
+    pa, lda = view(add, torch.bfloat16) if add is not None else (None, 0)
+    c0 = (ctypes.c_int * APPLY_MAX_EXTRA)()
+    c1 = (ctypes.c_int * APPLY_MAX_EXTRA)()
+    dst = (ctypes.c_void_p * APPLY_MAX_EXTRA)()
+    ldd = (ctypes.c_long * APPLY_MAX_EXTRA)()
+    add2 = (ctypes.c_void_p * APPLY_MAX_EXTRA)()
+    lda2 = (ctypes.c_long * APPLY_MAX_EXTRA)()
+    for k, (a0, a1, d, a2) in enumerate(extras):
+        if tuple(d.shape[:3]) != (B, H, W) or d.shape[-1] != a1 - a0 or (a2 is not None and tuple(a2.shape) != tuple(d.shape)):
+            raise _lib.MiError("gbn_apply_multi: extra destination %d is %s for channels [%d, %d) of %s" % (k, tuple(d.shape), a0, a1, tuple(y.shape)))
+        pd, l_d = view(d, torch.bfloat16)
+        c0[k], c1[k], dst[k], ldd[k] = int(a0), int(a1), pd.value, l_d
+        if a2 is not None:
+            p2, l2 = view(a2, torch.bfloat16)
+            add2[k], lda2[k] = p2.value, l2
+    check(_L().mi_gbn_apply_multi(py, ldy, _p(scale), _p(shift), pa, lda, po, ldo, B * H * W, C, int(relu), n, c0, c1, dst, ldd, add2, lda2, _stream()),
+          "mi_gbn_apply_multi")
+    return out
+
+
 def _gm(g, mask, relu6=False):
     pg, ldg = view(g)
     gf = g.dtype == torch.float32

@@ -211,26 +211,44 @@ def _hard_block(run, x, layers, links, out_ch):
         offs[i] = off
         off += layers[i - 1].cout
     outbuf = gk.new(B, H, W, out_ch, x.t.device, x.t.dtype)
-    outs = [x]
+    # the gather buffers of the layers with several links, allocated up front: a layer's BatchNorm apply writes its output into the block's buffer AND into
+    # the channel range it has in every later layer's gather (up to gk.APPLY_MAX_EXTRA of them; round 5) - only the block input is still copied
+    gathers = {}
     for li, (u, lk) in enumerate(zip(layers, links), 1):
         if len(lk) > 1:
-            cin = sum(outs[j].t.shape[-1] for j in lk)
+            widths = [x.t.shape[-1] if j == 0 else layers[j - 1].cout for j in lk]
+            cin = sum(widths)
             # a layer the MFMA-tile kernels take (pranet._tile_route: the big gathered layers, 466 -> 168 ...) reads a gather buffer of the 32-padded
             # channel count, pad channels zero: the kernels' operand as it is
             cbuf = _rup32(cin) if (not run.f32 and _tile_route(u, B * H * W)) else cin
             buf = gk.new(B, H, W, cbuf, x.t.device, x.t.dtype)
             if cbuf != cin:
                 buf[..., cin:].zero_()
-            pieces, o = [], 0
-            for j in lk:
-                c = outs[j].t.shape[-1]
-                pieces.append(run.copy_into(outs[j], buf[..., o:o + c]))
+            offs_j, o = {}, 0
+            for j, c in zip(lk, widths):
+                offs_j[j] = (o, c)
                 o += c
+            gathers[li] = (buf, offs_j)
+    outs, fused = [x], set()
+    for li, (u, lk) in enumerate(zip(layers, links), 1):
+        if len(lk) > 1:
+            buf, offs_j = gathers[li]
+            pieces = []
+            for j in lk:
+                o, c = offs_j[j]
+                pieces.append(run.alias_into(outs[j], buf[..., o:o + c]) if (j, li) in fused else run.copy_into(outs[j], buf[..., o:o + c]))
             inp = run.cat(buf, pieces)
         else:
             inp = outs[lk[0]]
         dst = outbuf[..., offs[li]:offs[li] + u.cout] if li in offs else None
-        outs.append(run.conv_bn(inp, u, 6, out=dst))
+        extras = []
+        if run.multi:
+            for l2 in sorted(gathers):
+                if l2 > li and li in gathers[l2][1] and len(extras) < gk.APPLY_MAX_EXTRA:
+                    o, c = gathers[l2][1][li]
+                    extras.append((0, u.cout, gathers[l2][0][..., o:o + c], None))
+                    fused.add((li, l2))
+        outs.append(run.conv_bn(inp, u, 6, out=dst, extras=extras or None))
     return run.cat(outbuf, [outs[i] for i in keep])
 
 

@@ -207,6 +207,8 @@ class _Run:
     def __init__(self, net, train, rec):
         self.net, self.train, self.rec, self.tape, self.side = net, train, rec, [], None
         self.wq, self.wq_slots, self.wq_fix = None, None, []            # weight gradients queued during backward (see _conv_backward)
+        # MI_APPLY_MULTI=0: every gather copy / hierarchical add as its own launch again (the BatchNorm apply then has one destination; same bits)
+        self.multi = os.environ.get("MI_APPLY_MULTI", "1") != "0"
         self.wq_bytes = 0
         # fp32: the evaluation forward in the reference's precision (csrc/gf32.hip; _Engine.set_precision): every activation fp32, every conv with
         # its eval()-BatchNorm affine, residual and activation in one launch
@@ -255,16 +257,27 @@ class _Run:
 
     # ---- conv (+ bias) + BatchNorm2d (+ add) (+ ReLU | ReLU6): BasicConv2d of PraNet_Res2Net.py:7-20, the conv/bn pairs of Res2Net_v1b.py,
     #      ConvLayer of hardnet_68.py:56-80 (relu=6), the conv(bias)-bn-relu stems of FAM (gcpa_gald.py:84-86)
-    def conv_bn(self, x, u, relu, add=None, out=None, out_f32=False):
+    def _apply(self, y, sc, sh, act, add, out, out_f32, extras):
+        """BatchNorm apply; `extras` = [(c0, c1, dst, add2 _Var or None), ...]: channel ranges of the result that also go elsewhere in the same launch."""
+        if not extras:
+            return gk.gbn_apply(y, sc, sh, act, add=add, out=out, out_f32=out_f32)
+        return gk.gbn_apply_multi(y, sc, sh, act, [(c0, c1, d, None if a2 is None else a2.t) for c0, c1, d, a2 in extras], add=add, out=out)
+
+    def conv_bn(self, x, u, relu, add=None, out=None, out_f32=False, extras=None):
         net, bn = self.net, u.bn
         act = 2 if relu == 6 else int(bool(relu))
         bias = None if u.bias is None else u.bias.detach()
+        if extras and out_f32:
+            raise _lib.MiError("conv_bn: extra destinations go with a bf16 output")
         if not self.train:
             sc, sh = net._eval_fold(u)
             if self.f32:
-                return self.var(gk.gconv_f32(x.t, u.weight.detach(), u.geom, bias=bias, scale=sc, shift=sh, add=None if add is None else add.t, relu=relu, out=out), False)
+                o = gk.gconv_f32(x.t, u.weight.detach(), u.geom, bias=bias, scale=sc, shift=sh, add=None if add is None else add.t, relu=relu, out=out)
+                for c0, c1, d, a2 in (extras or ()):          # fp32 evaluation: the extra destinations as their own element-wise launches
+                    gk.gbinary(gk.OP_COPY, o[..., c0:c1], out=d) if a2 is None else gk.gbinary(gk.OP_ADD, o[..., c0:c1], a2.t, out=d)
+                return self.var(o, False)
             y, _ = _conv_forward(x.t, u, bias, False, net=net)
-            return self.var(gk.gbn_apply(y, sc, sh, act, add=None if add is None else add.t, out=out, out_f32=out_f32), False)
+            return self.var(self._apply(y, sc, sh, act, None if add is None else add.t, out, out_f32, extras), False)
         hw = gk.conv_out_hw(x.t.shape[1], x.t.shape[2], *u.geom)
         if not _mfma_tile_ok(u, x.t) and gk.gconv_bn_fits(x.t.shape[0], *hw) and os.environ.get("MI_BN_INLAUNCH", "0") == "1":
             # small maps, opt-in (MI_BN_INLAUNCH=1): the conv's last workgroup finalizes the statistics itself (one launch instead of two; the same bits).
@@ -275,7 +288,7 @@ class _Run:
             y, st = _conv_forward(x.t, u, bias, True, net=net)
             M = y.shape[0] * y.shape[1] * y.shape[2]
             fin = gk.gbn_finalize(st, u.cout, M, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)      # mean, invstd, scale, shift
-        o = gk.gbn_apply(y, fin[2], fin[3], act, add=None if add is None else add.t, out=out, out_f32=out_f32)
+        o = self._apply(y, fin[2], fin[3], act, None if add is None else add.t, out, out_f32, extras)
         ov = self.var(o)
 
         def back():
@@ -429,6 +442,30 @@ class _Run:
         self.record(back)
         return ov
 
+    def added(self, a, b, t):
+        """The variable of t = a + b that a producer's apply has ALREADY written (conv_bn extras): binary(OP_ADD)'s place on the tape without its launch."""
+        ov = self.var(t)
+
+        def back():
+            g = ov.g
+            ov.g = None
+            if g is not None:
+                _acc(a, g, False)
+                _acc(b, g, False)
+        self.record(back)
+        return ov
+
+    def alias_into(self, a, out):
+        """copy_into whose copy the producer of `a` has already made (conv_bn extras)."""
+        ov = self.var(out)
+
+        def back():
+            if ov.g is not None:
+                _acc(a, ov.g, False)
+                ov.g = None
+        self.record(back)
+        return ov
+
     def copy_into(self, a, out):
         ov = self.var(gk.gbinary(gk.OP_COPY, a.t, out=out))
 
@@ -552,21 +589,32 @@ def _bottle2neck(run, x, blk):
     """Res2Net_v1b.py:63-92: 1x1 to four `width`-channel groups; groups 0..2 through 3x3 convs, each (in a 'normal' block) taking the
     previous group's output added to its own input; group 3 passes through ('normal') or through AvgPool2d(3, stride, 1) ('stage')."""
     w, s, stage = blk["width"], blk["stride"], blk["stage"]
-    o1 = run.conv_bn(x, blk["conv1"], True)
-    groups, slots = run.split(o1, w, 4)
-    B, H, W, _ = o1.t.shape
+    B, H, W = x.t.shape[0], x.t.shape[1], x.t.shape[2]
     Ho, Wo = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
     cat = gk.new(B, Ho, Wo, 4 * w, x.t.device, x.t.dtype)
-    pieces, prev, sums = [], None, []
+    # 'normal' blocks (round 5): what used to be three element-wise launches comes out of the BatchNorm applies that produce the operands - conv1's apply also
+    # writes the pass-through group into its slot of the concatenation, the apply of branch i also writes (its output + group i+1) = the next branch's input
+    fuse = run.multi and not stage
+    o1 = run.conv_bn(x, blk["conv1"], True, extras=[(3 * w, 4 * w, cat[..., 3 * w:], None)] if fuse else None)
+    groups, slots = run.split(o1, w, 4)
+    pieces, prev, sums, ahead = [], None, [], None
     for i in range(3):
         if i == 0 or stage:
             inp = groups[i]
+        elif ahead is not None:
+            inp = ahead
+            sums.append((inp, groups[i]))
         else:
             inp = run.binary(gk.OP_ADD, prev, groups[i])
             sums.append((inp, groups[i]))
-        prev = run.conv_bn(inp, blk["convs"][i], True, out=cat[..., i * w:(i + 1) * w])
+        nxt = gk.new(B, Ho, Wo, w, x.t.device, x.t.dtype) if (fuse and i < 2) else None
+        prev = run.conv_bn(inp, blk["convs"][i], True, out=cat[..., i * w:(i + 1) * w], extras=None if nxt is None else [(0, w, nxt, groups[i + 1])])
+        ahead = None if nxt is None else run.added(prev, groups[i + 1], nxt)
         pieces.append(prev)
-    pieces.append(run.avgpool(groups[3], 3, s, 1, True, out=cat[..., 3 * w:]) if stage else run.copy_into(groups[3], cat[..., 3 * w:]))
+    if stage:
+        pieces.append(run.avgpool(groups[3], 3, s, 1, True, out=cat[..., 3 * w:]))
+    else:
+        pieces.append(run.alias_into(groups[3], cat[..., 3 * w:]) if fuse else run.copy_into(groups[3], cat[..., 3 * w:]))
     catv = run.cat(cat, pieces)
     if blk["down"] is not None:
         res = run.conv_bn(x if s == 1 else run.avgpool(x, s, s, 0, False), blk["down"], False)       # AvgPool2d(1, 1) is the identity

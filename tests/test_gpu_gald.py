@@ -388,3 +388,39 @@ def test_gald_fused_loss_heads_equal_the_materialised_path():
     gmax = max(float(v.norm()) for v in gb.values())
     worst = max(1 - _cos(ga[k].cpu().numpy(), gb[k].cpu().numpy()) for k in ga if float(gb[k].norm()) > 1e-3 * gmax)
     assert worst < 1e-2, worst
+
+
+@pytest.mark.parametrize("which", ["hardblock", "bottle2neck", "bottle2neck_stage"])
+def test_applies_with_extra_destinations_leave_every_bit_of_a_block_unchanged(which, monkeypatch):
+    """Round 5: a HarDBlock layer's BatchNorm apply also writes its output into the later layers' gather buffers, a Res2Net bottleneck's applies also write the
+    pass-through group and the next branch's input (mi_gbn_apply_multi) - launches removed, values not: output, input gradient and every parameter gradient of
+    the block are EQUAL BIT FOR BIT to the run with MI_APPLY_MULTI=0 (one launch per copy / add), in train() and in eval()."""
+    from rnd_semantic_segmentation_amd.host import gald, pranet
+    if which == "hardblock":
+        make, shape = (lambda: gald.HarDBlock(64, 14, 1.7, 8)), (2, 64, 24, 20)
+    elif which == "bottle2neck":
+        make, shape = (lambda: pranet.Bottle2neck(256, 64, stride=1, downsample=None, baseWidth=26, scale=4, stype="normal")), (2, 256, 22, 18)
+    else:
+        make, shape = (lambda: pranet.Bottle2neck(64, 64, stride=1, downsample=True, baseWidth=26, scale=4, stype="stage")), (2, 64, 22, 18)
+    x0 = torch.from_numpy(np.maximum(_u("multi.x." + which, shape, 3), 0))
+    res = []
+    for multi in ("1", "0"):
+        monkeypatch.setenv("MI_APPLY_MULTI", multi)
+        torch.manual_seed(5)
+        mod = make()
+        synth.load_formula_weights(mod, prefix="multi." + which + ".", bn_bias=synth.COND_BN_BIAS)
+        mod.cuda().train()
+        x = x0.clone().cuda().requires_grad_(True)
+        y = mod(x)
+        (y.float() * torch.linspace(-1, 1, y.numel(), device="cuda").view_as(y)).sum().backward()
+        grads = {k: p.grad.detach().clone() for k, p in mod.named_parameters() if p.grad is not None}
+        mod.eval()
+        with torch.no_grad():
+            ye = mod(x0.clone().cuda())
+        torch.cuda.synchronize()
+        res.append((y.detach().clone(), x.grad.detach().clone(), grads, ye.detach().clone()))
+    (ya, dxa, ga, ea), (yb, dxb, gb, eb) = res
+    assert torch.equal(ya, yb) and torch.equal(dxa, dxb) and torch.equal(ea, eb)
+    assert ga.keys() == gb.keys() and len(ga) > 0
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), k

@@ -394,3 +394,36 @@ def test_elementwise_and_reverse_attention(gk):
     dfeat, dgate = gk.gra_bwd(gt, _nhwc(feat).cuda(), _nhwc(dy).cuda())
     _close_bf16(dfeat.permute(0, 3, 1, 2), fd.grad, "reverse attention dfeat")
     assert float((dgate.permute(0, 3, 1, 2).double().cpu() - gd.grad).abs().max()) < 1e-4 * float(gd.grad.abs().max()) + 1e-5
+
+
+@pytest.mark.parametrize("C,ranges,relu", [(104, [(78, 104, False), (0, 26, True)], 1), (40, [(0, 40, False), (0, 40, False), (8, 24, True)], 2),
+                                           (256, [(0, 256, True), (64, 128, False), (0, 8, False), (248, 256, True)], 0)])
+def test_batchnorm_apply_with_extra_destinations_equals_the_separate_launches(gk, C, ranges, relu):
+    """mi_gbn_apply_multi: channel ranges of the result, as stored, also go to other views in the same launch - optionally plus a second operand.  Against
+    mi_gbn_apply followed by the copy / add launches it replaces (mi_gbinary on the stored tensor): EQUAL BIT FOR BIT, for 2-byte (26-channel Res2Net groups),
+    16-byte and mixed alignments, channel-slice views on both sides, with and without the residual operand of the apply itself."""
+    B, H, W = 2, 9, 7
+    dev = "cuda"
+    y = _nhwc(_rand((B, C, H, W), 3)).to(dev).to(torch.bfloat16)
+    sc = (_rand((C,), 4).float() * 0.5 + 1.0).to(dev)
+    sh = _rand((C,), 5).float().to(dev)
+    res = _nhwc(_rand((B, C, H, W), 6)).to(dev).to(torch.bfloat16) if relu != 2 else None
+    want_out = gk.gbn_apply(y, sc, sh, relu, add=res)
+    extras, want = [], []
+    for k, (c0, c1, with_add) in enumerate(ranges):
+        wide = torch.full((B, H, W, (c1 - c0) + 6), 7.0, dtype=torch.bfloat16, device=dev)          # destination = a channel slice of a wider buffer
+        dst = wide[..., 2:2 + (c1 - c0)] if (c1 - c0) % 8 else wide[..., :c1 - c0]
+        a2 = _nhwc(_rand((B, c1 - c0, H, W), 10 + k)).to(dev).to(torch.bfloat16) if with_add else None
+        extras.append((c0, c1, dst, a2))
+        src = want_out[..., c0:c1]
+        want.append(gk.gbinary(gk.OP_ADD, src, a2) if with_add else gk.gbinary(gk.OP_COPY, src))
+    out = gk.gbn_apply_multi(y, sc, sh, relu, extras, add=res)
+    torch.cuda.synchronize()
+    assert torch.equal(out, want_out)
+    for k, ((c0, c1, dst, a2), w) in enumerate(zip(extras, want)):
+        assert torch.equal(dst, w), "extra destination %d (channels %d..%d) differs from the separate launch" % (k, c0, c1)
+        full, off = dst._base, dst.storage_offset() % dst._base.shape[-1]
+        assert bool((full[..., :off] == 7.0).all()) and bool((full[..., off + (c1 - c0):] == 7.0).all())        # nothing outside the view was touched
+    from rnd_semantic_segmentation_amd._lib import MiError
+    with pytest.raises(MiError):
+        gk.gbn_apply_multi(y, sc, sh, relu, extras * 3)                                               # more than four destinations
