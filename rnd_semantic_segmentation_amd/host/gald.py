@@ -30,6 +30,7 @@ from .pranet import FlatAdam, _acc, _Engine, _grad_target, _Run, _rup32, _tile_r
 
 
 class _GaldRun(_Run):
+    WGRAD_STREAM = True           # GALD trains eagerly and its weight gradients are few and large: +1.5 % with them beside the data-gradient chain
     def maxpool(self, x, k, stride, pad):
         H, W = x.t.shape[1], x.t.shape[2]
         if self.f32:

@@ -203,6 +203,7 @@ def _grad_target(v):
 
 class _Run:
     """One forward pass.  train: BatchNorm2d on batch statistics (module.training); rec: record the backward tape."""
+    WGRAD_STREAM = False          # the large weight gradients of backward() on the side stream (see _conv_backward)
 
     def __init__(self, net, train, rec):
         self.net, self.train, self.rec, self.tape, self.side = net, train, rec, [], None
@@ -329,20 +330,29 @@ class _Run:
         """Weight gradient (off the critical path: nothing reads it before the optimizer, so it runs on the side stream beside the data-gradient
         chain - the convs of these nets are far too small to fill 256 CUs alone) and data gradient."""
         slot, acc = self.net._grad_slot(u.weight)
-        # MI_TAPE_WGRAD_STREAM=1 (off by default).  Measured: every weight gradient on the side stream costs PraNet 6 % as a graph and 18 % eager
-        # (hundreds of 20-60 us launches, each fork / join a dependency the GPU has to resolve); only the launches of >= 8 GFLOP there: PraNet still
-        # -10 % as a graph (659 vs 734 images/s: a second stream in the capture changes how the whole graph is scheduled), GALD +1 % (110.9 vs 109.7)
+        # MI_TAPE_WGRAD_STREAM (default: the run class's WGRAD_STREAM - off for PraNet, on for GALD).  Measured: every weight gradient on the side stream costs
+        # PraNet 6 % as a graph and 18 % eager (hundreds of 20-60 us launches, each fork / join a dependency the GPU has to resolve); only the launches of
+        # >= 8 GFLOP there: PraNet still -10 % as a graph (659 vs 734 images/s: a second stream in the capture changes how the whole graph is scheduled),
+        # GALD (eager, its decoder's and padded gathers' weight gradients are 100 - 400 us launches) +1.5 % (175.6 vs 173.0 images/s, round 5)
         work = 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * u.cout * (1 if u.depthwise else u.cin) * u.geom[0] * u.geom[1]
         side = self.side if work >= 8e9 else None
         if _mfma_tile_ok(u, x.t) and dy.is_contiguous() and dy.shape[-1] == _rup32(u.cout):
             k, s, p, d = u.geom[0], u.geom[2], u.geom[4], u.geom[6]
             np_, cp = _rup32(u.cout), _rup32(u.cin)
+            def wgrad(dw, accumulate):
+                # on the side stream the launch runs beside the data-gradient chain: the deferred-reducer form plans its split for that (mi_conv_wgrad_partial)
+                if side is not None:                     # (GALD: 176.6 vs 175.9 images/s)
+                    b = K.WgradBatch()
+                    K.conv_wgrad(dy, x.t, dw, k, s, p, d, accumulate=accumulate, batch=b)
+                    b.flush()
+                else:
+                    K.conv_wgrad(dy, x.t, dw, k, s, p, d, accumulate=accumulate)
             if np_ == u.cout and cp == u.cin:
-                _off_path(side, lambda: K.conv_wgrad(dy, x.t, slot, k, s, p, d, accumulate=acc), dy, x.t)
+                _off_path(side, lambda: wgrad(slot, acc), dy, x.t)
             else:           # padded operands: the gradient of the padded weight, its real corner into the parameter's slot
                 def padded_wgrad():
                     wide = torch.empty((np_, cp, k, k), dtype=torch.float32, device=dy.device)
-                    K.conv_wgrad(dy, x.t, wide, k, s, p, d)
+                    wgrad(wide, False)
                     slot.add_(wide[:u.cout, :u.cin]) if acc else slot.copy_(wide[:u.cout, :u.cin])
                 _off_path(side, padded_wgrad, dy, x.t)
             if x.needs:
@@ -572,7 +582,7 @@ class _Run:
         self.wq_bytes = 0
 
     def backward(self):
-        self.side = _SideStream.get(self.net._store.data.device) if os.environ.get("MI_TAPE_WGRAD_STREAM", "0") == "1" else None
+        self.side = _SideStream.get(self.net._store.data.device) if os.environ.get("MI_TAPE_WGRAD_STREAM", "1" if self.WGRAD_STREAM else "0") == "1" else None
         self.wq, self.wq_slots = ([], set()) if os.environ.get("MI_WGRAD_BATCH", "1") != "0" else (None, None)
         self.wq_fix = []
         for fn in reversed(self.tape):
