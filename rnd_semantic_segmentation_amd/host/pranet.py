@@ -108,6 +108,7 @@ def _basic(name, cin, cout, k, pad=0):
     return _Unit(name + ".conv", name + ".bn", cin, cout, k, 1, pad)
 
 
+_SIDE_MIN_WORK = 8e9          # weight gradients at least this large go to the side stream one by one (GALD: flat from 2 to 16 GFLOP; none: -3 %)
 _WQ_BUDGET = int(float(os.environ.get("MI_WGRAD_QUEUE_MB", "2048")) * (1 << 20))
 # With a side stream (GALD) the queue is flushed every few convs, so that the table-driven launches run beside the data-gradient chain instead of alone at the end
 # of the tape: 4 jobs per launch 176.8 images/s, 8: 175.9, 2: 175.3, 16: 174.0, only at the end: 172.1 (one box, two rounds)
@@ -338,7 +339,7 @@ class _Run:
         # >= 8 GFLOP there: PraNet still -10 % as a graph (659 vs 734 images/s: a second stream in the capture changes how the whole graph is scheduled),
         # GALD (eager, its decoder's and padded gathers' weight gradients are 100 - 400 us launches) +1.5 % (175.6 vs 173.0 images/s, round 5)
         work = 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * u.cout * (1 if u.depthwise else u.cin) * u.geom[0] * u.geom[1]
-        side = self.side if work >= 8e9 else None
+        side = self.side if work >= _SIDE_MIN_WORK else None
         if _mfma_tile_ok(u, x.t) and dy.is_contiguous() and dy.shape[-1] == _rup32(u.cout):
             k, s, p, d = u.geom[0], u.geom[2], u.geom[4], u.geom[6]
             np_, cp = _rup32(u.cout), _rup32(u.cin)
